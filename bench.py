@@ -1,0 +1,195 @@
+"""bench.py -- headline benchmark of the MI355X-native HEXL hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: an
+in-place forward NTT (input_mod_factor = output_mod_factor = 1) followed by an
+in-place inverse NTT over 4096 polynomials of degree N = 65536 with a 55-bit
+prime (BASELINE.json configs[2]; at --gpus G > 1 rank g transforms the 4096
+polynomials of RNS prime g, configs[3]: embarrassingly parallel, no data-path
+collective, weak scaling).  Inputs are generated on the device (splitmix64) and
+are resident in HBM before the timed region starts.
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement):
+value = Fwd+Inv NTTs per second over the whole job; `roofline` = algorithmic
+bytes (16*N per transform) of the dominant kernel per launch /
+its average duration, measured with HIP events on the launch stream inside the
+timed region; `cpu_baseline` = the oracle's scalar Harvey NTT (a port of the
+reference's native path, oracle/hexl_oracle.c) on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N = 65536
+BATCH = 4096
+# GeneratePrimes(8, 54, true, 65536): the 8 RNS primes of BASELINE configs[3]
+# (tests/golden/hexl_kat.json generate_primes_survey_probe)
+PRIMES = [18014398510661633, 18014398512365569, 18014398514200577, 18014398514987009,
+          18014398515511297, 18014398516559873, 18014398521016321, 18014398524424193]
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def cpu_baseline(seconds_single=4.0, seconds_all=8.0):
+    """Oracle (port of the reference's native radix-2 path) on the host cores.
+
+    Bounded sample: single-thread for ~4 s, then one worker per core (capped at
+    64 threads) for ~8 s, each worker looping fwd+inv over its own polynomial.
+    """
+    import ctypes as C
+
+    import numpy as np
+
+    from oracle import hexl_oracle as ho
+
+    q = PRIMES[0]
+    plan = ho.lib.ho_ntt_create(N, q, 0)
+    cores = min(os.cpu_count() or 1, 64)
+
+    def worker(seed, deadline, counts, idx):
+        buf = ho.fill_splitmix(N, seed, q)
+        p = buf.ctypes.data_as(C.POINTER(C.c_uint64))
+        done = 0
+        while time.perf_counter() < deadline:
+            for _ in range(4):
+                ho.lib.ho_ntt_forward_batch(plan, p, p, 1, 1, 1)
+                ho.lib.ho_ntt_inverse_batch(plan, p, p, 1, 1, 1)
+            done += 8
+        counts[idx] = done
+
+    def run(nthreads, seconds):
+        counts = [0] * nthreads
+        t0 = time.perf_counter()
+        deadline = t0 + seconds
+        ts = [threading.Thread(target=worker, args=(1 + i, deadline, counts, i))
+              for i in range(nthreads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        return sum(counts) / (time.perf_counter() - t0)
+
+    single = run(1, seconds_single)
+    allc = run(cores, seconds_all)
+    ho.lib.ho_ntt_destroy(plan)
+    return {
+        "value": allc, "unit": "NTT/s", "cores": cores, "kind": "port",
+        "single_thread_value": single,
+        "sample": (f"oracle scalar Harvey radix-2 fwd+inv NTT, N={N}, q={q} (55-bit), "
+                   f"1 poly per thread in place; 1 thread x {seconds_single:.0f} s then "
+                   f"{cores} threads x {seconds_all:.0f} s"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH, help=argparse.SUPPRESS)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    import torch
+
+    import hexl_amd as hx
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    batch = args.batch
+    q = PRIMES[rank % len(PRIMES)]
+    ntt = hx.NTT(N, q)
+    data = torch.empty((batch, N), dtype=torch.int64, device="cuda")
+    hx.fill_splitmix(data, N, batch, 1 + rank * batch, q)
+    check = data[:2].clone()
+
+    def step():
+        ntt.ComputeForward(data, data, 1, 1)
+        ntt.ComputeInverse(data, data, 1, 1)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    hx.profile_start(8 * args.steps + 16)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    records = hx.profile_stop()
+    # fwd followed by inv is the identity: the data must be back where it started
+    assert torch.equal(check, data[:2]), "round trip mismatch inside the timed region"
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ntts = 2 * batch * args.steps * world
+    value = ntts / elapsed
+    kern = {}
+    for name, ms in records:
+        kern.setdefault(name, []).append(ms)
+    kern_avg = {k: sum(v) / len(v) for k, v in kern.items()}
+    dominant = max(kern_avg, key=lambda k: kern_avg[k] * len(kern[k]))
+    alg_bytes = 16.0 * N * batch  # this kernel reads and writes every polynomial once
+    achieved = alg_bytes / (kern_avg[dominant] * 1e-3) / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "Fwd+Inv NTTs/sec, N=65536 q~55b batch=4096",
+            "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {
+                "workload": ("in-place ForwardNTT(1,1) + InverseNTT(1,1), N=65536, "
+                             f"55-bit prime per GPU, batch={batch} polys per GPU resident in HBM"),
+                "N": N, "batch_per_gpu": batch, "modulus_bits": 55,
+                "primes": PRIMES[:max(1, min(world, 8))],
+                "parallelism": f"batch-sharded x{world}, no collectives"},
+            "hbm_algorithmic_GBps": value * 16.0 * N / 1e9,
+            "roofline": {
+                "bound": "hbm", "kernel": dominant, "achieved": achieved,
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_kernel_ms": kern_avg,
+                "note": ("per-kernel HIP-event timing on the launch stream inside the timed "
+                         "region; every kernel of the transform is listed in avg_kernel_ms")},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        elif world > 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

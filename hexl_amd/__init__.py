@@ -1,0 +1,383 @@
+"""hexl_amd -- MI355X-native NTT / Eltwise hot path of intel/hexl.
+
+Python host-side mirror of the reference's operator interface
+(``intel::hexl::NTT``, ``intel::hexl::Eltwise*``; hexl/include/hexl/ntt/ntt.hpp,
+hexl/include/hexl/eltwise/*.hpp) over the C-ABI of ``include/hexl_amd.h``.
+Names, argument meaning and error behaviour follow the reference; operands are
+device-resident ``torch`` tensors (``torch.int64`` / ``torch.uint64`` storage
+holding uint64 words), and a leading batch dimension is allowed everywhere a
+polynomial is expected.  PyTorch is used for device memory and streams only.
+
+There is no CPU fallback: importing works without a GPU (so the library's
+symbols can be checked), but every compute call raises ``HexlAmdError`` unless
+the HIP kernels can run.
+"""
+import ctypes as C
+import os
+
+try:
+    # torch bundles its own libamdhip64.so.7; it has to be the first HIP runtime
+    # mapped into the process, or two runtimes end up half-initialised.
+    import torch as _torch_first  # noqa: F401
+except ImportError:  # pure ctypes use without torch: the system ROCm runtime
+    _torch_first = None
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libhexl_amd.so")
+
+__all__ = [
+    "NTT", "EltwiseAddMod", "EltwiseSubMod", "EltwiseMultMod", "EltwiseFMAMod",
+    "EltwiseReduceMod", "EltwiseReduceFMAMod", "HexlAmdError", "lib", "LIB_PATH",
+    "MinimalPrimitiveRoot", "GeneratePrimes", "IsPrime", "InverseMod", "MultiplyMod",
+    "PowMod", "IsPrimitiveRoot", "ReverseBits", "MultiplyFactor", "fill_splitmix",
+    "from_numpy", "to_numpy",
+]
+
+LIB_PATH = _LIB_PATH
+
+
+class HexlAmdError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise HexlAmdError(
+            f"{_LIB_PATH} is missing: build it with `python -m hexl_amd.build` "
+            "(hipcc, gfx950). hexl_amd has no CPU fallback.")
+    lib = C.CDLL(_LIB_PATH)
+    u64, p64, vp, ci = C.c_uint64, C.c_void_p, C.c_void_p, C.c_int
+
+    def sig(name, res, *args):
+        f = getattr(lib, name)
+        f.restype = res
+        f.argtypes = list(args)
+
+    sig("hexl_amd_last_error", C.c_char_p)
+    sig("hexl_amd_device_count", ci, C.POINTER(ci))
+    sig("hexl_amd_ntt_create", ci, C.POINTER(vp), u64, u64, u64, ci)
+    sig("hexl_amd_ntt_destroy", ci, vp)
+    sig("hexl_amd_ntt_degree", u64, vp)
+    sig("hexl_amd_ntt_modulus", u64, vp)
+    sig("hexl_amd_ntt_root_of_unity", u64, vp)
+    sig("hexl_amd_ntt_device", ci, vp)
+    sig("hexl_amd_ntt_table", C.POINTER(u64), vp, ci)
+    for name in ("hexl_amd_ntt_forward", "hexl_amd_ntt_inverse"):
+        sig(name, ci, vp, p64, p64, u64, u64, u64, vp)
+    for name in ("hexl_amd_ntt_forward_rns", "hexl_amd_ntt_inverse_rns"):
+        sig(name, ci, C.POINTER(vp), u64, p64, p64, u64, u64, u64, vp)
+    for name in ("hexl_amd_ntt_forward_host", "hexl_amd_ntt_inverse_host"):
+        sig(name, ci, vp, p64, p64, u64, u64, u64)
+    sig("hexl_amd_eltwise_add_mod", ci, p64, p64, p64, u64, u64, vp)
+    sig("hexl_amd_eltwise_add_mod_scalar", ci, p64, p64, u64, u64, u64, vp)
+    sig("hexl_amd_eltwise_sub_mod", ci, p64, p64, p64, u64, u64, vp)
+    sig("hexl_amd_eltwise_sub_mod_scalar", ci, p64, p64, u64, u64, u64, vp)
+    sig("hexl_amd_eltwise_mult_mod", ci, p64, p64, p64, u64, u64, u64, vp)
+    sig("hexl_amd_eltwise_fma_mod", ci, p64, p64, u64, p64, u64, u64, u64, vp)
+    sig("hexl_amd_eltwise_reduce_mod", ci, p64, p64, u64, u64, u64, u64, vp)
+    sig("hexl_amd_eltwise_reduce_fma_mod", ci, p64, p64, u64, p64, u64, u64, u64, vp)
+    sig("hexl_amd_eltwise_host", ci, ci, p64, p64, p64, u64, u64, u64, u64, u64)
+    sig("hexl_amd_multiply_factor", u64, u64, u64, u64)
+    sig("hexl_amd_inverse_mod", u64, u64, u64)
+    sig("hexl_amd_multiply_mod", u64, u64, u64, u64)
+    sig("hexl_amd_pow_mod", u64, u64, u64, u64)
+    sig("hexl_amd_is_primitive_root", ci, u64, u64, u64)
+    sig("hexl_amd_generate_primitive_root", u64, u64, u64)
+    sig("hexl_amd_minimal_primitive_root", u64, u64, u64)
+    sig("hexl_amd_reverse_bits", u64, u64, u64)
+    sig("hexl_amd_is_prime", ci, u64)
+    sig("hexl_amd_generate_primes", C.c_size_t, C.POINTER(u64), C.c_size_t, C.c_size_t, ci,
+        C.c_size_t)
+    sig("hexl_amd_ntt_check_arguments", ci, u64, u64)
+    sig("hexl_amd_fill_splitmix", ci, p64, u64, u64, u64, u64, vp)
+    sig("hexl_amd_profile_start", ci, ci)
+    sig("hexl_amd_profile_stop", ci, C.POINTER(ci))
+    sig("hexl_amd_profile_get", ci, ci, C.POINTER(C.c_char_p), C.POINTER(C.c_float))
+    return lib
+
+
+lib = _load()
+
+# Every symbol include/hexl_amd.h declares (checked by tests/test_capi_symbols.py)
+C_ABI_SYMBOLS = [
+    "hexl_amd_last_error", "hexl_amd_device_count", "hexl_amd_ntt_create",
+    "hexl_amd_ntt_destroy", "hexl_amd_ntt_degree", "hexl_amd_ntt_modulus",
+    "hexl_amd_ntt_root_of_unity", "hexl_amd_ntt_device", "hexl_amd_ntt_table",
+    "hexl_amd_ntt_forward", "hexl_amd_ntt_inverse", "hexl_amd_ntt_forward_rns",
+    "hexl_amd_ntt_inverse_rns", "hexl_amd_ntt_forward_host", "hexl_amd_ntt_inverse_host",
+    "hexl_amd_eltwise_add_mod", "hexl_amd_eltwise_add_mod_scalar", "hexl_amd_eltwise_sub_mod",
+    "hexl_amd_eltwise_sub_mod_scalar", "hexl_amd_eltwise_mult_mod", "hexl_amd_eltwise_fma_mod",
+    "hexl_amd_eltwise_reduce_mod", "hexl_amd_eltwise_reduce_fma_mod", "hexl_amd_eltwise_host",
+    "hexl_amd_multiply_factor", "hexl_amd_inverse_mod", "hexl_amd_multiply_mod",
+    "hexl_amd_pow_mod", "hexl_amd_is_primitive_root", "hexl_amd_generate_primitive_root",
+    "hexl_amd_minimal_primitive_root", "hexl_amd_reverse_bits", "hexl_amd_is_prime",
+    "hexl_amd_generate_primes", "hexl_amd_ntt_check_arguments", "hexl_amd_fill_splitmix",
+    "hexl_amd_profile_start", "hexl_amd_profile_stop", "hexl_amd_profile_get",
+]
+
+
+def _check(rc):
+    if rc != 0:
+        raise HexlAmdError(lib.hexl_amd_last_error().decode() or f"hexl_amd error {rc}")
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _require_gpu():
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise HexlAmdError("no MI355X visible: hexl_amd has no CPU fallback")
+    return torch
+
+
+def _ptr(t):
+    torch = _torch()
+    if not isinstance(t, torch.Tensor):
+        raise HexlAmdError("expected a torch tensor")
+    if not t.is_cuda:
+        raise HexlAmdError("expected a device (cuda) tensor; host tensors go through the "
+                           "C-ABI *_host entry points")
+    if t.dtype not in (torch.int64, torch.uint64):
+        raise HexlAmdError(f"expected int64/uint64 storage, got {t.dtype}")
+    if not t.is_contiguous():
+        raise HexlAmdError("expected a contiguous tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+def from_numpy(a, device="cuda"):
+    """uint64 numpy array -> device tensor (int64 storage, same bits)."""
+    import numpy as np
+    torch = _require_gpu()
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return torch.from_numpy(a.view(np.int64)).to(device)
+
+
+def to_numpy(t):
+    """device tensor -> uint64 numpy array."""
+    import numpy as np
+    torch = _torch()
+    if t.dtype == torch.uint64:
+        t = t.view(torch.int64)
+    return t.detach().cpu().numpy().view(np.uint64)
+
+
+# ----------------------------------------------------------------------------
+# number theory (host) -- hexl/include/hexl/number-theory/number-theory.hpp
+# ----------------------------------------------------------------------------
+def MultiplyFactor(operand, bit_shift, modulus):
+    return lib.hexl_amd_multiply_factor(operand, bit_shift, modulus)
+
+
+def InverseMod(x, modulus):
+    return lib.hexl_amd_inverse_mod(x, modulus)
+
+
+def MultiplyMod(x, y, modulus):
+    return lib.hexl_amd_multiply_mod(x, y, modulus)
+
+
+def PowMod(base, exp, modulus):
+    return lib.hexl_amd_pow_mod(base, exp, modulus)
+
+
+def IsPrimitiveRoot(root, degree, modulus):
+    return bool(lib.hexl_amd_is_primitive_root(root, degree, modulus))
+
+
+def MinimalPrimitiveRoot(degree, modulus):
+    return lib.hexl_amd_minimal_primitive_root(degree, modulus)
+
+
+def ReverseBits(x, bit_width):
+    return lib.hexl_amd_reverse_bits(x, bit_width)
+
+
+def IsPrime(n):
+    return bool(lib.hexl_amd_is_prime(n))
+
+
+def GeneratePrimes(num_primes, bit_size, prefer_small_primes, ntt_size=1):
+    out = (C.c_uint64 * num_primes)()
+    found = lib.hexl_amd_generate_primes(out, num_primes, bit_size,
+                                         int(bool(prefer_small_primes)), ntt_size)
+    if found != num_primes:
+        raise HexlAmdError("Failed to find enough primes")
+    return [int(x) for x in out]
+
+
+# ----------------------------------------------------------------------------
+# NTT -- hexl/include/hexl/ntt/ntt.hpp:22-293
+# ----------------------------------------------------------------------------
+class NTT:
+    """Negacyclic forward / inverse NTT plan resident on one GPU.
+
+    Mirrors ``intel::hexl::NTT``: ``NTT(degree, q)`` or
+    ``NTT(degree, q, root_of_unity)``.  ``ComputeForward(result, operand,
+    input_mod_factor, output_mod_factor)`` and ``ComputeInverse`` take device
+    tensors of ``k * degree`` words (k >= 1 polynomials, back to back);
+    ``result`` may be ``operand``.
+    """
+
+    def __init__(self, degree, q, root_of_unity=0, device=None):
+        torch = _require_gpu()
+        if device is None:
+            device = torch.cuda.current_device()
+        h = C.c_void_p()
+        _check(lib.hexl_amd_ntt_create(C.byref(h), degree, q, root_of_unity, int(device)))
+        self._h = h
+        self._device = int(device)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.hexl_amd_ntt_destroy(h)
+
+    @staticmethod
+    def CheckArguments(degree, modulus):
+        return bool(lib.hexl_amd_ntt_check_arguments(degree, modulus))
+
+    def GetDegree(self):
+        return lib.hexl_amd_ntt_degree(self._h)
+
+    def GetModulus(self):
+        return lib.hexl_amd_ntt_modulus(self._h)
+
+    def GetMinimalRootOfUnity(self):
+        return lib.hexl_amd_ntt_root_of_unity(self._h)
+
+    def _table(self, which):
+        import numpy as np
+        n = self.GetDegree()
+        p = lib.hexl_amd_ntt_table(self._h, which)
+        return np.ctypeslib.as_array(p, shape=(n,)).copy()
+
+    def GetRootOfUnityPowers(self):
+        return self._table(0)
+
+    def GetPrecon32RootOfUnityPowers(self):
+        return self._table(1)
+
+    def GetPrecon64RootOfUnityPowers(self):
+        return self._table(2)
+
+    def GetInvRootOfUnityPowers(self):
+        return self._table(3)
+
+    def GetPrecon32InvRootOfUnityPowers(self):
+        return self._table(4)
+
+    def GetPrecon52InvRootOfUnityPowers(self):
+        return self._table(5)
+
+    def GetPrecon64InvRootOfUnityPowers(self):
+        return self._table(6)
+
+    def _batch(self, result, operand):
+        n = self.GetDegree()
+        if operand.numel() % n or result.numel() != operand.numel():
+            raise HexlAmdError("operand/result must hold k * degree words")
+        return operand.numel() // n
+
+    def ComputeForward(self, result, operand, input_mod_factor, output_mod_factor):
+        b = self._batch(result, operand)
+        _check(lib.hexl_amd_ntt_forward(self._h, _ptr(result), _ptr(operand), b,
+                                        input_mod_factor, output_mod_factor, _stream()))
+
+    def ComputeInverse(self, result, operand, input_mod_factor, output_mod_factor):
+        b = self._batch(result, operand)
+        _check(lib.hexl_amd_ntt_inverse(self._h, _ptr(result), _ptr(operand), b,
+                                        input_mod_factor, output_mod_factor, _stream()))
+
+
+def _rns(fn, plans, result, operand, in_mf, out_mf):
+    k = len(plans)
+    n = plans[0].GetDegree()
+    if operand.numel() % (k * n) or result.numel() != operand.numel():
+        raise HexlAmdError("operand must hold len(plans) * batch * degree words")
+    arr = (C.c_void_p * k)(*[p._h for p in plans])
+    _check(fn(arr, k, _ptr(result), _ptr(operand), operand.numel() // (k * n), in_mf, out_mf,
+              _stream()))
+
+
+def ComputeForwardRNS(plans, result, operand, input_mod_factor, output_mod_factor):
+    """plans[k] transforms polynomials [k*B, (k+1)*B) of the (K, B, N) operand."""
+    _rns(lib.hexl_amd_ntt_forward_rns, plans, result, operand, input_mod_factor,
+         output_mod_factor)
+
+
+def ComputeInverseRNS(plans, result, operand, input_mod_factor, output_mod_factor):
+    _rns(lib.hexl_amd_ntt_inverse_rns, plans, result, operand, input_mod_factor,
+         output_mod_factor)
+
+
+# ----------------------------------------------------------------------------
+# Eltwise -- hexl/include/hexl/eltwise/*.hpp
+# ----------------------------------------------------------------------------
+def EltwiseAddMod(result, operand1, operand2, n, modulus):
+    """operand2: tensor (vector-vector) or int (vector-scalar)."""
+    if isinstance(operand2, int):
+        _check(lib.hexl_amd_eltwise_add_mod_scalar(_ptr(result), _ptr(operand1), operand2, n,
+                                                   modulus, _stream()))
+    else:
+        _check(lib.hexl_amd_eltwise_add_mod(_ptr(result), _ptr(operand1), _ptr(operand2), n,
+                                            modulus, _stream()))
+
+
+def EltwiseSubMod(result, operand1, operand2, n, modulus):
+    if isinstance(operand2, int):
+        _check(lib.hexl_amd_eltwise_sub_mod_scalar(_ptr(result), _ptr(operand1), operand2, n,
+                                                   modulus, _stream()))
+    else:
+        _check(lib.hexl_amd_eltwise_sub_mod(_ptr(result), _ptr(operand1), _ptr(operand2), n,
+                                            modulus, _stream()))
+
+
+def EltwiseMultMod(result, operand1, operand2, n, modulus, input_mod_factor):
+    _check(lib.hexl_amd_eltwise_mult_mod(_ptr(result), _ptr(operand1), _ptr(operand2), n,
+                                         modulus, input_mod_factor, _stream()))
+
+
+def EltwiseFMAMod(result, arg1, arg2, arg3, n, modulus, input_mod_factor):
+    p3 = _ptr(arg3) if arg3 is not None else None
+    _check(lib.hexl_amd_eltwise_fma_mod(_ptr(result), _ptr(arg1), arg2, p3, n, modulus,
+                                        input_mod_factor, _stream()))
+
+
+def EltwiseReduceMod(result, operand, n, modulus, input_mod_factor, output_mod_factor):
+    _check(lib.hexl_amd_eltwise_reduce_mod(_ptr(result), _ptr(operand), n, modulus,
+                                           input_mod_factor, output_mod_factor, _stream()))
+
+
+def EltwiseReduceFMAMod(result, arg1, arg2, arg3, n, modulus, input_mod_factor):
+    """Fused EltwiseReduceMod(q -> 1) + EltwiseFMAMod (BASELINE config 5)."""
+    p3 = _ptr(arg3) if arg3 is not None else None
+    _check(lib.hexl_amd_eltwise_reduce_fma_mod(_ptr(result), _ptr(arg1), arg2, p3, n, modulus,
+                                               input_mod_factor, _stream()))
+
+
+def profile_start(max_records=4096):
+    _check(lib.hexl_amd_profile_start(max_records))
+
+
+def profile_stop():
+    """Returns [(kernel_name, milliseconds), ...] in launch order."""
+    n = C.c_int(0)
+    _check(lib.hexl_amd_profile_stop(C.byref(n)))
+    out = []
+    for i in range(n.value):
+        name, ms = C.c_char_p(), C.c_float()
+        _check(lib.hexl_amd_profile_get(i, C.byref(name), C.byref(ms)))
+        out.append((name.value.decode(), ms.value))
+    return out
+
+
+def fill_splitmix(data, n, batch, seed0, bound):
+    """Device-side synthetic input: poly b = splitmix64(seed0 + b) mod bound."""
+    _check(lib.hexl_amd_fill_splitmix(_ptr(data), n, batch, seed0, bound, _stream()))

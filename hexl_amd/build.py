@@ -1,0 +1,82 @@
+"""Builds hexl_amd/lib/libhexl_amd.so (C-ABI + gfx950 kernels) and
+hexl_amd/lib/libhexl.so (the intel::hexl C++ shim over the C-ABI) with hipcc.
+
+In-tree build: the .so files travel with the repo snapshot to the GPU box
+(they are git-ignored, not gpurun-ignored).  hipcc cross-compiles gfx950
+without a GPU present.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib")
+OBJ = os.path.join(HERE, "lib", "obj")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+CORE_SOURCES = ["ntt_kernels.hip", "eltwise_kernels.hip", "capi.cpp", "number_theory.cpp"]
+SHIM_SOURCES = ["hexl_shim.cpp"]
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-command-line-argument",
+          f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def _headers():
+    hs = []
+    for d, _, fs in os.walk(os.path.join(ROOT, "include")):
+        hs += [os.path.join(d, f) for f in fs]
+    hs += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    return hs
+
+
+def _compile(src):
+    obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+    path = os.path.join(CSRC, src)
+    if _newer(obj, [path] + _headers()):
+        return obj
+    cmd = [HIPCC, f"--offload-arch={ARCH}"] + COMMON + ["-c", path, "-o", obj]
+    if src.endswith(".cpp"):
+        cmd.insert(1, "-x")
+        cmd.insert(2, "c++")
+        cmd.remove(f"--offload-arch={ARCH}")
+        cmd += ["-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError(f"hipcc failed on {src}")
+    return obj
+
+
+def build(verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = CORE_SOURCES + [s for s in SHIM_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = dict(zip(srcs, ex.map(_compile, srcs)))
+    core = os.path.join(LIB, "libhexl_amd.so")
+    core_objs = [objs[s] for s in CORE_SOURCES]
+    if not _newer(core, core_objs):
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", core] + core_objs
+        subprocess.check_call(cmd)
+    shim = os.path.join(LIB, "libhexl.so")
+    shim_objs = [objs[s] for s in SHIM_SOURCES if s in objs]
+    if shim_objs and not _newer(shim, shim_objs + [core]):
+        cmd = [HIPCC, "-shared", "-fPIC", "-o", shim] + shim_objs + [
+            f"-L{LIB}", "-lhexl_amd", "-Wl,-rpath,$ORIGIN"]
+        subprocess.check_call(cmd)
+    if verbose:
+        print("built", core, "and", shim if shim_objs else "(no shim yet)")
+    return core
+
+
+if __name__ == "__main__":
+    build(verbose=True)

@@ -1,0 +1,563 @@
+// capi.cpp -- the C-ABI of include/hexl_amd.h: plan construction (host table
+// builder + upload), argument validation, device selection, host-pointer
+// staging.  All compute is in ntt_kernels.hip / eltwise_kernels.hip; there is
+// no CPU fallback -- if HIP is unusable every compute entry point fails.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hexl_amd.h"
+#include "internal.h"
+#include "number_theory.h"
+
+using namespace hexl_amd;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  return fail(e == hipErrorNoDevice || e == hipErrorInvalidDevice ? HEXL_AMD_ERR_NO_DEVICE
+                                                                   : HEXL_AMD_ERR_HIP,
+              "%s: %s", what, hipGetErrorString(e));
+}
+
+#define HX_HIP(call)                                 \
+  do {                                               \
+    hipError_t e_ = (call);                          \
+    if (e_ != hipSuccess) return hip_fail(e_, #call); \
+  } while (0)
+
+// Makes `device` current for the scope if it is not already.
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceScope(int device) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != device) {
+      err = hipSetDevice(device);
+      switched = (err == hipSuccess);
+    }
+  }
+  ~DeviceScope() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+// Per-thread staging buffers for the host-pointer entry points.
+struct Staging {
+  int device = -1;
+  void* buf = nullptr;
+  size_t cap = 0;
+  hipStream_t stream = nullptr;
+  ~Staging() {
+    // Process teardown may already have destroyed the HIP runtime; leak.
+  }
+  int ensure(int dev, size_t bytes) {
+    if (device != dev) {
+      buf = nullptr;
+      cap = 0;
+      stream = nullptr;
+      device = dev;
+    }
+    if (!stream) HX_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (cap < bytes) {
+      if (buf) HX_HIP(hipFree(buf));
+      buf = nullptr;
+      cap = 0;
+      HX_HIP(hipMalloc(&buf, bytes));
+      cap = bytes;
+    }
+    return HEXL_AMD_OK;
+  }
+};
+thread_local Staging g_staging;
+
+}  // namespace
+
+struct hexl_amd_ntt {
+  u64 n = 0, q = 0, w = 0;
+  u32 log_n = 0;
+  int device = 0;
+  // Reference-layout host tables (hexl_amd_ntt_table): built lazily except 0/2/3/6.
+  mutable std::vector<u64> host[7];
+  mutable std::once_flag once[7];
+  ulonglong2* d_fwd = nullptr;
+  ulonglong2* d_inv = nullptr;
+  NttTables t{};
+};
+
+extern "C" {
+
+const char* hexl_amd_last_error(void) { return g_last_error.c_str(); }
+
+int hexl_amd_device_count(int* count) {
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (count) *count = (e == hipSuccess) ? c : 0;
+  if (e != hipSuccess || c == 0) return fail(HEXL_AMD_ERR_NO_DEVICE, "no HIP device visible");
+  return HEXL_AMD_OK;
+}
+
+int hexl_amd_ntt_check_arguments(uint64_t degree, uint64_t modulus) {
+  return nt::ntt_check_arguments(degree, modulus) ? 1 : 0;
+}
+
+int hexl_amd_ntt_create(hexl_amd_ntt** out, uint64_t degree, uint64_t modulus,
+                        uint64_t root_of_unity, int device) {
+  if (!out) return fail(HEXL_AMD_ERR_INVALID_ARG, "plan == nullptr");
+  *out = nullptr;
+  if (!nt::ntt_check_arguments(degree, modulus))
+    return fail(HEXL_AMD_ERR_INVALID_ARG,
+                "degree %llu / modulus %llu: need a power-of-two degree in [2, 2^20] and a "
+                "prime modulus == 1 mod 2*degree below 2^62",
+                (unsigned long long)degree, (unsigned long long)modulus);
+  const u64 n = degree, q = modulus;
+  u64 w = root_of_unity;
+  if (w == 0) w = nt::minimal_primitive_root(2 * n, q);
+  if (!nt::is_primitive_root(w, 2 * n, q))
+    return fail(HEXL_AMD_ERR_INVALID_ARG, "%llu is not a primitive 2*%llu-th root of unity",
+                (unsigned long long)w, (unsigned long long)n);
+  if (device < 0) HX_HIP(hipGetDevice(&device));
+  int ndev = 0;
+  HX_HIP(hipGetDeviceCount(&ndev));
+  if (device >= ndev) return fail(HEXL_AMD_ERR_NO_DEVICE, "device %d of %d", device, ndev);
+
+  hexl_amd_ntt* p = new (std::nothrow) hexl_amd_ntt;
+  if (!p) return fail(HEXL_AMD_ERR_ALLOC, "out of host memory");
+  p->n = n;
+  p->q = q;
+  p->w = w;
+  p->log_n = (u32)nt::log2_floor(n);
+  p->device = device;
+
+  // R[bitrev(i)] = w^i and Rinv[bitrev(i)] = w^-i (hexl/ntt/ntt-internal.cpp:60-72;
+  // the reference inverts each power with Euclid, powers of w^-1 give the same values).
+  const u64 w_inv = nt::inverse_mod(w, q);
+  std::vector<u64>& R = p->host[0];
+  std::vector<u64> Rinv(n);
+  R.assign(n, 0);
+  {
+    u64 pw = 1, pwi = 1;
+    for (u64 i = 0; i < n; ++i) {
+      const u64 idx = nt::reverse_bits(i, p->log_n);
+      R[idx] = pw;
+      Rinv[idx] = pwi;
+      pw = nt::multiply_mod(pw, w, q);
+      pwi = nt::multiply_mod(pwi, w_inv, q);
+    }
+  }
+  // Stage-ordered inverse table of the reference (ntt-internal.cpp:143-154).
+  std::vector<u64>& IR = p->host[3];
+  IR.assign(n, 0);
+  IR[0] = 1;
+  {
+    u64 idx = 1;
+    for (u64 m = n >> 1; m > 0; m >>= 1)
+      for (u64 i = 0; i < m; ++i) IR[idx++] = Rinv[m + i];
+  }
+  p->host[2].resize(n);
+  p->host[6].resize(n);
+  for (u64 i = 0; i < n; ++i) {
+    p->host[2][i] = nt::multiply_factor(R[i], 64, q);
+    p->host[6][i] = nt::multiply_factor(IR[i], 64, q);
+  }
+  // Device tables: heap-ordered (value, precon) pairs.
+  std::vector<ulonglong2> hf(n), hi(n);
+  for (u64 i = 0; i < n; ++i) {
+    hf[i].x = R[i];
+    hf[i].y = p->host[2][i];
+    hi[i].x = Rinv[i];
+    hi[i].y = nt::multiply_factor(Rinv[i], 64, q);
+  }
+  InvLast il;
+  il.n1 = nt::inverse_mod(n, q);
+  il.n1p = nt::multiply_factor(il.n1, 64, q);
+  il.n1w = nt::multiply_mod(il.n1, Rinv[1], q);
+  il.n1wp = nt::multiply_factor(il.n1w, 64, q);
+
+  DeviceScope scope(device);
+  hipError_t e = scope.err;
+  if (e == hipSuccess) e = hipMalloc((void**)&p->d_fwd, n * sizeof(ulonglong2));
+  if (e == hipSuccess) e = hipMalloc((void**)&p->d_inv, n * sizeof(ulonglong2));
+  if (e == hipSuccess)
+    e = hipMemcpy(p->d_fwd, hf.data(), n * sizeof(ulonglong2), hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = hipMemcpy(p->d_inv, hi.data(), n * sizeof(ulonglong2), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (p->d_fwd) (void)hipFree(p->d_fwd);
+    if (p->d_inv) (void)hipFree(p->d_inv);
+    delete p;
+    return hip_fail(e, "uploading NTT tables");
+  }
+  p->t.fwd = p->d_fwd;
+  p->t.inv = p->d_inv;
+  p->t.q = q;
+  p->t.log_n = p->log_n;
+  p->t.inv_last = il;
+  *out = p;
+  return HEXL_AMD_OK;
+}
+
+int hexl_amd_ntt_destroy(hexl_amd_ntt* p) {
+  if (!p) return HEXL_AMD_OK;
+  {
+    DeviceScope scope(p->device);
+    if (p->d_fwd) (void)hipFree(p->d_fwd);
+    if (p->d_inv) (void)hipFree(p->d_inv);
+  }
+  delete p;
+  return HEXL_AMD_OK;
+}
+
+uint64_t hexl_amd_ntt_degree(const hexl_amd_ntt* p) { return p ? p->n : 0; }
+uint64_t hexl_amd_ntt_modulus(const hexl_amd_ntt* p) { return p ? p->q : 0; }
+uint64_t hexl_amd_ntt_root_of_unity(const hexl_amd_ntt* p) { return p ? p->w : 0; }
+int hexl_amd_ntt_device(const hexl_amd_ntt* p) { return p ? p->device : -1; }
+
+const uint64_t* hexl_amd_ntt_table(const hexl_amd_ntt* p, int which) {
+  if (!p || which < 0 || which > 6) return nullptr;
+  // 1, 4, 5: 32- / 52-bit preconditioned variants, rarely wanted -> lazy.
+  auto lazy = [&](int idx, int src, u64 shift) {
+    std::call_once(p->once[idx], [&] {
+      p->host[idx].resize(p->n);
+      for (u64 i = 0; i < p->n; ++i)
+        p->host[idx][i] = nt::multiply_factor(p->host[src][i], shift, p->q);
+    });
+  };
+  if (which == 1) lazy(1, 0, 32);
+  if (which == 4) lazy(4, 3, 32);
+  if (which == 5) lazy(5, 3, 52);
+  return p->host[which].data();
+}
+
+static int check_ntt_args(const hexl_amd_ntt* p, const void* result, const void* operand,
+                          bool forward, uint64_t in_mf, uint64_t out_mf) {
+  if (!p) return fail(HEXL_AMD_ERR_INVALID_ARG, "plan == nullptr");
+  if (!result) return fail(HEXL_AMD_ERR_INVALID_ARG, "result == nullptr");
+  if (!operand) return fail(HEXL_AMD_ERR_INVALID_ARG, "operand == nullptr");
+  if (forward) {
+    // ntt-internal.cpp:193-197
+    if (!(in_mf == 1 || in_mf == 2 || in_mf == 4))
+      return fail(HEXL_AMD_ERR_INVALID_ARG, "input_mod_factor must be 1, 2 or 4; got %llu",
+                  (unsigned long long)in_mf);
+    if (!(out_mf == 1 || out_mf == 4))
+      return fail(HEXL_AMD_ERR_INVALID_ARG, "output_mod_factor must be 1 or 4; got %llu",
+                  (unsigned long long)out_mf);
+  } else {
+    // ntt-internal.cpp:257-260
+    if (!(in_mf == 1 || in_mf == 2))
+      return fail(HEXL_AMD_ERR_INVALID_ARG, "input_mod_factor must be 1 or 2; got %llu",
+                  (unsigned long long)in_mf);
+    if (!(out_mf == 1 || out_mf == 2))
+      return fail(HEXL_AMD_ERR_INVALID_ARG, "output_mod_factor must be 1 or 2; got %llu",
+                  (unsigned long long)out_mf);
+  }
+  return HEXL_AMD_OK;
+}
+
+static int ntt_run(const hexl_amd_ntt* p, uint64_t* result, const uint64_t* operand,
+                   uint64_t batch, bool forward, uint64_t in_mf, uint64_t out_mf,
+                   void* stream) {
+  if (int rc = check_ntt_args(p, result, operand, forward, in_mf, out_mf)) return rc;
+  DeviceScope scope(p->device);
+  if (scope.err != hipSuccess) return hip_fail(scope.err, "hipSetDevice");
+  hipError_t e = forward ? ntt_forward_launch(p->t, result, operand, batch, out_mf,
+                                              (hipStream_t)stream)
+                         : ntt_inverse_launch(p->t, result, operand, batch, out_mf,
+                                              (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, forward ? "forward NTT launch" : "inverse NTT launch");
+  return HEXL_AMD_OK;
+}
+
+int hexl_amd_ntt_forward(const hexl_amd_ntt* p, uint64_t* result, const uint64_t* operand,
+                         uint64_t batch, uint64_t in_mf, uint64_t out_mf, void* stream) {
+  return ntt_run(p, result, operand, batch, true, in_mf, out_mf, stream);
+}
+
+int hexl_amd_ntt_inverse(const hexl_amd_ntt* p, uint64_t* result, const uint64_t* operand,
+                         uint64_t batch, uint64_t in_mf, uint64_t out_mf, void* stream) {
+  return ntt_run(p, result, operand, batch, false, in_mf, out_mf, stream);
+}
+
+static int ntt_run_rns(const hexl_amd_ntt* const* plans, uint64_t num_plans, uint64_t* result,
+                       const uint64_t* operand, uint64_t batch_per_plan, bool forward,
+                       uint64_t in_mf, uint64_t out_mf, void* stream) {
+  if (!plans) return fail(HEXL_AMD_ERR_INVALID_ARG, "plans == nullptr");
+  for (uint64_t k = 0; k < num_plans; ++k) {
+    if (!plans[k]) return fail(HEXL_AMD_ERR_INVALID_ARG, "plans[%llu] == nullptr",
+                               (unsigned long long)k);
+    if (plans[k]->n != plans[0]->n || plans[k]->device != plans[0]->device)
+      return fail(HEXL_AMD_ERR_INVALID_ARG, "plans must share degree and device");
+  }
+  for (uint64_t k = 0; k < num_plans; ++k) {
+    const uint64_t off = k * batch_per_plan * plans[k]->n;
+    if (int rc = ntt_run(plans[k], result + off, operand + off, batch_per_plan, forward, in_mf,
+                         out_mf, stream))
+      return rc;
+  }
+  return HEXL_AMD_OK;
+}
+
+int hexl_amd_ntt_forward_rns(const hexl_amd_ntt* const* plans, uint64_t num_plans,
+                             uint64_t* result, const uint64_t* operand,
+                             uint64_t batch_per_plan, uint64_t in_mf, uint64_t out_mf,
+                             void* stream) {
+  return ntt_run_rns(plans, num_plans, result, operand, batch_per_plan, true, in_mf, out_mf,
+                     stream);
+}
+
+int hexl_amd_ntt_inverse_rns(const hexl_amd_ntt* const* plans, uint64_t num_plans,
+                             uint64_t* result, const uint64_t* operand,
+                             uint64_t batch_per_plan, uint64_t in_mf, uint64_t out_mf,
+                             void* stream) {
+  return ntt_run_rns(plans, num_plans, result, operand, batch_per_plan, false, in_mf, out_mf,
+                     stream);
+}
+
+static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t* operand,
+                        uint64_t batch, bool forward, uint64_t in_mf, uint64_t out_mf) {
+  if (int rc = check_ntt_args(p, result, operand, forward, in_mf, out_mf)) return rc;
+  if (batch == 0) return HEXL_AMD_OK;
+  DeviceScope scope(p->device);
+  if (scope.err != hipSuccess) return hip_fail(scope.err, "hipSetDevice");
+  const size_t bytes = (size_t)batch * p->n * sizeof(u64);
+  if (int rc = g_staging.ensure(p->device, bytes)) return rc;
+  u64* d = (u64*)g_staging.buf;
+  hipStream_t st = g_staging.stream;
+  HX_HIP(hipMemcpyAsync(d, operand, bytes, hipMemcpyHostToDevice, st));
+  hipError_t e = forward ? ntt_forward_launch(p->t, d, d, batch, out_mf, st)
+                         : ntt_inverse_launch(p->t, d, d, batch, out_mf, st);
+  if (e != hipSuccess) return hip_fail(e, "NTT launch");
+  HX_HIP(hipMemcpyAsync(result, d, bytes, hipMemcpyDeviceToHost, st));
+  HX_HIP(hipStreamSynchronize(st));
+  return HEXL_AMD_OK;
+}
+
+int hexl_amd_ntt_forward_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t* operand,
+                              uint64_t batch, uint64_t in_mf, uint64_t out_mf) {
+  return ntt_run_host(p, result, operand, batch, true, in_mf, out_mf);
+}
+
+int hexl_amd_ntt_inverse_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t* operand,
+                              uint64_t batch, uint64_t in_mf, uint64_t out_mf) {
+  return ntt_run_host(p, result, operand, batch, false, in_mf, out_mf);
+}
+
+// ------------------------------------------------------------------ eltwise
+
+static int check_elt(EltOp op, const EltArgs& g) {
+  if (!g.result) return fail(HEXL_AMD_ERR_INVALID_ARG, "result == nullptr");
+  if (!g.a) return fail(HEXL_AMD_ERR_INVALID_ARG, "operand1 == nullptr");
+  if ((op == ELT_ADD || op == ELT_SUB || op == ELT_MULT) && !g.b)
+    return fail(HEXL_AMD_ERR_INVALID_ARG, "operand2 == nullptr");
+  if (g.n == 0) return fail(HEXL_AMD_ERR_INVALID_ARG, "n == 0");
+  if (g.q <= 1) return fail(HEXL_AMD_ERR_INVALID_ARG, "modulus must be > 1");
+  switch (op) {
+    case ELT_ADD:
+    case ELT_SUB:
+    case ELT_ADD_SCALAR:
+    case ELT_SUB_SCALAR:
+      if (g.q >= (1ull << 63)) return fail(HEXL_AMD_ERR_INVALID_ARG, "modulus must be < 2^63");
+      if ((op == ELT_ADD_SCALAR || op == ELT_SUB_SCALAR) && g.scalar >= g.q)
+        return fail(HEXL_AMD_ERR_INVALID_ARG, "scalar operand must be < modulus");
+      break;
+    case ELT_MULT:
+      if (!(g.in_mf == 1 || g.in_mf == 2 || g.in_mf == 4))
+        return fail(HEXL_AMD_ERR_INVALID_ARG, "input_mod_factor must be 1, 2 or 4");
+      if (g.q >= (1ull << 62) || g.in_mf * g.q >= (1ull << 63))
+        return fail(HEXL_AMD_ERR_INVALID_ARG,
+                    "need modulus < 2^62 and input_mod_factor * modulus < 2^63");
+      break;
+    case ELT_FMA:
+      if (!(g.in_mf == 1 || g.in_mf == 2 || g.in_mf == 4 || g.in_mf == 8))
+        return fail(HEXL_AMD_ERR_INVALID_ARG, "input_mod_factor must be 1, 2, 4 or 8");
+      if (g.q >= (1ull << 61)) return fail(HEXL_AMD_ERR_INVALID_ARG, "modulus must be < 2^61");
+      break;
+    case ELT_REDUCE:
+      if (!(g.in_mf == g.q || g.in_mf == 2 || g.in_mf == 4))
+        return fail(HEXL_AMD_ERR_INVALID_ARG, "input_mod_factor must be modulus, 2 or 4");
+      if (!(g.out_mf == 1 || g.out_mf == 2))
+        return fail(HEXL_AMD_ERR_INVALID_ARG, "output_mod_factor must be 1 or 2");
+      break;
+    case ELT_REDUCE_FMA:
+      if (g.q >= (1ull << 61)) return fail(HEXL_AMD_ERR_INVALID_ARG, "modulus must be < 2^61");
+      break;
+  }
+  return HEXL_AMD_OK;
+}
+
+static int elt_run(EltOp op, const EltArgs& g, void* stream) {
+  if (int rc = check_elt(op, g)) return rc;
+  hipError_t e = eltwise_launch(op, g, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "eltwise launch");
+  return HEXL_AMD_OK;
+}
+
+int hexl_amd_eltwise_add_mod(uint64_t* result, const uint64_t* a, const uint64_t* b, uint64_t n,
+                             uint64_t q, void* stream) {
+  return elt_run(ELT_ADD, EltArgs{result, a, b, 0, n, q, 1, 1}, stream);
+}
+int hexl_amd_eltwise_add_mod_scalar(uint64_t* result, const uint64_t* a, uint64_t b, uint64_t n,
+                                    uint64_t q, void* stream) {
+  return elt_run(ELT_ADD_SCALAR, EltArgs{result, a, nullptr, b, n, q, 1, 1}, stream);
+}
+int hexl_amd_eltwise_sub_mod(uint64_t* result, const uint64_t* a, const uint64_t* b, uint64_t n,
+                             uint64_t q, void* stream) {
+  return elt_run(ELT_SUB, EltArgs{result, a, b, 0, n, q, 1, 1}, stream);
+}
+int hexl_amd_eltwise_sub_mod_scalar(uint64_t* result, const uint64_t* a, uint64_t b, uint64_t n,
+                                    uint64_t q, void* stream) {
+  return elt_run(ELT_SUB_SCALAR, EltArgs{result, a, nullptr, b, n, q, 1, 1}, stream);
+}
+int hexl_amd_eltwise_mult_mod(uint64_t* result, const uint64_t* a, const uint64_t* b,
+                              uint64_t n, uint64_t q, uint64_t in_mf, void* stream) {
+  return elt_run(ELT_MULT, EltArgs{result, a, b, 0, n, q, in_mf, 1}, stream);
+}
+int hexl_amd_eltwise_fma_mod(uint64_t* result, const uint64_t* arg1, uint64_t arg2,
+                             const uint64_t* arg3, uint64_t n, uint64_t q, uint64_t in_mf,
+                             void* stream) {
+  return elt_run(ELT_FMA, EltArgs{result, arg1, arg3, arg2, n, q, in_mf, 1}, stream);
+}
+int hexl_amd_eltwise_reduce_mod(uint64_t* result, const uint64_t* operand, uint64_t n,
+                                uint64_t q, uint64_t in_mf, uint64_t out_mf, void* stream) {
+  return elt_run(ELT_REDUCE, EltArgs{result, operand, nullptr, 0, n, q, in_mf, out_mf}, stream);
+}
+int hexl_amd_eltwise_reduce_fma_mod(uint64_t* result, const uint64_t* arg1, uint64_t arg2,
+                                    const uint64_t* arg3, uint64_t n, uint64_t q,
+                                    uint64_t in_mf, void* stream) {
+  if (in_mf == q)
+    return elt_run(ELT_REDUCE_FMA, EltArgs{result, arg1, arg3, arg2, n, q, in_mf, 1}, stream);
+  return elt_run(ELT_FMA, EltArgs{result, arg1, arg3, arg2, n, q, in_mf, 1}, stream);
+}
+
+int hexl_amd_eltwise_host(int op, uint64_t* result, const uint64_t* operand1,
+                          const uint64_t* operand2, uint64_t scalar, uint64_t n, uint64_t q,
+                          uint64_t in_mf, uint64_t out_mf) {
+  if (op < 0 || op > 6) return fail(HEXL_AMD_ERR_INVALID_ARG, "unknown eltwise op %d", op);
+  EltArgs g{result, operand1, operand2, scalar, n, q, in_mf, out_mf};
+  if (int rc = check_elt((EltOp)op, g)) return rc;
+  int device = 0;
+  HX_HIP(hipGetDevice(&device));
+  const size_t bytes = (size_t)n * sizeof(u64);
+  const bool has_b = operand2 != nullptr;
+  if (int rc = g_staging.ensure(device, bytes * (has_b ? 2 : 1))) return rc;
+  u64* da = (u64*)g_staging.buf;
+  u64* db = has_b ? da + n : nullptr;
+  hipStream_t st = g_staging.stream;
+  HX_HIP(hipMemcpyAsync(da, operand1, bytes, hipMemcpyHostToDevice, st));
+  if (has_b) HX_HIP(hipMemcpyAsync(db, operand2, bytes, hipMemcpyHostToDevice, st));
+  g.result = da;
+  g.a = da;
+  g.b = db;
+  hipError_t e = eltwise_launch((EltOp)op, g, st);
+  if (e != hipSuccess) return hip_fail(e, "eltwise launch");
+  HX_HIP(hipMemcpyAsync(result, da, bytes, hipMemcpyDeviceToHost, st));
+  HX_HIP(hipStreamSynchronize(st));
+  return HEXL_AMD_OK;
+}
+
+// ------------------------------------------------------------------ number theory
+
+uint64_t hexl_amd_multiply_factor(uint64_t operand, uint64_t bit_shift, uint64_t modulus) {
+  return nt::multiply_factor(operand, bit_shift, modulus);
+}
+uint64_t hexl_amd_inverse_mod(uint64_t x, uint64_t modulus) { return nt::inverse_mod(x, modulus); }
+uint64_t hexl_amd_multiply_mod(uint64_t x, uint64_t y, uint64_t modulus) {
+  return nt::multiply_mod(x, y, modulus);
+}
+uint64_t hexl_amd_pow_mod(uint64_t base, uint64_t exp, uint64_t modulus) {
+  return nt::pow_mod(base, exp, modulus);
+}
+int hexl_amd_is_primitive_root(uint64_t root, uint64_t degree, uint64_t modulus) {
+  return nt::is_primitive_root(root, degree, modulus) ? 1 : 0;
+}
+uint64_t hexl_amd_generate_primitive_root(uint64_t degree, uint64_t modulus) {
+  return nt::generate_primitive_root(degree, modulus);
+}
+uint64_t hexl_amd_minimal_primitive_root(uint64_t degree, uint64_t modulus) {
+  return nt::minimal_primitive_root(degree, modulus);
+}
+uint64_t hexl_amd_reverse_bits(uint64_t x, uint64_t bit_width) {
+  return nt::reverse_bits(x, bit_width);
+}
+int hexl_amd_is_prime(uint64_t n) { return nt::is_prime(n) ? 1 : 0; }
+size_t hexl_amd_generate_primes(uint64_t* out, size_t num_primes, size_t bit_size,
+                                int prefer_small_primes, size_t ntt_size) {
+  return nt::generate_primes(out, num_primes, bit_size, prefer_small_primes != 0, ntt_size);
+}
+
+// ------------------------------------------------------------------ profiling
+
+namespace {
+struct ProfileState {
+  std::vector<ProfileRecord> records;
+  ProfileSink sink{nullptr, 0, 0};
+  std::vector<float> ms;
+};
+thread_local ProfileState g_prof_state;
+}  // namespace
+
+int hexl_amd_profile_start(int max_records) {
+  ProfileState& ps = g_prof_state;
+  if (max_records <= 0) return fail(HEXL_AMD_ERR_INVALID_ARG, "max_records <= 0");
+  for (size_t i = ps.records.size(); i < (size_t)max_records; ++i) {
+    ProfileRecord r{nullptr, nullptr, nullptr};
+    HX_HIP(hipEventCreate(&r.start));
+    HX_HIP(hipEventCreate(&r.stop));
+    ps.records.push_back(r);
+  }
+  ps.sink.records = ps.records.data();
+  ps.sink.capacity = max_records;
+  ps.sink.count = 0;
+  g_profile = &ps.sink;
+  return HEXL_AMD_OK;
+}
+
+int hexl_amd_profile_stop(int* num_records) {
+  ProfileState& ps = g_prof_state;
+  g_profile = nullptr;
+  const int n = ps.sink.count;
+  ps.ms.assign(n, 0.f);
+  for (int i = 0; i < n; ++i) {
+    HX_HIP(hipEventSynchronize(ps.records[i].stop));
+    HX_HIP(hipEventElapsedTime(&ps.ms[i], ps.records[i].start, ps.records[i].stop));
+  }
+  if (num_records) *num_records = n;
+  return HEXL_AMD_OK;
+}
+
+int hexl_amd_profile_get(int i, const char** name, float* ms) {
+  ProfileState& ps = g_prof_state;
+  if (i < 0 || i >= (int)ps.ms.size()) return fail(HEXL_AMD_ERR_INVALID_ARG, "bad record index");
+  if (name) *name = ps.records[i].name;
+  if (ms) *ms = ps.ms[i];
+  return HEXL_AMD_OK;
+}
+
+int hexl_amd_fill_splitmix(uint64_t* data, uint64_t n, uint64_t batch, uint64_t seed0,
+                           uint64_t bound, void* stream) {
+  if (!data) return fail(HEXL_AMD_ERR_INVALID_ARG, "data == nullptr");
+  hipError_t e = fill_splitmix_launch(data, n, batch, seed0, bound, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "fill launch");
+  return HEXL_AMD_OK;
+}
+
+}  // extern "C"

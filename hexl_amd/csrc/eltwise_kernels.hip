@@ -1,0 +1,257 @@
+// eltwise_kernels.hip -- element-wise modular arithmetic on uint64 vectors for
+// gfx950.  Streaming, HBM-bound kernels: 16 bytes per lane per access, one
+// pair of elements per thread with a grid-stride fallback for very large n.
+//
+// Replaces (results canonical in [0, q), hence bit-identical):
+//   EltwiseAddMod     hexl/eltwise/eltwise-add-mod.cpp:16-113
+//   EltwiseSubMod     hexl/eltwise/eltwise-sub-mod.cpp:15-110
+//   EltwiseMultMod    hexl/eltwise/eltwise-mult-mod-internal.hpp:34-100
+//   EltwiseFMAMod     hexl/eltwise/eltwise-fma-mod-internal.hpp:12-39
+//   EltwiseReduceMod  hexl/eltwise/eltwise-reduce-mod.cpp:16-123
+// Algorithmic bytes per element: 24 (two inputs + one output) or 16.
+#include <hip/hip_runtime.h>
+
+#include "internal.h"
+#include "modarith.h"
+
+namespace hexl_amd {
+
+// x in [0, k*q) -> [0, q) by conditional subtraction, k in {1,2,4,8}
+// (number-theory.hpp:214-258 ReduceMod<k>)
+__device__ __forceinline__ u64 reduce_k(u64 x, u64 q, u64 k) {
+  if (k >= 8) x = csub(x, q << 2);
+  if (k >= 4) x = csub(x, q << 1);
+  if (k >= 2) x = csub(x, q);
+  return x;
+}
+
+struct AddOp {
+  u64 q;
+  __device__ __forceinline__ u64 operator()(u64 a, u64 b) const { return csub(a + b, q); }
+};
+struct AddScalarOp {  // eltwise-add-mod.cpp:45-69: compare against q - b
+  u64 b, diff;
+  __device__ __forceinline__ u64 operator()(u64 a, u64) const {
+    return a >= diff ? a - diff : a + b;
+  }
+};
+struct SubOp {
+  u64 q;
+  __device__ __forceinline__ u64 operator()(u64 a, u64 b) const {
+    return a >= b ? a - b : a + q - b;
+  }
+};
+struct SubScalarOp {
+  u64 q, b;
+  __device__ __forceinline__ u64 operator()(u64 a, u64) const {
+    return a >= b ? a - b : a + q - b;
+  }
+};
+// Generalised Barrett, alpha = 62, beta = -2 (eltwise-mult-mod-internal.hpp:50-93):
+// c1 = floor(x*y / 2^(ceil(log q) - 2)); q_hat = hi64(c1 * mu); Z = lo64(x*y) - q_hat*q.
+struct MultOp {
+  u64 q, mu, in_mf;
+  u32 shift;  // ceil(log2 q) - 2
+  __device__ __forceinline__ u64 operator()(u64 a, u64 b) const {
+    const u64 x = reduce_k(a, q, in_mf);
+    const u64 y = reduce_k(b, q, in_mf);
+    const u64 lo = x * y;
+    const u64 hi = __umul64hi(x, y);
+    const u64 c1 = shift ? ((lo >> shift) | (hi << (64 - shift))) : lo;
+    const u64 q_hat = __umul64hi(c1, mu);
+    return csub(lo - q_hat * q, q);
+  }
+};
+// (a * s + c) mod q with s reduced on the host and its Shoup factor sp
+// (eltwise-fma-mod-internal.hpp:12-39; MultiplyMod number-theory.cpp:54-59)
+template <bool HAS_C>
+struct FmaOp {
+  u64 q, s, sp, in_mf;
+  __device__ __forceinline__ u64 operator()(u64 a, u64 c) const {
+    const u64 x = reduce_k(a, q, in_mf);
+    u64 r = csub(mul_lazy(x, s, sp, q), q);
+    if (HAS_C) r = csub(r + reduce_k(c, q, in_mf), q);
+    return r;
+  }
+};
+// eltwise-reduce-mod.cpp:16-79.  mode 0: arbitrary word -> [0,q) (Barrett);
+// 1: arbitrary word -> [0,2q); 2: [0,2q)->[0,q); 3: [0,4q)->[0,q);
+// 4: [0,4q)->[0,2q); 5: copy.
+struct ReduceOp {
+  u64 q, barrett;  // floor(2^64 / q)
+  int mode;
+  __device__ __forceinline__ u64 barrett1(u64 x) const {
+    if (x < q) return x;
+    const u64 r = x - __umul64hi(x, barrett) * q;
+    return r;
+  }
+  __device__ __forceinline__ u64 operator()(u64 a, u64) const {
+    switch (mode) {
+      case 0: {
+        u64 r = barrett1(a);
+        return a < q ? a : csub(r, q);
+      }
+      case 1:
+        return barrett1(a);
+      case 2:
+        return csub(a, q);
+      case 3:
+        return csub(csub(a, q << 1), q);
+      case 4:
+        return csub(a, q << 1);
+      default:
+        return a;
+    }
+  }
+};
+// Fused ReduceMod(q -> 1) on both vector inputs + FMAMod (BASELINE config 5).
+template <bool HAS_C>
+struct ReduceFmaOp {
+  u64 q, s, sp, barrett;
+  __device__ __forceinline__ u64 full(u64 x) const {
+    if (x < q) return x;
+    return csub(x - __umul64hi(x, barrett) * q, q);
+  }
+  __device__ __forceinline__ u64 operator()(u64 a, u64 c) const {
+    u64 r = csub(mul_lazy(full(a), s, sp, q), q);
+    if (HAS_C) r = csub(r + full(c), q);
+    return r;
+  }
+};
+
+template <class Op, bool HAS_B>
+__global__ void __launch_bounds__(256)
+eltwise_vec2(u64* __restrict__ res, const u64* __restrict__ a, const u64* __restrict__ b,
+             u64 npairs, Op op) {
+  const ulonglong2* a2 = reinterpret_cast<const ulonglong2*>(a);
+  const ulonglong2* b2 = reinterpret_cast<const ulonglong2*>(b);
+  ulonglong2* r2 = reinterpret_cast<ulonglong2*>(res);
+  const u64 stride = (u64)gridDim.x * 256;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < npairs; i += stride) {
+    const ulonglong2 va = a2[i];
+    ulonglong2 vb = make_ulonglong2(0, 0);
+    if (HAS_B) vb = b2[i];
+    r2[i] = make_ulonglong2(op(va.x, vb.x), op(va.y, vb.y));
+  }
+}
+
+template <class Op, bool HAS_B>
+__global__ void __launch_bounds__(256)
+eltwise_scalar(u64* res, const u64* a, const u64* b, u64 begin, u64 n, Op op) {
+  const u64 stride = (u64)gridDim.x * 256;
+  for (u64 i = begin + (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const u64 vb = HAS_B ? b[i] : 0;
+    res[i] = op(a[i], vb);
+  }
+}
+
+static unsigned grid_for(u64 items) {
+  const u64 blocks = (items + 255) / 256;
+  const u64 cap = 1u << 20;
+  return (unsigned)(blocks < cap ? (blocks ? blocks : 1) : cap);
+}
+
+template <class Op, bool HAS_B>
+static hipError_t run(const EltArgs& g, const u64* b, Op op, hipStream_t st) {
+  if (g.n == 0) return hipSuccess;
+  const uintptr_t mask = (uintptr_t)g.result | (uintptr_t)g.a | (HAS_B ? (uintptr_t)b : 0);
+  u64 done = 0;
+  ScopedKernelTimer timer("eltwise", st);
+  if ((mask & 15) == 0 && g.n >= 2) {
+    const u64 npairs = g.n / 2;
+    hipLaunchKernelGGL((eltwise_vec2<Op, HAS_B>), dim3(grid_for(npairs)), dim3(256), 0, st,
+                       g.result, g.a, b, npairs, op);
+    done = npairs * 2;
+  }
+  if (done < g.n) {
+    hipLaunchKernelGGL((eltwise_scalar<Op, HAS_B>), dim3(grid_for(g.n - done)), dim3(256), 0,
+                       st, g.result, g.a, b, done, g.n, op);
+  }
+  return hipGetLastError();
+}
+
+static u64 host_floor_2_64_over(u64 num_shifted_operand, u64 q) {
+  // floor(operand * 2^64 / q)
+  return (u64)((((unsigned __int128)num_shifted_operand) << 64) / q);
+}
+
+static u64 host_reduce_k(u64 x, u64 q, u64 k) {
+  if (k >= 8 && x >= 4 * q) x -= 4 * q;
+  if (k >= 4 && x >= 2 * q) x -= 2 * q;
+  if (k >= 2 && x >= q) x -= q;
+  return x;
+}
+
+hipError_t eltwise_launch(EltOp op, const EltArgs& g, hipStream_t st) {
+  const u64 q = g.q;
+  switch (op) {
+    case ELT_ADD:
+      return run<AddOp, true>(g, g.b, AddOp{q}, st);
+    case ELT_ADD_SCALAR:
+      return run<AddScalarOp, false>(g, nullptr, AddScalarOp{g.scalar, q - g.scalar}, st);
+    case ELT_SUB:
+      return run<SubOp, true>(g, g.b, SubOp{q}, st);
+    case ELT_SUB_SCALAR:
+      return run<SubScalarOp, false>(g, nullptr, SubScalarOp{q, g.scalar}, st);
+    case ELT_MULT: {
+      const u32 ceil_log = 64 - __builtin_clzll(q);  // floor(log2 q) + 1
+      const u32 shift = ceil_log - 2;
+      const u64 mu = host_floor_2_64_over(1ull << (ceil_log + 62 - 64), q);
+      return run<MultOp, true>(g, g.b, MultOp{q, mu, g.in_mf, shift}, st);
+    }
+    case ELT_FMA: {
+      const u64 s = host_reduce_k(g.scalar, q, g.in_mf);
+      const u64 sp = host_floor_2_64_over(s, q);
+      if (g.b) return run<FmaOp<true>, true>(g, g.b, FmaOp<true>{q, s, sp, g.in_mf}, st);
+      return run<FmaOp<false>, false>(g, nullptr, FmaOp<false>{q, s, sp, g.in_mf}, st);
+    }
+    case ELT_REDUCE: {
+      int mode;
+      if (g.in_mf == g.out_mf)
+        mode = 5;  // copy (eltwise-reduce-mod.cpp:94-99); in place: no-op
+      else if (g.in_mf == q)
+        mode = g.out_mf == 1 ? 0 : 1;
+      else if (g.in_mf == 2)
+        mode = 2;
+      else
+        mode = g.out_mf == 1 ? 3 : 4;
+      if (mode == 5 && g.result == g.a) return hipSuccess;
+      return run<ReduceOp, false>(g, nullptr, ReduceOp{q, host_floor_2_64_over(1, q), mode},
+                                  st);
+    }
+    case ELT_REDUCE_FMA: {
+      const u64 s = g.scalar % q;
+      const u64 sp = host_floor_2_64_over(s, q);
+      const u64 bar = host_floor_2_64_over(1, q);
+      if (g.b)
+        return run<ReduceFmaOp<true>, true>(g, g.b, ReduceFmaOp<true>{q, s, sp, bar}, st);
+      return run<ReduceFmaOp<false>, false>(g, nullptr, ReduceFmaOp<false>{q, s, sp, bar}, st);
+    }
+  }
+  return hipErrorInvalidValue;
+}
+
+// splitmix64 stream: coefficient i of polynomial b = mix(seed0 + b + (i+1)*gamma) mod bound
+__global__ void __launch_bounds__(256)
+fill_splitmix_kernel(u64* data, u64 n, u64 total, u64 seed0, u64 bound) {
+  const u64 stride = (u64)gridDim.x * 256;
+  for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < total; k += stride) {
+    const u64 b = k / n, i = k - b * n;
+    u64 z = seed0 + b + (i + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    data[k] = bound ? z % bound : z;
+  }
+}
+
+hipError_t fill_splitmix_launch(u64* data, u64 n, u64 batch, u64 seed0, u64 bound,
+                                hipStream_t st) {
+  const u64 total = n * batch;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(fill_splitmix_kernel, dim3(grid_for(total)), dim3(256), 0, st, data, n,
+                     total, seed0, bound);
+  return hipGetLastError();
+}
+
+}  // namespace hexl_amd

@@ -1,0 +1,91 @@
+// internal.h -- declarations shared by the kernel translation units and the
+// C-ABI layer (capi.cpp).  Not installed.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
+#include <stdint.h>
+
+namespace hexl_amd {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+// Scalars of the last inverse stage: n1 = N^-1 mod q, n1w = N^-1 * R[1]^-1,
+// each with its floor(x * 2^64 / q) companion
+// (hexl/ntt/ntt-radix-2.cpp:490-497).
+struct InvLast {
+  u64 n1, n1p, n1w, n1wp;
+};
+
+// Device-resident state of one NTT plan.
+struct NttTables {
+  const ulonglong2* fwd;  // heap-ordered (R[n], floor(R[n] 2^64 / q)), n in [0, N)
+  const ulonglong2* inv;  // heap-ordered (R[n]^-1, precon)
+  u64 q;
+  u32 log_n;
+  InvLast inv_last;
+};
+
+// Optional per-kernel timing (bench support): when a sink is active on the
+// calling thread every kernel launch is bracketed by a pair of hipEvents
+// recorded on the launch stream.
+struct ProfileRecord {
+  const char* name;
+  hipEvent_t start, stop;
+};
+struct ProfileSink {
+  ProfileRecord* records;
+  int capacity;
+  int count;
+};
+extern thread_local ProfileSink* g_profile;
+
+struct ScopedKernelTimer {
+  ProfileRecord* r = nullptr;
+  hipStream_t st;
+  ScopedKernelTimer(const char* name, hipStream_t stream) : st(stream) {
+    ProfileSink* s = g_profile;
+    if (s && s->count < s->capacity) {
+      r = &s->records[s->count++];
+      r->name = name;
+      (void)hipEventRecord(r->start, st);
+    }
+  }
+  ~ScopedKernelTimer() {
+    if (r) (void)hipEventRecord(r->stop, st);
+  }
+};
+
+hipError_t ntt_forward_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
+                              u64 out_mf, hipStream_t st);
+hipError_t ntt_inverse_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
+                              u64 out_mf, hipStream_t st);
+
+// Element-wise launchers (eltwise_kernels.hip)
+enum EltOp {
+  ELT_ADD = 0,
+  ELT_ADD_SCALAR = 1,
+  ELT_SUB = 2,
+  ELT_SUB_SCALAR = 3,
+  ELT_MULT = 4,
+  ELT_FMA = 5,
+  ELT_REDUCE = 6,
+  ELT_REDUCE_FMA = 7
+};
+
+struct EltArgs {
+  u64* result;
+  const u64* a;
+  const u64* b;  // second vector (add/sub/mult) or addend (fma); may be null
+  u64 scalar;    // scalar operand (add/sub scalar forms, fma multiplier)
+  u64 n;
+  u64 q;
+  u64 in_mf;
+  u64 out_mf;
+};
+
+hipError_t eltwise_launch(EltOp op, const EltArgs& args, hipStream_t st);
+hipError_t fill_splitmix_launch(u64* data, u64 n, u64 batch, u64 seed0, u64 bound,
+                                hipStream_t st);
+
+}  // namespace hexl_amd

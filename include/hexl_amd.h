@@ -1,0 +1,238 @@
+/*
+ * hexl_amd.h -- C-ABI of the MI355X-native NTT / Eltwise hot path.
+ *
+ * This is the drop-in boundary: plain `extern "C"` entry points, raw pointers
+ * and sizes, no C++ or torch types.  Every entry point names the reference
+ * interface it replaces (paths relative to the intel/hexl tree).  The C++ shim
+ * in include/hexl/ (namespace intel::hexl) is written on top of exactly these
+ * functions; INTEGRATION.md shows the binding a HEXL maintainer would add.
+ *
+ * Conventions
+ *   - A polynomial is N contiguous uint64_t; a batch is `batch` polynomials
+ *     back to back (stride N).  Forward input / inverse output are in natural
+ *     coefficient order, forward output / inverse input in bit-reversed order
+ *     (hexl/include/hexl/ntt/ntt.hpp:92,102).
+ *   - `result` may alias `operand` (in-place), as in the reference.
+ *   - Functions without a `_host` suffix take DEVICE pointers and enqueue on
+ *     `stream` (a hipStream_t passed as void*; NULL = the default stream) and
+ *     return without synchronising.  `_host` variants take host pointers,
+ *     stage through device memory, and return after the result is back on the
+ *     host (this is what the single-call intel::hexl API needs).
+ *   - Every function returns HEXL_AMD_OK (0) or an error code; the message is
+ *     available from hexl_amd_last_error() (thread-local).  There is no CPU
+ *     fallback: without a usable gfx950 device every compute entry point fails
+ *     with HEXL_AMD_ERR_NO_DEVICE / HEXL_AMD_ERR_HIP.
+ *   - Thread-safety: plans are immutable after creation and may be used from
+ *     many threads concurrently (hexl README.md:264-265 "thread-safe").
+ */
+#ifndef HEXL_AMD_H_
+#define HEXL_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HEXL_AMD_VERSION_MAJOR 0
+#define HEXL_AMD_VERSION_MINOR 1
+
+enum {
+  HEXL_AMD_OK = 0,
+  HEXL_AMD_ERR_INVALID_ARG = 1, /* argument outside the reference's contract */
+  HEXL_AMD_ERR_HIP = 2,         /* a HIP runtime call failed                  */
+  HEXL_AMD_ERR_NO_DEVICE = 3,   /* no gfx950 device visible                   */
+  HEXL_AMD_ERR_ALLOC = 4
+};
+
+/* Message describing the last error on the calling thread ("" if none). */
+const char* hexl_amd_last_error(void);
+
+/* Number of visible HIP devices (0 and HEXL_AMD_ERR_NO_DEVICE if none). */
+int hexl_amd_device_count(int* count);
+
+/* ---------------------------------------------------------------------------
+ * NTT plan == the state of one intel::hexl::NTT object
+ * (hexl/include/hexl/ntt/ntt.hpp:22-293; ctors hexl/ntt/ntt-internal.cpp:24-52;
+ * tables hexl/ntt/ntt-internal.cpp:54-169), resident on one device.
+ * ------------------------------------------------------------------------- */
+typedef struct hexl_amd_ntt hexl_amd_ntt;
+
+/* Replaces NTT::NTT(degree, q[, root_of_unity]) (ntt-internal.cpp:24-52).
+ * degree: power of two in [2, 2^20]; modulus: prime, == 1 mod 2*degree,
+ * < 2^62 (NTT::CheckArguments, ntt-internal.cpp:171-186 -- enforced here in
+ * all builds); root_of_unity: a primitive 2N-th root, or 0 for
+ * MinimalPrimitiveRoot(2N, q).  device: HIP device ordinal, or -1 for the
+ * calling thread's current device.  Builds the twiddle tables on the host,
+ * uploads them once. */
+int hexl_amd_ntt_create(hexl_amd_ntt** plan, uint64_t degree, uint64_t modulus,
+                        uint64_t root_of_unity, int device);
+int hexl_amd_ntt_destroy(hexl_amd_ntt* plan);
+
+/* Getters (ntt.hpp:113-119). */
+uint64_t hexl_amd_ntt_degree(const hexl_amd_ntt* plan);
+uint64_t hexl_amd_ntt_modulus(const hexl_amd_ntt* plan);
+uint64_t hexl_amd_ntt_root_of_unity(const hexl_amd_ntt* plan);
+int hexl_amd_ntt_device(const hexl_amd_ntt* plan);
+
+/* Host copies of the reference-layout tables (ntt.hpp:122-194).  `which`:
+ *   0 GetRootOfUnityPowers          1 GetPrecon32RootOfUnityPowers
+ *   2 GetPrecon64RootOfUnityPowers  3 GetInvRootOfUnityPowers
+ *   4 GetPrecon32InvRootOfUnityPowers 5 GetPrecon52InvRootOfUnityPowers
+ *   6 GetPrecon64InvRootOfUnityPowers
+ * Returns a pointer to N uint64_t owned by the plan (NULL on bad `which`). */
+const uint64_t* hexl_amd_ntt_table(const hexl_amd_ntt* plan, int which);
+
+/* Replaces NTT::ComputeForward (ntt.hpp:99-100; ntt-internal.cpp:188-250 and
+ * the kernels it dispatches to: ntt-radix-2.cpp:17-261, fwd-ntt-avx512.cpp)
+ * for `batch` independent polynomials.  input_mod_factor in {1,2,4}: operand
+ * in [0, f*q); output_mod_factor in {1,4}: result in [0, f*q) (canonical for
+ * 1, any representative for 4). */
+int hexl_amd_ntt_forward(const hexl_amd_ntt* plan, uint64_t* result,
+                         const uint64_t* operand, uint64_t batch,
+                         uint64_t input_mod_factor, uint64_t output_mod_factor,
+                         void* stream);
+
+/* Replaces NTT::ComputeInverse (ntt.hpp:109-110; ntt-internal.cpp:252-310;
+ * ntt-radix-2.cpp:330-519, inv-ntt-avx512.cpp).  input_mod_factor in {1,2},
+ * output_mod_factor in {1,2}. */
+int hexl_amd_ntt_inverse(const hexl_amd_ntt* plan, uint64_t* result,
+                         const uint64_t* operand, uint64_t batch,
+                         uint64_t input_mod_factor, uint64_t output_mod_factor,
+                         void* stream);
+
+/* RNS form: `num_plans` plans (one per prime, same degree, same device);
+ * polynomials [k*batch_per_plan, (k+1)*batch_per_plan) belong to plans[k].
+ * This is the per-modulus loop of the in-tree callers
+ * (hexl/experimental/seal/key-switch-internal.cpp:52-90) as one call. */
+int hexl_amd_ntt_forward_rns(const hexl_amd_ntt* const* plans,
+                             uint64_t num_plans, uint64_t* result,
+                             const uint64_t* operand, uint64_t batch_per_plan,
+                             uint64_t input_mod_factor,
+                             uint64_t output_mod_factor, void* stream);
+int hexl_amd_ntt_inverse_rns(const hexl_amd_ntt* const* plans,
+                             uint64_t num_plans, uint64_t* result,
+                             const uint64_t* operand, uint64_t batch_per_plan,
+                             uint64_t input_mod_factor,
+                             uint64_t output_mod_factor, void* stream);
+
+/* Host-pointer forms used by the intel::hexl::NTT shim: H2D, transform, D2H,
+ * synchronous. */
+int hexl_amd_ntt_forward_host(const hexl_amd_ntt* plan, uint64_t* result,
+                              const uint64_t* operand, uint64_t batch,
+                              uint64_t input_mod_factor,
+                              uint64_t output_mod_factor);
+int hexl_amd_ntt_inverse_host(const hexl_amd_ntt* plan, uint64_t* result,
+                              const uint64_t* operand, uint64_t batch,
+                              uint64_t input_mod_factor,
+                              uint64_t output_mod_factor);
+
+/* ---------------------------------------------------------------------------
+ * Element-wise modular arithmetic on device vectors of n uint64_t.
+ * ------------------------------------------------------------------------- */
+
+/* EltwiseAddMod vector-vector / vector-scalar
+ * (hexl/include/hexl/eltwise/eltwise-add-mod.hpp:22-37;
+ * hexl/eltwise/eltwise-add-mod.cpp:16-113).  Inputs < modulus < 2^63. */
+int hexl_amd_eltwise_add_mod(uint64_t* result, const uint64_t* operand1,
+                             const uint64_t* operand2, uint64_t n,
+                             uint64_t modulus, void* stream);
+int hexl_amd_eltwise_add_mod_scalar(uint64_t* result, const uint64_t* operand1,
+                                    uint64_t operand2, uint64_t n,
+                                    uint64_t modulus, void* stream);
+
+/* EltwiseSubMod (eltwise-sub-mod.hpp:22-37; eltwise-sub-mod.cpp:15-110). */
+int hexl_amd_eltwise_sub_mod(uint64_t* result, const uint64_t* operand1,
+                             const uint64_t* operand2, uint64_t n,
+                             uint64_t modulus, void* stream);
+int hexl_amd_eltwise_sub_mod_scalar(uint64_t* result, const uint64_t* operand1,
+                                    uint64_t operand2, uint64_t n,
+                                    uint64_t modulus, void* stream);
+
+/* EltwiseMultMod (eltwise-mult-mod.hpp:23-25; eltwise-mult-mod.cpp:18-83;
+ * eltwise-mult-mod-internal.hpp:34-100).  input_mod_factor in {1,2,4},
+ * input_mod_factor * modulus < 2^63, modulus < 2^62. */
+int hexl_amd_eltwise_mult_mod(uint64_t* result, const uint64_t* operand1,
+                              const uint64_t* operand2, uint64_t n,
+                              uint64_t modulus, uint64_t input_mod_factor,
+                              void* stream);
+
+/* EltwiseFMAMod: result = (arg1 * arg2 + arg3) mod q, arg3 may be NULL
+ * (eltwise-fma-mod.hpp:22-24; eltwise-fma-mod.cpp:17-101;
+ * eltwise-fma-mod-internal.hpp:12-39).  input_mod_factor in {1,2,4,8},
+ * modulus < 2^61. */
+int hexl_amd_eltwise_fma_mod(uint64_t* result, const uint64_t* arg1,
+                             uint64_t arg2, const uint64_t* arg3, uint64_t n,
+                             uint64_t modulus, uint64_t input_mod_factor,
+                             void* stream);
+
+/* EltwiseReduceMod (eltwise-reduce-mod.hpp:24-26; eltwise-reduce-mod.cpp:16-123).
+ * input_mod_factor in {modulus, 2, 4}; output_mod_factor in {1, 2}. */
+int hexl_amd_eltwise_reduce_mod(uint64_t* result, const uint64_t* operand,
+                                uint64_t n, uint64_t modulus,
+                                uint64_t input_mod_factor,
+                                uint64_t output_mod_factor, void* stream);
+
+/* Fused EltwiseFMAMod + EltwiseReduceMod for the BASELINE config-5 shape:
+ * result = ((arg1 mod q) * arg2 + (arg3 mod q)) mod q where arg1/arg3 are
+ * arbitrary 64-bit words when input_mod_factor == modulus (single-word Barrett
+ * first, eltwise-reduce-mod.cpp:32-55), else as hexl_amd_eltwise_fma_mod. */
+int hexl_amd_eltwise_reduce_fma_mod(uint64_t* result, const uint64_t* arg1,
+                                    uint64_t arg2, const uint64_t* arg3,
+                                    uint64_t n, uint64_t modulus,
+                                    uint64_t input_mod_factor, void* stream);
+
+/* Host-pointer forms for the intel::hexl::Eltwise* shim (synchronous).
+ * `op`: 0 add, 1 add_scalar, 2 sub, 3 sub_scalar, 4 mult, 5 fma, 6 reduce.
+ * Unused operands are NULL / 0. */
+int hexl_amd_eltwise_host(int op, uint64_t* result, const uint64_t* operand1,
+                          const uint64_t* operand2, uint64_t scalar,
+                          uint64_t n, uint64_t modulus,
+                          uint64_t input_mod_factor,
+                          uint64_t output_mod_factor);
+
+/* ---------------------------------------------------------------------------
+ * Host-side scalar number theory the plan builder uses; exported because it
+ * is part of the reference's installed API
+ * (hexl/include/hexl/number-theory/number-theory.hpp:19-339,
+ *  hexl/number-theory/number-theory.cpp:13-261).
+ * ------------------------------------------------------------------------- */
+uint64_t hexl_amd_multiply_factor(uint64_t operand, uint64_t bit_shift,
+                                  uint64_t modulus);
+uint64_t hexl_amd_inverse_mod(uint64_t x, uint64_t modulus);
+uint64_t hexl_amd_multiply_mod(uint64_t x, uint64_t y, uint64_t modulus);
+uint64_t hexl_amd_pow_mod(uint64_t base, uint64_t exp, uint64_t modulus);
+int hexl_amd_is_primitive_root(uint64_t root, uint64_t degree,
+                               uint64_t modulus);
+uint64_t hexl_amd_generate_primitive_root(uint64_t degree, uint64_t modulus);
+uint64_t hexl_amd_minimal_primitive_root(uint64_t degree, uint64_t modulus);
+uint64_t hexl_amd_reverse_bits(uint64_t x, uint64_t bit_width);
+int hexl_amd_is_prime(uint64_t n);
+/* Writes up to num_primes primes to out; returns how many were found. */
+size_t hexl_amd_generate_primes(uint64_t* out, size_t num_primes,
+                                size_t bit_size, int prefer_small_primes,
+                                size_t ntt_size);
+/* NTT::CheckArguments (ntt-internal.cpp:171-186): 1 if (degree, modulus) is a
+ * legal negacyclic NTT parameter set. */
+int hexl_amd_ntt_check_arguments(uint64_t degree, uint64_t modulus);
+
+/* ---------------------------------------------------------------------------
+ * Bench / test support (device-side synthetic input):
+ * poly b of the batch gets coefficients splitmix64(seed0 + b) mod bound.
+ * ------------------------------------------------------------------------- */
+int hexl_amd_fill_splitmix(uint64_t* data, uint64_t n, uint64_t batch,
+                           uint64_t seed0, uint64_t bound, void* stream);
+
+/* Per-kernel timing for bench.py's roofline line: between start and stop every
+ * kernel this thread launches through the entry points above is bracketed by a
+ * pair of hipEvents recorded on its launch stream.  stop() synchronises the
+ * events; get(i) returns the kernel family name and its duration in ms. */
+int hexl_amd_profile_start(int max_records);
+int hexl_amd_profile_stop(int* num_records);
+int hexl_amd_profile_get(int i, const char** name, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEXL_AMD_H_ */

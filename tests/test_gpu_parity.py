@@ -1,0 +1,487 @@
+"""GPU parity tests: the HIP path (through the C-ABI, via the hexl_amd Python
+mirror of intel::hexl::NTT / Eltwise*) against the CPU oracle and the
+reference's known-answer vectors.  Bit-exact for canonical outputs; lazy
+outputs are compared modulo q plus a range check, exactly as the reference's
+own tests do (test/test-ntt.cpp:246-251, test/test-ntt-avx512.cpp:268-278).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "hexl_kat.json")))
+
+
+@pytest.fixture(scope="module")
+def hx():
+    import hexl_amd
+    return hexl_amd
+
+
+@pytest.fixture(scope="module")
+def ho():
+    from oracle import hexl_oracle
+    return hexl_oracle
+
+
+def U(x):
+    return np.asarray(x, dtype=np.uint64)
+
+
+def dev(hx, a):
+    return hx.from_numpy(U(a))
+
+
+def host(hx, t):
+    return hx.to_numpy(t)
+
+
+def resolve_q(ho, q):
+    return ho.generate_primes(*q["gp"])[0] if isinstance(q, dict) else q
+
+
+def resolve(v, q):
+    if isinstance(v, dict):
+        return q - v["q_minus"]
+    if isinstance(v, list):
+        return [resolve(x, q) for x in v]
+    return v
+
+
+# ---------------------------------------------------------------- NTT KATs
+@pytest.mark.parametrize("case", KAT["ntt_forward"]["cases"],
+                         ids=lambda c: f"n{c['n']}_q{c['q']}")
+def test_ntt_kat_api(hx, case):
+    """TEST_P(DegreeModulusInputOutput, API), test/test-ntt.cpp:227-339."""
+    import torch
+    n, q = case["n"], case["q"]
+    inp, exp = U(case["in"]), U(case["out"])
+    ntt = hx.NTT(n, q)
+    # in-place forward
+    buf = dev(hx, inp)
+    ntt.ComputeForward(buf, buf, 1, 1)
+    assert (host(hx, buf) == exp).all()
+    # in-place lazy forward
+    buf = dev(hx, inp)
+    ntt.ComputeForward(buf, buf, 2, 4)
+    got = host(hx, buf)
+    assert (got < 4 * q).all() and (got % np.uint64(q) == exp).all()
+    # out-of-place round trip; the destination starts as garbage (99)
+    src = dev(hx, inp)
+    out = torch.full_like(src, 99)
+    ntt.ComputeForward(out, src, 1, 1)
+    assert (host(hx, out) == exp).all()
+    assert (host(hx, src) == inp).all()
+    back = torch.full_like(src, 99)
+    ntt.ComputeInverse(back, out, 1, 1)
+    assert (host(hx, back) == inp).all()
+    # forward with in_mf = 2
+    ntt.ComputeForward(out, src, 2, 1)
+    assert (host(hx, out) == exp).all()
+    # lazy inverse
+    ntt.ComputeInverse(back, out, 1, 2)
+    got = host(hx, back)
+    assert (got < 2 * q).all() and (got % np.uint64(q) == inp).all()
+    # in-place inverse
+    ntt.ComputeInverse(out, out, 1, 1)
+    assert (host(hx, out) == inp).all()
+
+
+@pytest.mark.parametrize("case", KAT["ntt_root_powers"]["cases"])
+def test_ntt_root_powers(hx, case):
+    ntt = hx.NTT(case["n"], case["q"])
+    assert [int(x) for x in ntt.GetRootOfUnityPowers()] == case["powers"]
+
+
+def test_ntt_tables_match_oracle(hx, ho):
+    n, q = 1024, 0xffffee001
+    a, b = hx.NTT(n, q), ho.NTT(n, q)
+    assert a.GetMinimalRootOfUnity() == b.w == 46310425
+    assert (a.GetRootOfUnityPowers() == b.root_pows).all()
+    assert (a.GetPrecon64RootOfUnityPowers() == b.precon_root_pows).all()
+    assert (a.GetInvRootOfUnityPowers() == b.inv_root_pows).all()
+    assert (a.GetPrecon64InvRootOfUnityPowers() == b.precon_inv_root_pows).all()
+    assert [int(x) for x in a.GetPrecon32RootOfUnityPowers()] == [
+        (int(w) << 32) // q for w in b.root_pows]
+    assert [int(x) for x in a.GetPrecon52InvRootOfUnityPowers()] == [
+        (int(w) << 52) // q for w in b.inv_root_pows]
+
+
+def test_ntt_custom_root(hx, ho):
+    """NTT(N, q, root): test/test-ntt.cpp:200-216 uses the minimal root; also
+    check a non-minimal primitive root against the oracle."""
+    n, q = 8, 769
+    w = ho.minimal_primitive_root(2 * n, q)
+    x = dev(hx, [1, 2, 3, 4, 5, 6, 7, 8])
+    y1, y2 = x.clone(), x.clone()
+    hx.NTT(n, q).ComputeForward(y1, y1, 1, 1)
+    hx.NTT(n, q, w).ComputeForward(y2, y2, 1, 1)
+    assert (host(hx, y1) == host(hx, y2)).all()
+    w3 = pow(w, 3, q)
+    y3 = x.clone()
+    hx.NTT(n, q, w3).ComputeForward(y3, y3, 1, 1)
+    assert (host(hx, y3) == ho.NTT(n, q, w3).forward(host(hx, x), 1, 1)).all()
+
+
+# ---------------------------------------------------------------- NTT vs oracle
+SWEEP_N = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384,
+           32768, 65536, 131072]
+
+
+@pytest.mark.parametrize("n", SWEEP_N)
+@pytest.mark.parametrize("bits", [27, 33, 49, 54, 60, 61])
+def test_ntt_vs_oracle(hx, ho, n, bits):
+    """Random inputs, all legal (in_mf, out_mf), in-place and out-of-place,
+    small and large moduli (pattern of test/test-ntt-avx512.cpp:169-398 and
+    test/test-ntt.cpp:406-478).  61-bit primes exercise the generic 64-bit
+    path, <= 54-bit ones the q < 2^55 path."""
+    import torch
+    if n > 8192 and bits in (27, 33, 60):
+        pytest.skip("large-N sweep trimmed to three moduli")
+    q = ho.generate_primes(1, bits, bits % 2 == 0, n)[0]
+    batch = 3 if n <= 16384 else 2
+    ont, gnt = ho.NTT(n, q), hx.NTT(n, q)
+    x = np.stack([ho.fill_splitmix(n, bits * 1000 + n + b, q) for b in range(batch)])
+    f_ref = ont.forward(x, 1, 1)
+    dx = dev(hx, x)
+    out = torch.empty_like(dx)
+    gnt.ComputeForward(out, dx, 1, 1)
+    assert (host(hx, out) == f_ref).all()
+    assert (host(hx, dx) == x).all()  # operand untouched out-of-place
+    inplace = dx.clone()
+    gnt.ComputeForward(inplace, inplace, 1, 1)
+    assert (host(hx, inplace) == f_ref).all()
+    # inverse, canonical, out-of-place and in-place
+    back = torch.empty_like(dx)
+    gnt.ComputeInverse(back, out, 1, 1)
+    assert (host(hx, back) == x).all()
+    gnt.ComputeInverse(out, out, 1, 1)
+    assert (host(hx, out) == x).all()
+    # lazy ranges
+    for in_mf, out_mf in ((1, 4), (2, 1), (2, 4), (4, 1), (4, 4)):
+        xin = np.stack([ho.fill_splitmix(n, 77 + in_mf + b, in_mf * q) for b in range(batch)])
+        ref = ont.forward(xin % np.uint64(q), 1, 1)
+        d = dev(hx, xin)
+        gnt.ComputeForward(d, d, in_mf, out_mf)
+        got = host(hx, d)
+        assert (got < out_mf * q).all()
+        assert ((got % np.uint64(q)) == ref).all()
+        if out_mf == 1:
+            assert (got == ref).all()
+    for in_mf, out_mf in ((1, 2), (2, 1), (2, 2)):
+        xin = np.stack([ho.fill_splitmix(n, 99 + in_mf + b, in_mf * q) for b in range(batch)])
+        ref = ont.inverse(xin % np.uint64(q), 1, 1)
+        d = dev(hx, xin)
+        gnt.ComputeInverse(d, d, in_mf, out_mf)
+        got = host(hx, d)
+        assert (got < out_mf * q).all()
+        assert ((got % np.uint64(q)) == ref).all()
+        if out_mf == 1:
+            assert (got == ref).all()
+
+
+def test_ntt_ragged_batches(hx, ho):
+    """Batches that do not fill a 4096-element tile, or straddle one."""
+    import torch
+    for n, batch in ((2, 1), (2, 5), (64, 1), (64, 65), (1024, 3), (1024, 5), (4096, 1)):
+        q = ho.generate_primes(1, 54, True, n)[0]
+        x = np.stack([ho.fill_splitmix(n, 5 + b, q) for b in range(batch)])
+        ont, gnt = ho.NTT(n, q), hx.NTT(n, q)
+        d = dev(hx, x)
+        guard = torch.full((d.numel() + 8192,), -7, dtype=torch.int64, device="cuda")
+        res = guard[4096:4096 + d.numel()].view_as(d)
+        gnt.ComputeForward(res, d, 1, 1)
+        assert (host(hx, res) == ont.forward(x, 1, 1)).all()
+        assert (guard[:4096] == -7).all() and (guard[4096 + d.numel():] == -7).all()
+        gnt.ComputeInverse(res, res, 1, 1)
+        assert (host(hx, res) == x).all()
+        assert (guard[:4096] == -7).all() and (guard[4096 + d.numel():] == -7).all()
+
+
+def test_ntt_misaligned_views(hx, ho):
+    """Buffers that are only 8-byte aligned (the reference's API promises no
+    more than uint64_t alignment)."""
+    import torch
+    for n in (64, 4096, 65536):
+        q = ho.generate_primes(1, 54, True, n)[0]
+        x = np.stack([ho.fill_splitmix(n, 3 + b, q) for b in range(2)])
+        ont, gnt = ho.NTT(n, q), hx.NTT(n, q)
+        raw_in = torch.zeros(2 * n + 3, dtype=torch.int64, device="cuda")
+        raw_out = torch.zeros(2 * n + 3, dtype=torch.int64, device="cuda")
+        vin, vout = raw_in[1:1 + 2 * n], raw_out[1:1 + 2 * n]
+        assert vin.data_ptr() % 16 == 8
+        vin.copy_(hx.from_numpy(x).reshape(-1))
+        gnt.ComputeForward(vout, vin, 1, 1)
+        assert (host(hx, vout).reshape(2, n) == ont.forward(x, 1, 1)).all()
+        gnt.ComputeInverse(vout, vout, 1, 1)
+        assert (host(hx, vout).reshape(2, n) == x).all()
+        assert int(raw_out[0]) == 0 and int(raw_out[-1]) == 0
+
+
+def test_ntt_zeros(hx):
+    """NttNativeTest.ForwardZeros / InverseZeros, test/test-ntt.cpp:406-418."""
+    import torch
+    for n in (16, 1024, 65536):
+        q = hx.GeneratePrimes(1, 54, True, n)[0]
+        ntt = hx.NTT(n, q)
+        z = torch.zeros(n, dtype=torch.int64, device="cuda")
+        ntt.ComputeForward(z, z, 1, 1)
+        assert int(z.abs().sum()) == 0
+        ntt.ComputeInverse(z, z, 1, 1)
+        assert int(z.abs().sum()) == 0
+
+
+def test_ntt_argument_errors(hx):
+    """The reference throws only under HEXL_DEBUG (test/test-ntt.cpp:21-94);
+    the C-ABI reports the same contract violations in all builds."""
+    import torch
+    with pytest.raises(hx.HexlAmdError):
+        hx.NTT(1024, 0xffffee001 + 2)  # not prime / not 1 mod 2N
+    with pytest.raises(hx.HexlAmdError):
+        hx.NTT(1000, 0xffffee001)  # not a power of two
+    with pytest.raises(hx.HexlAmdError):
+        hx.NTT(8, 769, 2)  # not a primitive 2N-th root
+    ntt = hx.NTT(8, 769)
+    x = torch.zeros(8, dtype=torch.int64, device="cuda")
+    for bad in ((3, 1), (1, 2), (8, 1)):
+        with pytest.raises(hx.HexlAmdError):
+            ntt.ComputeForward(x, x, *bad)
+    for bad in ((4, 1), (1, 4)):
+        with pytest.raises(hx.HexlAmdError):
+            ntt.ComputeInverse(x, x, *bad)
+    with pytest.raises(hx.HexlAmdError):
+        ntt.ComputeForward(x, x.cpu(), 1, 1)
+
+
+def test_ntt_rns(hx, ho):
+    """BASELINE configs[3] shape at reduced batch: 8 RNS primes x B polys."""
+    import torch
+    n, B = 65536, 2
+    primes = KAT["generate_primes_survey_probe"]["cases"][1]["out"]
+    plans = [hx.NTT(n, p) for p in primes]
+    x = np.stack([np.stack([ho.fill_splitmix(n, 1000 * k + b, p) for b in range(B)])
+                  for k, p in enumerate(primes)])
+    d = dev(hx, x)
+    out = torch.empty_like(d)
+    hx.ComputeForwardRNS(plans, out, d, 1, 1)
+    got = host(hx, out)
+    for k, p in enumerate(primes):
+        assert (got[k] == ho.NTT(n, p).forward(x[k], 1, 1)).all()
+    hx.ComputeInverseRNS(plans, out, out, 1, 1)
+    assert (host(hx, out) == x).all()
+
+
+def test_ntt_headline_full_size_properties(hx, ho):
+    """BASELINE configs[2] at full size: N=65536, 55-bit q, batch=4096 (2 GiB).
+    Size-independent properties on the device plus oracle spot checks."""
+    import torch
+    n, batch = 65536, 4096
+    q = KAT["generate_primes_survey_probe"]["cases"][1]["out"][0]
+    ntt = hx.NTT(n, q)
+    x = torch.empty((batch, n), dtype=torch.int64, device="cuda")
+    hx.fill_splitmix(x, n, batch, 1, q)
+    # device generator == oracle generator
+    assert (host(hx, x[17]) == ho.fill_splitmix(n, 1 + 17, q)).all()
+    y = torch.empty_like(x)
+    ntt.ComputeForward(y, x, 1, 1)
+    assert int(y.min()) >= 0 and int(y.max()) < q
+    ont = ho.NTT(n, q)
+    for b in (0, 1, 2047, 4095):
+        assert (host(hx, y[b]) == ont.forward(host(hx, x[b]), 1, 1)).all()
+    # linearity: NTT(x_b + x_{b+1}) == NTT(x_b) + NTT(x_{b+1}) on 64 pairs
+    s = torch.empty((64, n), dtype=torch.int64, device="cuda")
+    hx.EltwiseAddMod(s, x[:64].contiguous(), x[64:128].contiguous(), 64 * n, q)
+    fs = torch.empty_like(s)
+    ntt.ComputeForward(fs, s, 1, 1)
+    fsum = torch.empty_like(s)
+    hx.EltwiseAddMod(fsum, y[:64].contiguous(), y[64:128].contiguous(), 64 * n, q)
+    assert torch.equal(fs, fsum)
+    # round trip in place over the whole batch
+    ntt.ComputeInverse(y, y, 1, 1)
+    assert torch.equal(x, y)
+
+
+# ---------------------------------------------------------------- eltwise KATs
+@pytest.mark.parametrize("case", KAT["eltwise_mult_mod"]["cases"])
+def test_mult_mod_kat(hx, ho, case):
+    import torch
+    q = resolve_q(ho, case["q"])
+    a, b, exp = (resolve(case[k], q) for k in ("a", "b", "out"))
+    da, db = dev(hx, a), dev(hx, b)
+    out = torch.zeros_like(da)
+    hx.EltwiseMultMod(out, da, db, len(a), q, case["in_mf"])
+    assert host(hx, out).tolist() == exp
+    hx.EltwiseMultMod(da, da, db, len(a), q, case["in_mf"])  # in place
+    assert host(hx, da).tolist() == exp
+
+
+@pytest.mark.parametrize("case", KAT["eltwise_fma_mod"]["cases"])
+def test_fma_mod_kat(hx, ho, case):
+    q = resolve_q(ho, case["q"])
+    da = dev(hx, case["a"])
+    dc = dev(hx, case["c"]) if case["c"] is not None else None
+    hx.EltwiseFMAMod(da, da, case["s"], dc, len(case["a"]), q, case["in_mf"])
+    assert host(hx, da).tolist() == case["out"]
+
+
+@pytest.mark.parametrize("case", KAT["eltwise_reduce_mod"]["cases"])
+def test_reduce_mod_kat(hx, case):
+    import torch
+    q = case["q"]
+    in_mf = q if case["in_mf"] == "q" else case["in_mf"]
+    da = dev(hx, case["a"])
+    out = torch.zeros_like(da)
+    hx.EltwiseReduceMod(out, da, len(case["a"]), q, in_mf, case["out_mf"])
+    assert host(hx, out).tolist() == case["out"]
+
+
+@pytest.mark.parametrize("case", KAT["eltwise_add_mod"]["cases"])
+def test_add_mod_kat(hx, ho, case):
+    q = resolve_q(ho, case["q"])
+    a, b, exp = (resolve(case[k], q) for k in ("a", "b", "out"))
+    da = dev(hx, a)
+    hx.EltwiseAddMod(da, da, b if isinstance(b, int) else dev(hx, b), len(a), q)
+    assert host(hx, da).tolist() == exp
+
+
+@pytest.mark.parametrize("case", KAT["eltwise_sub_mod"]["cases"])
+def test_sub_mod_kat(hx, ho, case):
+    q = resolve_q(ho, case["q"])
+    a, b, exp = (resolve(case[k], q) for k in ("a", "b", "out"))
+    da = dev(hx, a)
+    hx.EltwiseSubMod(da, da, b if isinstance(b, int) else dev(hx, b), len(a), q)
+    assert host(hx, da).tolist() == exp
+
+
+@pytest.mark.parametrize("bits", [1, 2, 10, 30, 31, 32, 33, 49, 50, 51, 54, 58, 59, 60, 61])
+@pytest.mark.parametrize("n,offset", [(1031, 0), (1031, 1), (1, 0), (4096, 0)])
+def test_eltwise_vs_oracle(hx, ho, bits, n, offset):
+    """n = 1031 (odd on purpose, test/test-eltwise-fma-mod-avx512.cpp:143-211)
+    and an 8-byte-misaligned view exercise the scalar head/tail paths."""
+    import torch
+    rng = np.random.default_rng(bits * 7 + n)
+    q = (int(rng.integers(1 << bits, 1 << (bits + 1), dtype=np.uint64)) | 1) if bits > 1 else 3
+
+    def dv(a):
+        t = torch.zeros(n + offset + 3, dtype=torch.int64, device="cuda")
+        v = t[offset:offset + n]
+        v.copy_(hx.from_numpy(a))
+        return v
+
+    def out():
+        return torch.zeros(n + offset + 3, dtype=torch.int64, device="cuda")[offset:offset + n]
+
+    for in_mf in (1, 2, 4):
+        if in_mf * q >= 1 << 63:
+            continue
+        a = rng.integers(0, in_mf * q, size=n, dtype=np.uint64)
+        b = rng.integers(0, in_mf * q, size=n, dtype=np.uint64)
+        r = out()
+        hx.EltwiseMultMod(r, dv(a), dv(b), n, q, in_mf)
+        assert (host(hx, r) == ho.eltwise_mult_mod(a, b, q, in_mf)).all()
+    if bits <= 60:
+        for in_mf in (1, 2, 4, 8):
+            a = rng.integers(0, in_mf * q, size=n, dtype=np.uint64)
+            c = rng.integers(0, in_mf * q, size=n, dtype=np.uint64)
+            s = int(rng.integers(0, in_mf * q, dtype=np.uint64))
+            r = out()
+            hx.EltwiseFMAMod(r, dv(a), s, dv(c), n, q, in_mf)
+            assert (host(hx, r) == ho.eltwise_fma_mod(a, s, c, q, in_mf)).all()
+            hx.EltwiseFMAMod(r, dv(a), s, None, n, q, in_mf)
+            assert (host(hx, r) == ho.eltwise_fma_mod(a, s, None, q, in_mf)).all()
+        # fused reduce + fma on arbitrary 64-bit words
+        a = rng.integers(0, 1 << 64, size=n, dtype=np.uint64)
+        c = rng.integers(0, 1 << 64, size=n, dtype=np.uint64)
+        s = int(rng.integers(0, q, dtype=np.uint64))
+        r = out()
+        hx.EltwiseReduceFMAMod(r, dv(a), s, dv(c), n, q, q)
+        ref = ho.eltwise_fma_mod(ho.eltwise_reduce_mod(a, q, q, 1), s,
+                                 ho.eltwise_reduce_mod(c, q, q, 1), q, 1)
+        assert (host(hx, r) == ref).all()
+    a = rng.integers(0, q, size=n, dtype=np.uint64)
+    b = rng.integers(0, q, size=n, dtype=np.uint64)
+    s = int(b[0])
+    r = out()
+    hx.EltwiseAddMod(r, dv(a), dv(b), n, q)
+    assert (host(hx, r) == ho.eltwise_add_mod(a, b, q)).all()
+    hx.EltwiseAddMod(r, dv(a), s, n, q)
+    assert (host(hx, r) == ho.eltwise_add_mod(a, s, q)).all()
+    hx.EltwiseSubMod(r, dv(a), dv(b), n, q)
+    assert (host(hx, r) == ho.eltwise_sub_mod(a, b, q)).all()
+    hx.EltwiseSubMod(r, dv(a), s, n, q)
+    assert (host(hx, r) == ho.eltwise_sub_mod(a, s, q)).all()
+    big = rng.integers(0, 1 << 64, size=n, dtype=np.uint64)
+    hx.EltwiseReduceMod(r, dv(big), n, q, q, 1)
+    assert (host(hx, r) == ho.eltwise_reduce_mod(big, q, q, 1)).all()
+    hx.EltwiseReduceMod(r, dv(big), n, q, q, 2)
+    got = host(hx, r)
+    assert (got < 2 * q).all() and (got % np.uint64(q) == big % np.uint64(q)).all()
+    if 4 * q < 1 << 64:
+        x4 = rng.integers(0, 4 * q, size=n, dtype=np.uint64)
+        hx.EltwiseReduceMod(r, dv(x4), n, q, 4, 1)
+        assert (host(hx, r) == ho.eltwise_reduce_mod(x4, q, 4, 1)).all()
+        hx.EltwiseReduceMod(r, dv(x4), n, q, 4, 2)
+        assert (host(hx, r) == ho.eltwise_reduce_mod(x4, q, 4, 2)).all()
+    x2 = rng.integers(0, 2 * q, size=n, dtype=np.uint64)
+    hx.EltwiseReduceMod(r, dv(x2), n, q, 2, 1)
+    assert (host(hx, r) == ho.eltwise_reduce_mod(x2, q, 2, 1)).all()
+
+
+def test_eltwise_config2_and_config5_shapes(hx, ho):
+    """BASELINE configs[1] (N=4096 x 256, 50-bit) MultMod and configs[4]
+    (N=131072 x 1024, 61-bit... FMAMod needs q < 2^61: the first 61-bit prime
+    of the survey) at full size, checked on sampled slices + a checksum."""
+    import torch
+    q = KAT["generate_primes_survey_probe"]["cases"][0]["out"][0]
+    n = 4096 * 256
+    a = torch.empty(n, dtype=torch.int64, device="cuda")
+    b = torch.empty(n, dtype=torch.int64, device="cuda")
+    hx.fill_splitmix(a, 4096, 256, 11, q)
+    hx.fill_splitmix(b, 4096, 256, 911, q)
+    r = torch.empty_like(a)
+    hx.EltwiseMultMod(r, a, b, n, q, 1)
+    assert (host(hx, r) == ho.eltwise_mult_mod(host(hx, a), host(hx, b), q, 1)).all()
+
+    q = KAT["generate_primes_survey_probe"]["cases"][2]["out"][0]
+    N, B = 131072, 1024
+    n = N * B
+    a = torch.empty(n, dtype=torch.int64, device="cuda")
+    c = torch.empty(n, dtype=torch.int64, device="cuda")
+    hx.fill_splitmix(a, N, B, 21, 4 * q)
+    hx.fill_splitmix(c, N, B, 1021, 4 * q)
+    s = 3 * q + 12345
+    r = torch.empty_like(a)
+    hx.EltwiseFMAMod(r, a, s, c, n, q, 4)
+    assert int(r.min()) >= 0 and int(r.max()) < q
+    for blk in (0, 511, 1023):
+        sl = slice(blk * N, (blk + 1) * N)
+        ref = ho.eltwise_fma_mod(host(hx, a[sl]), s, host(hx, c[sl]), q, 4)
+        assert (host(hx, r[sl]) == ref).all()
+    # fused reduce+fma == reduce, reduce, fma
+    hx.fill_splitmix(a, N, B, 31, 0)
+    hx.fill_splitmix(c, N, B, 1031, 0)
+    fused = torch.empty_like(a)
+    hx.EltwiseReduceFMAMod(fused, a, s % q, c, n, q, q)
+    ra, rc = torch.empty_like(a), torch.empty_like(a)
+    hx.EltwiseReduceMod(ra, a, n, q, q, 1)
+    hx.EltwiseReduceMod(rc, c, n, q, q, 1)
+    hx.EltwiseFMAMod(ra, ra, s % q, rc, n, q, 1)
+    assert torch.equal(fused, ra)
+
+
+def test_eltwise_argument_errors(hx):
+    import torch
+    x = torch.zeros(8, dtype=torch.int64, device="cuda")
+    with pytest.raises(hx.HexlAmdError):
+        hx.EltwiseMultMod(x, x, x, 8, 769, 3)
+    with pytest.raises(hx.HexlAmdError):
+        hx.EltwiseFMAMod(x, x, 1, None, 8, 1 << 61, 1)
+    with pytest.raises(hx.HexlAmdError):
+        hx.EltwiseAddMod(x, x, 800, 8, 769)
+    with pytest.raises(hx.HexlAmdError):
+        hx.EltwiseReduceMod(x, x, 8, 769, 3, 1)
+    with pytest.raises(hx.HexlAmdError):
+        hx.EltwiseAddMod(x, x, x, 0, 769)

@@ -179,19 +179,21 @@ int hexl_amd_ntt_create(hexl_amd_ntt** out, uint64_t degree, uint64_t modulus,
     p->host[2][i] = nt::multiply_factor(R[i], 64, q);
     p->host[6][i] = nt::multiply_factor(IR[i], 64, q);
   }
-  // Device tables: heap-ordered (value, precon) pairs.
+  // Device tables: heap-ordered (value, Shoup factor) pairs; the factor has 63
+  // fractional bits under the Lazy arithmetic policy, 64 otherwise.
+  const u64 shoup_bits = q < kLazyModulusBound ? 63 : 64;
   std::vector<ulonglong2> hf(n), hi(n);
   for (u64 i = 0; i < n; ++i) {
     hf[i].x = R[i];
-    hf[i].y = p->host[2][i];
+    hf[i].y = nt::multiply_factor(R[i], shoup_bits, q);
     hi[i].x = Rinv[i];
-    hi[i].y = nt::multiply_factor(Rinv[i], 64, q);
+    hi[i].y = nt::multiply_factor(Rinv[i], shoup_bits, q);
   }
   InvLast il;
   il.n1 = nt::inverse_mod(n, q);
-  il.n1p = nt::multiply_factor(il.n1, 64, q);
+  il.n1p = nt::multiply_factor(il.n1, shoup_bits, q);
   il.n1w = nt::multiply_mod(il.n1, Rinv[1], q);
-  il.n1wp = nt::multiply_factor(il.n1w, 64, q);
+  il.n1wp = nt::multiply_factor(il.n1w, shoup_bits, q);
 
   DeviceScope scope(device);
   hipError_t e = scope.err;
@@ -209,7 +211,10 @@ int hexl_amd_ntt_create(hexl_amd_ntt** out, uint64_t degree, uint64_t modulus,
   }
   p->t.fwd = p->d_fwd;
   p->t.inv = p->d_inv;
-  p->t.q = q;
+  p->t.mod.q = q;
+  p->t.mod.two_q = q << 1;
+  p->t.mod.neg_q = 0 - q;
+  p->t.mod.barrett = nt::multiply_factor(1, 64, q);
   p->t.log_n = p->log_n;
   p->t.inv_last = il;
   *out = p;

@@ -5,10 +5,9 @@
 #include <hip/hip_vector_types.h>
 #include <stdint.h>
 
-namespace hexl_amd {
+#include "modarith.h"
 
-typedef uint64_t u64;
-typedef uint32_t u32;
+namespace hexl_amd {
 
 // Scalars of the last inverse stage: n1 = N^-1 mod q, n1w = N^-1 * R[1]^-1,
 // each with its floor(x * 2^64 / q) companion
@@ -17,11 +16,15 @@ struct InvLast {
   u64 n1, n1p, n1w, n1wp;
 };
 
+// Moduli below this bound use the Lazy arithmetic policy (modarith.h); their
+// device tables carry 63-bit Shoup factors.
+constexpr u64 kLazyModulusBound = 1ull << 56;
+
 // Device-resident state of one NTT plan.
 struct NttTables {
-  const ulonglong2* fwd;  // heap-ordered (R[n], floor(R[n] 2^64 / q)), n in [0, N)
+  const ulonglong2* fwd;  // heap-ordered (R[n], floor(R[n] 2^s / q)), s = 63 (Lazy) or 64
   const ulonglong2* inv;  // heap-ordered (R[n]^-1, precon)
-  u64 q;
+  ModConst mod;
   u32 log_n;
   InvLast inv_last;
 };

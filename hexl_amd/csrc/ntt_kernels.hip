@@ -33,6 +33,7 @@
 // outputs (output_mod_factor == 1) are therefore bit-identical to the
 // reference; lazy outputs are congruent and in range.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "internal.h"
 #include "modarith.h"
@@ -49,7 +50,7 @@ thread_local ProfileSink* g_profile = nullptr;
 // uses heap nodes (node << v) + g, g = 0 .. 2^v - 1.
 template <int R, class A>
 __device__ __forceinline__ void fwd_subtree(u64* x, const ulonglong2* __restrict__ tw,
-                                            u32 node, u64 q, u64 two_q) {
+                                            u32 node, const ModConst& m) {
 #pragma unroll
   for (int v = 0; v < R; ++v) {
     const int half = 1 << (R - 1 - v);
@@ -57,39 +58,57 @@ __device__ __forceinline__ void fwd_subtree(u64* x, const ulonglong2* __restrict
     for (int g = 0; g < (1 << v); ++g) {
       const ulonglong2 w = tw[(node << v) + g];
 #pragma unroll
-      for (int j = 0; j < half; ++j) {
-        fwd_butterfly<A>(x[g * 2 * half + j], x[g * 2 * half + j + half], w.x, w.y, q,
-                         two_q);
-      }
+      for (int j = 0; j < half; ++j)
+        fwd_butterfly<A>(x[g * 2 * half + j], x[g * 2 * half + j + half], w.x, w.y, m);
     }
   }
 }
 
+// number of leading zero bits of e seen as an R-bit number
+constexpr int leading_zeros(int e, int R) {
+  int n = 0;
+  for (int b = R - 1; b >= 0 && !((e >> b) & 1); --b) ++n;
+  return n;
+}
+
+template <int R, int E0, class A>
+struct InvLadder {
+  static __device__ __forceinline__ void run(u64* x, const ModConst& m) {
+    x[E0] = inv_ladder<leading_zeros(E0, R)>(x[E0], m);
+    InvLadder<R, E0 + 1, A>::run(x, m);
+  }
+};
+template <int R, class A>
+struct InvLadder<R, (1 << R), A> {
+  static __device__ __forceinline__ void run(u64*, const ModConst&) {}
+};
+
 // r inverse stages (deepest level first).  With LAST the v == 0 stage is the
 // root of the whole transform and folds N^-1 in (ntt-radix-2.cpp:490-509).
+// Lazy policy: no conditional subtraction inside the subtree, [0,2q) restored
+// at exit (not needed after LAST, whose outputs are both lazy products).
 template <int R, class A, bool LAST>
 __device__ __forceinline__ void inv_subtree(u64* x, const ulonglong2* __restrict__ tw,
-                                            u32 node, u64 q, u64 two_q,
-                                            const InvLast& il) {
+                                            u32 node, const ModConst& m, const InvLast& il) {
 #pragma unroll
   for (int v = R - 1; v >= 0; --v) {
     const int half = 1 << (R - 1 - v);
+    const int k = R - 1 - v;
 #pragma unroll
     for (int g = 0; g < (1 << v); ++g) {
       if (LAST && v == 0) {
 #pragma unroll
         for (int j = 0; j < half; ++j)
-          inv_butterfly_last<A>(x[j], x[j + half], il.n1, il.n1p, il.n1w, il.n1wp, q,
-                                two_q);
+          inv_butterfly_last<A>(x[j], x[j + half], il.n1, il.n1p, il.n1w, il.n1wp, m, k);
       } else {
         const ulonglong2 w = tw[(node << v) + g];
 #pragma unroll
         for (int j = 0; j < half; ++j)
-          inv_butterfly<A>(x[g * 2 * half + j], x[g * 2 * half + j + half], w.x, w.y, q,
-                           two_q);
+          inv_butterfly<A>(x[g * 2 * half + j], x[g * 2 * half + j + half], w.x, w.y, m, k);
       }
     }
   }
+  if (A::kLazy && !LAST) InvLadder<R, 0, A>::run(x, m);
 }
 
 // ---------------------------------------------------------------------------
@@ -100,7 +119,7 @@ __device__ __forceinline__ void inv_subtree(u64* x, const ulonglong2* __restrict
 template <bool FWD, int R, class A>
 __global__ void __launch_bounds__(256)
 strided_pass(u64* __restrict__ out, const u64* __restrict__ in,
-             const ulonglong2* __restrict__ tw, u64 q, u32 log_n, u32 a0, u32 reduce_out,
+             const ulonglong2* __restrict__ tw, ModConst m, u32 log_n, u32 a0, u32 finish,
              u64 items, InvLast il) {
   constexpr int E = 1 << R;
   const u64 wi = (u64)blockIdx.x * 256 + threadIdx.x;
@@ -114,27 +133,28 @@ strided_pass(u64* __restrict__ out, const u64* __restrict__ in,
   u32 node = (1u << a0) + h;
   // all lanes of a wave share h when a wave spans <= S columns
   if (log_s >= 6) node = __builtin_amdgcn_readfirstlane(node);
-  const u64 two_q = q << 1;
 
   u64 x[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) x[e] = in[base + ((u64)e << log_s)];
 
+  // finish: 0 = more passes follow, 1 = end of the network (lazy output range),
+  // 2 = end of the network, canonical output in [0,q)
   if (FWD) {
-    fwd_subtree<R, A>(x, tw, node, q, two_q);
-    if (reduce_out) {
+    fwd_subtree<R, A>(x, tw, node, m);
+    if (finish) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) x[e] = reduce_4q_to_q(x[e], q, two_q);
+      for (int e = 0; e < E; ++e) x[e] = fwd_finish<A>(x[e], m, finish == 2);
     }
   } else {
     if (a0 == 0) {
-      inv_subtree<R, A, true>(x, tw, node, q, two_q, il);
+      inv_subtree<R, A, true>(x, tw, node, m, il);
     } else {
-      inv_subtree<R, A, false>(x, tw, node, q, two_q, il);
+      inv_subtree<R, A, false>(x, tw, node, m, il);
     }
-    if (reduce_out) {
+    if (finish == 2) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) x[e] = csub(x[e], q);
+      for (int e = 0; e < E; ++e) x[e] = csub(x[e], m.q);
     }
   }
 #pragma unroll
@@ -144,23 +164,27 @@ strided_pass(u64* __restrict__ out, const u64* __restrict__ in,
 // ---------------------------------------------------------------------------
 // block_pass: the bottom TB stages on contiguous 2^TB-element blocks
 // ---------------------------------------------------------------------------
-constexpr int kTileLog = 12;               // 4096 elements = 32 KiB per workgroup
-constexpr int kRE = 4;                     // 16 elements per thread
-constexpr int kThreadsLog = kTileLog - kRE;  // 256 threads
-constexpr int kThreads = 1 << kThreadsLog;
-constexpr int kE = 1 << kRE;
+// A workgroup owns a 4096-element (32 KiB) tile = 4096 >> TB blocks.  RE = log2
+// of the elements a thread holds: RE = 4 -> 256 threads, rounds of 4 stages;
+// RE = 3 -> 512 threads, rounds of 3 stages, <= 64 VGPRs so that 4 workgroups
+// = 32 waves fit a CU (the integer pipes of gfx950 need ~8 waves per SIMD to
+// reach their issue rate -- tools/ubench2.hip).
+constexpr int kTileLog = 12;
 constexpr int kLdsWords = (1 << kTileLog) + (1 << (kTileLog - 4));
 
 // one 8-byte pad slot per 16 elements
 __device__ __forceinline__ u32 lds_slot(u32 p) { return p + (p >> 4); }
 
-template <int TB>
+template <int TB, int RE>
 struct Rounds {
-  static constexpr int NR = (TB + kRE - 1) / kRE;
-  static constexpr int R0 = TB - (NR - 1) * kRE;  // stages of round 0 (1..kRE)
-  static constexpr int r(int j) { return j == 0 ? R0 : kRE; }
-  static constexpr int u(int j) { return j == 0 ? 0 : R0 + (j - 1) * kRE; }
+  static constexpr int NR = (TB + RE - 1) / RE;
+  static constexpr int R0 = TB - (NR - 1) * RE;  // stages of round 0 (1..RE)
+  static constexpr int r(int j) { return j == 0 ? R0 : RE; }
+  static constexpr int u(int j) { return j == 0 ? 0 : R0 + (j - 1) * RE; }
   static constexpr int w(int j) { return TB - u(j) - r(j); }
+  static constexpr int kThreadsLog = kTileLog - RE;
+  static constexpr int kThreads = 1 << kThreadsLog;
+  static constexpr int kE = 1 << RE;
 };
 
 // Tile-local index of element e of virtual thread vt in a round with r stages
@@ -170,74 +194,108 @@ __device__ __forceinline__ u32 tile_index(u32 vt, int e) {
   return ((vt >> w) << (w + r)) + ((u32)e << w) + (vt & ((1u << w) - 1));
 }
 
-// vt >> w for vt = s*kThreads + tid, written so that it is visibly uniform
-// when 2^w >= kThreads.
-template <int w>
+// vt >> w for vt = s*threads + tid, written so that it is visibly uniform
+// when 2^w >= threads.
+template <int w, int TL>
 __device__ __forceinline__ u32 vt_high(int s, u32 tid) {
-  if (w >= kThreadsLog) return (u32)s >> (w - kThreadsLog);
-  return ((u32)s * kThreads + tid) >> w;
+  if (w >= TL) return (u32)s >> (w - TL);
+  return (((u32)s << TL) + tid) >> w;
 }
 
-template <int TB, int j, class A, bool FWD, bool LAST>
+template <int TB, int RE, int j, class A, bool FWD, bool LAST>
 __device__ __forceinline__ void run_round(u64* x, const ulonglong2* __restrict__ tw,
-                                          u32 tid, u32 a0, u32 tile_blk0, u64 q,
-                                          u64 two_q, const InvLast& il) {
-  constexpr int r = Rounds<TB>::r(j);
-  constexpr int w = Rounds<TB>::w(j);
-  constexpr int u = Rounds<TB>::u(j);
-  constexpr int SS = kE >> r;
+                                          u32 tid, u32 a0, u32 tile_blk0,
+                                          const ModConst& m, const InvLast& il) {
+  using RD = Rounds<TB, RE>;
+  constexpr int r = RD::r(j);
+  constexpr int w = RD::w(j);
+  constexpr int u = RD::u(j);
+  constexpr int SS = RD::kE >> r;
   const u32 level = 1u << (a0 + u);
 #pragma unroll
   for (int s = 0; s < SS; ++s) {
-    u32 node = level + (((tile_blk0 << u) + vt_high<w>(s, tid)) & (level - 1));
+    u32 node = level + (((tile_blk0 << u) + vt_high<w, RD::kThreadsLog>(s, tid)) & (level - 1));
     if (w >= 6) node = __builtin_amdgcn_readfirstlane(node);
     if (FWD)
-      fwd_subtree<r, A>(x + (s << r), tw, node, q, two_q);
+      fwd_subtree<r, A>(x + (s << r), tw, node, m);
     else
-      inv_subtree<r, A, LAST>(x + (s << r), tw, node, q, two_q, il);
+      inv_subtree<r, A, LAST>(x + (s << r), tw, node, m, il);
   }
 }
 
-template <int TB, int j>
+template <int TB, int RE, int j>
 __device__ __forceinline__ void lds_load_round(u64* x, const u64* lds, u32 tid) {
-  constexpr int r = Rounds<TB>::r(j);
-  constexpr int w = Rounds<TB>::w(j);
-  constexpr int SS = kE >> r;
+  using RD = Rounds<TB, RE>;
+  constexpr int r = RD::r(j);
+  constexpr int w = RD::w(j);
+  constexpr int SS = RD::kE >> r;
 #pragma unroll
   for (int s = 0; s < SS; ++s)
 #pragma unroll
     for (int e = 0; e < (1 << r); ++e)
-      x[(s << r) + e] = lds[lds_slot(tile_index<r, w>(s * kThreads + tid, e))];
+      x[(s << r) + e] = lds[lds_slot(tile_index<r, w>(s * RD::kThreads + tid, e))];
 }
 
-template <int TB, int j>
+template <int TB, int RE, int j>
 __device__ __forceinline__ void lds_store_round(const u64* x, u64* lds, u32 tid) {
-  constexpr int r = Rounds<TB>::r(j);
-  constexpr int w = Rounds<TB>::w(j);
-  constexpr int SS = kE >> r;
+  using RD = Rounds<TB, RE>;
+  constexpr int r = RD::r(j);
+  constexpr int w = RD::w(j);
+  constexpr int SS = RD::kE >> r;
 #pragma unroll
   for (int s = 0; s < SS; ++s)
 #pragma unroll
     for (int e = 0; e < (1 << r); ++e)
-      lds[lds_slot(tile_index<r, w>(s * kThreads + tid, e))] = x[(s << r) + e];
+      lds[lds_slot(tile_index<r, w>(s * RD::kThreads + tid, e))] = x[(s << r) + e];
+}
+
+// forward rounds J .. NR-1: LDS -> registers -> subtree -> LDS
+template <int TB, int RE, int J, class A>
+__device__ __forceinline__ void fwd_mid_rounds(u64* x, u64* lds, const ulonglong2* tw, u32 tid,
+                                               u32 a0, u32 tile_blk0, const ModConst& m,
+                                               const InvLast& il) {
+  if constexpr (J < Rounds<TB, RE>::NR) {
+    lds_load_round<TB, RE, J>(x, lds, tid);
+    run_round<TB, RE, J, A, true, false>(x, tw, tid, a0, tile_blk0, m, il);
+    __syncthreads();
+    lds_store_round<TB, RE, J>(x, lds, tid);
+    __syncthreads();
+    fwd_mid_rounds<TB, RE, J + 1, A>(x, lds, tw, tid, a0, tile_blk0, m, il);
+  }
+}
+
+// inverse rounds J .. 1 (deepest first)
+template <int TB, int RE, int J, class A>
+__device__ __forceinline__ void inv_mid_rounds(u64* x, u64* lds, const ulonglong2* tw, u32 tid,
+                                               u32 a0, u32 tile_blk0, const ModConst& m,
+                                               const InvLast& il) {
+  if constexpr (J >= 1) {
+    lds_load_round<TB, RE, J>(x, lds, tid);
+    run_round<TB, RE, J, A, false, false>(x, tw, tid, a0, tile_blk0, m, il);
+    __syncthreads();
+    lds_store_round<TB, RE, J>(x, lds, tid);
+    __syncthreads();
+    inv_mid_rounds<TB, RE, J - 1, A>(x, lds, tw, tid, a0, tile_blk0, m, il);
+  }
 }
 
 // FWD:  global --(round 0)--> LDS --(rounds 1..)--> LDS --> coalesced store
 // INV:  coalesced load --> LDS --(rounds NR-1..1)--> LDS --(round 0)--> global
-template <bool FWD, int TB, class A>
-__global__ void __launch_bounds__(kThreads)
+template <bool FWD, int TB, int RE, class A>
+__global__ void __launch_bounds__(1 << (kTileLog - RE), (RE == 3 ? 8 : 4))
 block_pass(u64* __restrict__ out, const u64* __restrict__ in,
-           const ulonglong2* __restrict__ tw, u64 q, u32 log_n, u32 reduce_out, u64 total,
+           const ulonglong2* __restrict__ tw, ModConst m, u32 log_n, u32 finish, u64 total,
            u32 vec16, InvLast il) {
-  using RD = Rounds<TB>;
+  using RD = Rounds<TB, RE>;
   constexpr int NR = RD::NR;
+  constexpr int kThreads = RD::kThreads;
+  constexpr int kE = RD::kE;
   __shared__ u64 lds[kLdsWords];
   const u32 tid = threadIdx.x;
   const u64 tile_base = (u64)blockIdx.x << kTileLog;
   const u32 a0 = log_n - TB;  // heap level of the block roots
   // index (within its polynomial) of the first 2^TB-block of this tile
   const u32 tile_blk0 = (u32)((tile_base & ((1ull << log_n) - 1)) >> TB);
-  const u64 two_q = q << 1;
   u64 x[kE];
 
   if (FWD) {
@@ -250,35 +308,20 @@ block_pass(u64* __restrict__ out, const u64* __restrict__ in,
           const u64 k = tile_base + tile_index<r, w>(s * kThreads + tid, e);
           x[(s << r) + e] = (k < total) ? in[k] : 0;
         }
-      run_round<TB, 0, A, true, false>(x, tw, tid, a0, tile_blk0, q, two_q, il);
-      lds_store_round<TB, 0>(x, lds, tid);
+      run_round<TB, RE, 0, A, true, false>(x, tw, tid, a0, tile_blk0, m, il);
+      lds_store_round<TB, RE, 0>(x, lds, tid);
       __syncthreads();
     }
-    if (NR > 1) {
-      lds_load_round<TB, (NR > 1 ? 1 : 0)>(x, lds, tid);
-      run_round<TB, (NR > 1 ? 1 : 0), A, true, false>(x, tw, tid, a0, tile_blk0, q, two_q,
-                                                      il);
-      __syncthreads();
-      lds_store_round<TB, (NR > 1 ? 1 : 0)>(x, lds, tid);
-      __syncthreads();
-    }
-    if (NR > 2) {
-      lds_load_round<TB, (NR > 2 ? 2 : 0)>(x, lds, tid);
-      run_round<TB, (NR > 2 ? 2 : 0), A, true, false>(x, tw, tid, a0, tile_blk0, q, two_q,
-                                                      il);
-      __syncthreads();
-      lds_store_round<TB, (NR > 2 ? 2 : 0)>(x, lds, tid);
-      __syncthreads();
-    }
+    fwd_mid_rounds<TB, RE, 1, A>(x, lds, tw, tid, a0, tile_blk0, m, il);
     // coalesced copy-out, 16 bytes per lane, final reduction fused
 #pragma unroll
     for (int i = 0; i < kE / 2; ++i) {
       const u32 p = 2 * (i * kThreads + tid);
       u64 v0 = lds[lds_slot(p)];
       u64 v1 = lds[lds_slot(p + 1)];
-      if (reduce_out) {
-        v0 = reduce_4q_to_q(v0, q, two_q);
-        v1 = reduce_4q_to_q(v1, q, two_q);
+      if (finish) {
+        v0 = fwd_finish<A>(v0, m, finish == 2);
+        v1 = fwd_finish<A>(v1, m, finish == 2);
       }
       if (tile_base + p < total) {
         if (vec16) {
@@ -307,27 +350,12 @@ block_pass(u64* __restrict__ out, const u64* __restrict__ in,
       lds[lds_slot(p + 1)] = v.y;
     }
     __syncthreads();
-    if (NR > 2) {
-      lds_load_round<TB, (NR > 2 ? 2 : 0)>(x, lds, tid);
-      run_round<TB, (NR > 2 ? 2 : 0), A, false, false>(x, tw, tid, a0, tile_blk0, q, two_q,
-                                                       il);
-      __syncthreads();
-      lds_store_round<TB, (NR > 2 ? 2 : 0)>(x, lds, tid);
-      __syncthreads();
-    }
-    if (NR > 1) {
-      lds_load_round<TB, (NR > 1 ? 1 : 0)>(x, lds, tid);
-      run_round<TB, (NR > 1 ? 1 : 0), A, false, false>(x, tw, tid, a0, tile_blk0, q, two_q,
-                                                       il);
-      __syncthreads();
-      lds_store_round<TB, (NR > 1 ? 1 : 0)>(x, lds, tid);
-      __syncthreads();
-    }
-    lds_load_round<TB, 0>(x, lds, tid);
+    inv_mid_rounds<TB, RE, NR - 1, A>(x, lds, tw, tid, a0, tile_blk0, m, il);
+    lds_load_round<TB, RE, 0>(x, lds, tid);
     if (a0 == 0)
-      run_round<TB, 0, A, false, true>(x, tw, tid, a0, tile_blk0, q, two_q, il);
+      run_round<TB, RE, 0, A, false, true>(x, tw, tid, a0, tile_blk0, m, il);
     else
-      run_round<TB, 0, A, false, false>(x, tw, tid, a0, tile_blk0, q, two_q, il);
+      run_round<TB, RE, 0, A, false, false>(x, tw, tid, a0, tile_blk0, m, il);
     {
       constexpr int r = RD::r(0), w = RD::w(0), SS = kE >> r;
 #pragma unroll
@@ -336,7 +364,7 @@ block_pass(u64* __restrict__ out, const u64* __restrict__ in,
         for (int e = 0; e < (1 << r); ++e) {
           const u64 k = tile_base + tile_index<r, w>(s * kThreads + tid, e);
           u64 v = x[(s << r) + e];
-          if (reduce_out) v = csub(v, q);
+          if (finish == 2) v = csub(v, m.q);
           if (k < total) out[k] = v;
         }
     }
@@ -348,8 +376,8 @@ block_pass(u64* __restrict__ out, const u64* __restrict__ in,
 // ---------------------------------------------------------------------------
 
 template <bool FWD, class A>
-static hipError_t launch_strided(int R, u64* out, const u64* in, const ulonglong2* tw, u64 q,
-                                 u32 log_n, u32 a0, u32 reduce_out, u64 batch,
+static hipError_t launch_strided(int R, u64* out, const u64* in, const ulonglong2* tw,
+                                 const ModConst& m, u32 log_n, u32 a0, u32 finish, u64 batch,
                                  const InvLast& il, hipStream_t st) {
   const u64 items = batch << (log_n - R);
   const unsigned grid = (unsigned)((items + 255) / 256);
@@ -357,7 +385,7 @@ static hipError_t launch_strided(int R, u64* out, const u64* in, const ulonglong
 #define HX_LAUNCH_S(RR)                                                                  \
   case RR:                                                                               \
     hipLaunchKernelGGL((strided_pass<FWD, RR, A>), dim3(grid), dim3(256), 0, st, out, in, \
-                       tw, q, log_n, a0, reduce_out, items, il);                         \
+                       tw, m, log_n, a0, finish, items, il);                             \
     break;
   switch (R) {
     HX_LAUNCH_S(1)
@@ -372,38 +400,56 @@ static hipError_t launch_strided(int R, u64* out, const u64* in, const ulonglong
   return hipGetLastError();
 }
 
+// Experiment knob: HEXL_AMD_BLOCK_RE=3|4 picks the block_pass geometry for
+// 12-stage tiles (default 3: 512 threads x 8 elements).
+static int block_re() {
+  static const int v = [] {
+    const char* e = getenv("HEXL_AMD_BLOCK_RE");
+    return (e && e[0] == '4') ? 4 : 3;
+  }();
+  return v;
+}
+
 template <bool FWD, class A>
-static hipError_t launch_block(int TB, u64* out, const u64* in, const ulonglong2* tw, u64 q,
-                               u32 log_n, u32 reduce_out, u64 batch, const InvLast& il,
-                               hipStream_t st) {
+static hipError_t launch_block(int TB, u64* out, const u64* in, const ulonglong2* tw,
+                               const ModConst& m, u32 log_n, u32 finish, u64 batch,
+                               const InvLast& il, hipStream_t st) {
   const u64 total = batch << log_n;
   const unsigned grid = (unsigned)((total + (1u << kTileLog) - 1) >> kTileLog);
   const u32 vec16 = (((uintptr_t)out | (uintptr_t)in) & 15) == 0 ? 1u : 0u;
   ScopedKernelTimer timer(FWD ? "ntt_fwd_block_pass" : "ntt_inv_block_pass", st);
-#define HX_LAUNCH_B(T)                                                                     \
-  case T:                                                                                  \
-    hipLaunchKernelGGL((block_pass<FWD, T, A>), dim3(grid), dim3(kThreads), 0, st, out, in, \
-                       tw, q, log_n, reduce_out, total, vec16, il);                        \
-    break;
+#define HX_LAUNCH_B(T, RE)                                                              \
+  hipLaunchKernelGGL((block_pass<FWD, T, RE, A>), dim3(grid), dim3(1 << (kTileLog - RE)), 0, \
+                     st, out, in, tw, m, log_n, finish, total, vec16, il)
   switch (TB) {
-    HX_LAUNCH_B(1)
-    HX_LAUNCH_B(2)
-    HX_LAUNCH_B(3)
-    HX_LAUNCH_B(4)
-    HX_LAUNCH_B(5)
-    HX_LAUNCH_B(6)
-    HX_LAUNCH_B(7)
-    HX_LAUNCH_B(8)
-    HX_LAUNCH_B(9)
-    HX_LAUNCH_B(10)
-    HX_LAUNCH_B(11)
-    HX_LAUNCH_B(12)
+    case 1: HX_LAUNCH_B(1, 4); break;
+    case 2: HX_LAUNCH_B(2, 4); break;
+    case 3: HX_LAUNCH_B(3, 4); break;
+    case 4: HX_LAUNCH_B(4, 4); break;
+    case 5: HX_LAUNCH_B(5, 4); break;
+    case 6: HX_LAUNCH_B(6, 4); break;
+    case 7: HX_LAUNCH_B(7, 4); break;
+    case 8: HX_LAUNCH_B(8, 4); break;
+    case 9: HX_LAUNCH_B(9, 4); break;
+    case 10: HX_LAUNCH_B(10, 4); break;
+    case 11: HX_LAUNCH_B(11, 4); break;
+    case 12:
+      if (block_re() == 3) {
+        HX_LAUNCH_B(12, 3);
+      } else {
+        HX_LAUNCH_B(12, 4);
+      }
+      break;
     default:
       return hipErrorInvalidValue;
   }
 #undef HX_LAUNCH_B
   return hipGetLastError();
 }
+
+// Lazy range policy: every multiplicand must stay below 2^62, i.e.
+// (4 + 2*20) q (forward) and 64 q (inverse subtrees of up to 5 stages) < 2^62.
+
 
 // Split the `top` leading stages into strided passes of at most 5 stages.
 static int split_top(int top, int* sizes) {
@@ -430,13 +476,13 @@ static hipError_t forward_impl(const NttTables& t, u64* result, const u64* opera
   u32 a0 = 0;
   InvLast il{};
   for (int i = 0; i < np; ++i) {
-    hipError_t e = launch_strided<true, A>(sizes[i], result, src, t.fwd, t.q, t.log_n, a0, 0,
+    hipError_t e = launch_strided<true, A>(sizes[i], result, src, t.fwd, t.mod, t.log_n, a0, 0,
                                            batch, il, st);
     if (e != hipSuccess) return e;
     a0 += sizes[i];
     src = result;
   }
-  return launch_block<true, A>(TB, result, src, t.fwd, t.q, t.log_n, out_mf == 1 ? 1 : 0,
+  return launch_block<true, A>(TB, result, src, t.fwd, t.mod, t.log_n, out_mf == 1 ? 2 : 1,
                                batch, il, st);
 }
 
@@ -447,15 +493,15 @@ static hipError_t inverse_impl(const NttTables& t, u64* result, const u64* opera
   const int TB = L < kTileLog ? L : kTileLog;
   int sizes[8];
   const int np = split_top(L - TB, sizes);
-  const u32 reduce = out_mf == 1 ? 1 : 0;
-  hipError_t e = launch_block<false, A>(TB, result, operand, t.inv, t.q, t.log_n,
-                                        np == 0 ? reduce : 0, batch, t.inv_last, st);
+  const u32 fin = out_mf == 1 ? 2 : 1;
+  hipError_t e = launch_block<false, A>(TB, result, operand, t.inv, t.mod, t.log_n,
+                                        np == 0 ? fin : 0, batch, t.inv_last, st);
   if (e != hipSuccess) return e;
   u32 a0 = (u32)(L - TB);
   for (int i = np - 1; i >= 0; --i) {
     a0 -= sizes[i];
-    e = launch_strided<false, A>(sizes[i], result, result, t.inv, t.q, t.log_n, a0,
-                                 i == 0 ? reduce : 0, batch, t.inv_last, st);
+    e = launch_strided<false, A>(sizes[i], result, result, t.inv, t.mod, t.log_n, a0,
+                                 i == 0 ? fin : 0, batch, t.inv_last, st);
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
@@ -464,15 +510,15 @@ static hipError_t inverse_impl(const NttTables& t, u64* result, const u64* opera
 hipError_t ntt_forward_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
                               u64 out_mf, hipStream_t st) {
   if (batch == 0) return hipSuccess;
-  if (t.q < (1ull << 55)) return forward_impl<Q55>(t, result, operand, batch, out_mf, st);
-  return forward_impl<Q64>(t, result, operand, batch, out_mf, st);
+  if (t.mod.q < kLazyModulusBound) return forward_impl<Lazy>(t, result, operand, batch, out_mf, st);
+  return forward_impl<Strict>(t, result, operand, batch, out_mf, st);
 }
 
 hipError_t ntt_inverse_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
                               u64 out_mf, hipStream_t st) {
   if (batch == 0) return hipSuccess;
-  if (t.q < (1ull << 55)) return inverse_impl<Q55>(t, result, operand, batch, out_mf, st);
-  return inverse_impl<Q64>(t, result, operand, batch, out_mf, st);
+  if (t.mod.q < kLazyModulusBound) return inverse_impl<Lazy>(t, result, operand, batch, out_mf, st);
+  return inverse_impl<Strict>(t, result, operand, batch, out_mf, st);
 }
 
 }  // namespace hexl_amd

@@ -13,7 +13,8 @@ typedef unsigned __int128 u128;
 
 u64 multiply_factor(u64 operand, u64 bit_shift, u64 modulus) {
   // floor(operand * 2^bit_shift / modulus), low 64 bits
-  // (number-theory.hpp:29-40; bit_shift in {32, 52, 64})
+  // (number-theory.hpp:29-40; bit_shift in {32, 52, 64}; 63 is used for the
+  // device tables of the Lazy arithmetic policy)
   u128 num = (u128)operand << bit_shift;
   return (u64)(num / modulus);
 }

@@ -13,27 +13,37 @@
 // index (the reference's stage-ordered inverse layout, ntt-internal.cpp:143-154,
 // is kept on the host for the getters only).
 //
-// Two kernels, both built from a register-resident "subtree": a thread owns
-// E = 2^r elements and runs r stages on them with no communication.
-//   * strided_pass  -- the top stages of a large transform (butterfly gap
-//     >= 4096): each thread owns one column, elements N/2^(a0+r) apart; lanes
-//     map to consecutive columns, so every load/store is a fully coalesced
-//     512-byte wave access and all twiddles are wave-uniform (scalar loads).
-//   * block_pass    -- the bottom <= 12 stages on a contiguous 4096-element
-//     (32 KiB) tile staged through LDS: 2-3 subtree rounds separated by LDS
-//     transposes, padded (one 8-byte slot per 16) so that every ds_read_b64 /
-//     ds_write_b64 pattern used is bank-conflict free or at worst 2-way on one
-//     slot; the final [0,4q)->[0,q) reduction (or N^-1 scaling for the
-//     inverse) is fused into the last store.
-// N <= 4096 is a single block_pass launch; N = 2^16 is strided_pass(4 stages)
-// + block_pass(12 stages), i.e. two HBM round trips per transform.
+// Everything is built from a register-resident "subtree": a thread owns 2^r
+// elements and runs r stages on them with no communication.
 //
-// Values stay lazy: [0,4q) forward, [0,2q) inverse, as in the reference's
-// Harvey butterflies (hexl/ntt/ntt-default.hpp:28-42, :112-125).  Canonical
-// outputs (output_mod_factor == 1) are therefore bit-identical to the
-// reference; lazy outputs are congruent and in range.
+//   tile_pass<S, CB>  One workgroup (512 threads x 8 elements) owns a tile of
+//     4096 elements = 32 KiB of LDS and runs S stages on it as ceil(S/3)
+//     subtree rounds separated by LDS transposes.  The 12 tile-index bits are
+//     [ sub-block | S transformed bits | CB column bits ]:
+//       CB = 0      the tile is 4096 contiguous coefficients = 4096 >> S whole
+//                   sub-blocks of the heap level a0 = log2(N) - S ("bottom"
+//                   stages; N <= 4096 is this kernel alone);
+//       CB = 12 - S the tile is all 2^S rows x 2^CB adjacent columns of one
+//                   polynomial, rows N >> S apart ("top" stages, a0 = 0); a
+//                   row segment is 2^CB * 8 >= 128 contiguous bytes.
+//     N = 2^16 is top(S=8, CB=4) + bottom(S=8): two HBM round trips, both
+//     kernels with the same 8 stages of arithmetic per byte moved.
+//     LDS slots are XOR-swizzled so that every ds_read_b64 / ds_write_b64
+//     pattern of every round is bank-conflict free; rounds whose gap is <= 64
+//     elements exchange data inside one wave and need no workgroup barrier.
+//     The output reduction (forward) / N^-1 scaling (inverse) is fused into the
+//     last store.
+//   strided_pass<R>   register-only pass (no LDS): each thread owns one column,
+//     elements N >> (a0 + R) apart.  Kept as the alternative top pass
+//     (HEXL_AMD_PLAN=strided: 4 + 12 stages for N = 2^16).
+//
+// Values stay lazy as in the reference's Harvey butterflies
+// (hexl/ntt/ntt-default.hpp:28-42, :112-125); see modarith.h for the two range
+// policies.  Canonical outputs (output_mod_factor == 1) are bit-identical to the
+// reference; lazy outputs are congruent and inside the reference's ranges.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "internal.h"
 #include "modarith.h"
@@ -42,21 +52,51 @@ namespace hexl_amd {
 
 thread_local ProfileSink* g_profile = nullptr;
 
+// Developer diagnostic (tools/phase_profile.py): per-wave s_memtime stamps at the
+// phase boundaries of tile_pass.  Compiled out of the product build.
+#ifdef HEXL_AMD_PHASE_PROFILE
+__device__ unsigned long long* g_phase_buf = nullptr;  // [block][wave][16]
+#define HX_STAMP(i)                                                                      \
+  do {                                                                                   \
+    if ((threadIdx.x & 63) == 0 && g_phase_buf)                                          \
+      g_phase_buf[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] =            \
+          __builtin_readcyclecounter();                                                  \
+  } while (0)
+#define HX_PROFILE_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+extern "C" int hexl_amd_debug_set_phase_buf(void* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_buf), &buf, sizeof(buf));
+}
+#else
+#define HX_STAMP(i)
+#define HX_PROFILE_WAIT_VMEM()
+#endif
+
 // ---------------------------------------------------------------------------
 // Register subtrees
 // ---------------------------------------------------------------------------
 
-// r forward stages on x[0 .. 2^r): stage v pairs elements 2^(r-1-v) apart and
-// uses heap nodes (node << v) + g, g = 0 .. 2^v - 1.
+// The 2^R - 1 twiddles of the subtree rooted at heap node `node`, fetched
+// before the first butterfly so that their latencies overlap (left to itself
+// the compiler issues one load + one full wait per stage).  wv[2^v + g] is the
+// twiddle of group g at depth v.
+template <int R>
+__device__ __forceinline__ void load_twiddles(ulonglong2* wv, const ulonglong2* __restrict__ tw,
+                                              u32 node) {
+#pragma unroll
+  for (int v = 0; v < R; ++v)
+#pragma unroll
+    for (int g = 0; g < (1 << v); ++g) wv[(1 << v) + g] = tw[(node << v) + g];
+}
+
+// R forward stages on x[0 .. 2^R): stage v pairs elements 2^(R-1-v) apart.
 template <int R, class A>
-__device__ __forceinline__ void fwd_subtree(u64* x, const ulonglong2* __restrict__ tw,
-                                            u32 node, const ModConst& m) {
+__device__ __forceinline__ void fwd_subtree(u64* x, const ulonglong2* wv, const ModConst& m) {
 #pragma unroll
   for (int v = 0; v < R; ++v) {
     const int half = 1 << (R - 1 - v);
 #pragma unroll
     for (int g = 0; g < (1 << v); ++g) {
-      const ulonglong2 w = tw[(node << v) + g];
+      const ulonglong2 w = wv[(1 << v) + g];
 #pragma unroll
       for (int j = 0; j < half; ++j)
         fwd_butterfly<A>(x[g * 2 * half + j], x[g * 2 * half + j + half], w.x, w.y, m);
@@ -83,13 +123,13 @@ struct InvLadder<R, (1 << R), A> {
   static __device__ __forceinline__ void run(u64*, const ModConst&) {}
 };
 
-// r inverse stages (deepest level first).  With LAST the v == 0 stage is the
+// R inverse stages (deepest level first).  With LAST the v == 0 stage is the
 // root of the whole transform and folds N^-1 in (ntt-radix-2.cpp:490-509).
 // Lazy policy: no conditional subtraction inside the subtree, [0,2q) restored
 // at exit (not needed after LAST, whose outputs are both lazy products).
 template <int R, class A, bool LAST>
-__device__ __forceinline__ void inv_subtree(u64* x, const ulonglong2* __restrict__ tw,
-                                            u32 node, const ModConst& m, const InvLast& il) {
+__device__ __forceinline__ void inv_subtree(u64* x, const ulonglong2* wv, const ModConst& m,
+                                            const InvLast& il) {
 #pragma unroll
   for (int v = R - 1; v >= 0; --v) {
     const int half = 1 << (R - 1 - v);
@@ -101,7 +141,7 @@ __device__ __forceinline__ void inv_subtree(u64* x, const ulonglong2* __restrict
         for (int j = 0; j < half; ++j)
           inv_butterfly_last<A>(x[j], x[j + half], il.n1, il.n1p, il.n1w, il.n1wp, m, k);
       } else {
-        const ulonglong2 w = tw[(node << v) + g];
+        const ulonglong2 w = wv[(1 << v) + g];
 #pragma unroll
         for (int j = 0; j < half; ++j)
           inv_butterfly<A>(x[g * 2 * half + j], x[g * 2 * half + j + half], w.x, w.y, m, k);
@@ -112,10 +152,12 @@ __device__ __forceinline__ void inv_subtree(u64* x, const ulonglong2* __restrict
 }
 
 // ---------------------------------------------------------------------------
-// strided_pass: R stages whose subtree roots sit at heap level a0
+// strided_pass: R stages whose subtree roots sit at heap level a0 (registers only)
 // ---------------------------------------------------------------------------
 // Work item -> (poly b, subtree h in [0, 2^a0), column c in [0, S)),
 // S = N >> (a0 + R); element e of the item is at b*N + (h*2^R + e)*S + c.
+// Lanes map to consecutive columns: every access is a coalesced 512-byte wave
+// access and the twiddles are wave-uniform (scalar loads).
 template <bool FWD, int R, class A>
 __global__ void __launch_bounds__(256)
 strided_pass(u64* __restrict__ out, const u64* __restrict__ in,
@@ -133,6 +175,8 @@ strided_pass(u64* __restrict__ out, const u64* __restrict__ in,
   u32 node = (1u << a0) + h;
   // all lanes of a wave share h when a wave spans <= S columns
   if (log_s >= 6) node = __builtin_amdgcn_readfirstlane(node);
+  ulonglong2 wv[E];
+  load_twiddles<R>(wv, tw, node);
 
   u64 x[E];
 #pragma unroll
@@ -141,16 +185,16 @@ strided_pass(u64* __restrict__ out, const u64* __restrict__ in,
   // finish: 0 = more passes follow, 1 = end of the network (lazy output range),
   // 2 = end of the network, canonical output in [0,q)
   if (FWD) {
-    fwd_subtree<R, A>(x, tw, node, m);
+    fwd_subtree<R, A>(x, wv, m);
     if (finish) {
 #pragma unroll
       for (int e = 0; e < E; ++e) x[e] = fwd_finish<A>(x[e], m, finish == 2);
     }
   } else {
     if (a0 == 0) {
-      inv_subtree<R, A, true>(x, tw, node, m, il);
+      inv_subtree<R, A, true>(x, wv, m, il);
     } else {
-      inv_subtree<R, A, false>(x, tw, node, m, il);
+      inv_subtree<R, A, false>(x, wv, m, il);
     }
     if (finish == 2) {
 #pragma unroll
@@ -162,210 +206,269 @@ strided_pass(u64* __restrict__ out, const u64* __restrict__ in,
 }
 
 // ---------------------------------------------------------------------------
-// block_pass: the bottom TB stages on contiguous 2^TB-element blocks
+// tile_pass: S stages on a 4096-element tile staged through LDS
 // ---------------------------------------------------------------------------
-// A workgroup owns a 4096-element (32 KiB) tile = 4096 >> TB blocks.  RE = log2
-// of the elements a thread holds: RE = 4 -> 256 threads, rounds of 4 stages;
-// RE = 3 -> 512 threads, rounds of 3 stages, <= 64 VGPRs so that 4 workgroups
-// = 32 waves fit a CU (the integer pipes of gfx950 need ~8 waves per SIMD to
-// reach their issue rate -- tools/ubench2.hip).
-constexpr int kTileLog = 12;
-constexpr int kLdsWords = (1 << kTileLog) + (1 << (kTileLog - 4));
+// Tile size is a template parameter TL (log2 elements): 10 -> 1024 elements
+// (8 KiB of LDS, 128 threads = 2 waves, 16 workgroups per CU) for N <= 2^16, 12 ->
+// 4096 elements (32 KiB, 512 threads, 4 workgroups per CU) for larger N.  Either
+// way a thread holds 8 elements, a round is 3 stages, and 32 waves fit a CU.
+constexpr int kRE = 3;  // 8 elements per thread
+constexpr int kE = 1 << kRE;
+constexpr int kMaxTileLog = 12;
 
-// one 8-byte pad slot per 16 elements
-__device__ __forceinline__ u32 lds_slot(u32 p) { return p + (p >> 4); }
+// XOR swizzle of the 8-byte slot index: every ds_read_b64 (32-lane groups, 64
+// banks) and ds_write_b64 (16-lane groups, 32 banks) access pattern of every
+// round of every (S, CB) geometry is bank-conflict free (simulated for all
+// patterns; SQ_LDS_BANK_CONFLICT confirms).  No padding: the tile is exactly
+// 32 KiB, four workgroups = 32 waves per CU.
+__device__ __forceinline__ u32 lds_slot(u32 p) {
+  return p ^ ((p >> 3) & 7) ^ (((p >> 6) & 7) << 3);
+}
 
-template <int TB, int RE>
+// Round structure of S stages: round 0 takes the remainder S - 3*(NR-1) stages
+// (1..3), the others 3.  w(j) is log2 of the finest butterfly gap of round j in
+// tile-index units (it includes the CB column bits).
+template <int S, int CB>
 struct Rounds {
-  static constexpr int NR = (TB + RE - 1) / RE;
-  static constexpr int R0 = TB - (NR - 1) * RE;  // stages of round 0 (1..RE)
-  static constexpr int r(int j) { return j == 0 ? R0 : RE; }
-  static constexpr int u(int j) { return j == 0 ? 0 : R0 + (j - 1) * RE; }
-  static constexpr int w(int j) { return TB - u(j) - r(j); }
-  static constexpr int kThreadsLog = kTileLog - RE;
-  static constexpr int kThreads = 1 << kThreadsLog;
-  static constexpr int kE = 1 << RE;
+  static constexpr int NR = (S + kRE - 1) / kRE;
+  static constexpr int R0 = S - (NR - 1) * kRE;
+  static constexpr int r(int j) { return j == 0 ? R0 : kRE; }
+  static constexpr int u(int j) { return j == 0 ? 0 : R0 + (j - 1) * kRE; }
+  static constexpr int w(int j) { return CB + S - u(j) - r(j); }
 };
 
-// Tile-local index of element e of virtual thread vt in a round with r stages
-// whose finest butterfly gap is 2^w.
+// Tile index of element e of virtual thread vt in a round with r stages whose
+// finest gap is 2^w.
 template <int r, int w>
 __device__ __forceinline__ u32 tile_index(u32 vt, int e) {
   return ((vt >> w) << (w + r)) + ((u32)e << w) + (vt & ((1u << w) - 1));
 }
 
-// vt >> w for vt = s*threads + tid, written so that it is visibly uniform
-// when 2^w >= threads.
+// vt >> w for vt = s*threads + tid, visibly uniform when 2^w >= threads.
 template <int w, int TL>
 __device__ __forceinline__ u32 vt_high(int s, u32 tid) {
-  if (w >= TL) return (u32)s >> (w - TL);
-  return (((u32)s << TL) + tid) >> w;
+  constexpr int kThreadsLog = TL - kRE;
+  if (w >= kThreadsLog) return (u32)s >> (w - kThreadsLog);
+  return (((u32)s << kThreadsLog) + tid) >> w;
 }
 
-template <int TB, int RE, int j, class A, bool FWD, bool LAST>
-__device__ __forceinline__ void run_round(u64* x, const ulonglong2* __restrict__ tw,
-                                          u32 tid, u32 a0, u32 tile_blk0,
-                                          const ModConst& m, const InvLast& il) {
-  using RD = Rounds<TB, RE>;
-  constexpr int r = RD::r(j);
-  constexpr int w = RD::w(j);
-  constexpr int u = RD::u(j);
-  constexpr int SS = RD::kE >> r;
-  const u32 level = 1u << (a0 + u);
+// Where the tile lives: element p is at base + (p >> CB << log_row) + (p & cols).
+struct TileGeom {
+  u64 base;
+  u32 log_row;    // 0 for CB == 0
+  u32 a0;         // heap level of the subtree roots of this pass
+  u32 tile_blk0;  // index within its polynomial of the tile's first sub-block
+};
+
+template <int CB>
+__device__ __forceinline__ u64 gaddr(const TileGeom& g, u32 p) {
+  if (CB == 0) return g.base + p;
+  return g.base + ((u64)(p >> CB) << g.log_row) + (p & ((1u << CB) - 1));
+}
+
+// Twiddles of round j for every sub-run this thread owns in that round.
+template <int S, int CB, int TL, int j>
+__device__ __forceinline__ void round_twiddles(ulonglong2* wv, const ulonglong2* __restrict__ tw,
+                                               u32 tid, const TileGeom& g) {
+  using RD = Rounds<S, CB>;
+  constexpr int r = RD::r(j), w = RD::w(j), u = RD::u(j);
+  constexpr int SS = kE >> r;
+  const u32 level = 1u << (g.a0 + u);
 #pragma unroll
   for (int s = 0; s < SS; ++s) {
-    u32 node = level + (((tile_blk0 << u) + vt_high<w, RD::kThreadsLog>(s, tid)) & (level - 1));
-    if (w >= 6) node = __builtin_amdgcn_readfirstlane(node);
-    if (FWD)
-      fwd_subtree<r, A>(x + (s << r), tw, node, m);
-    else
-      inv_subtree<r, A, LAST>(x + (s << r), tw, node, m, il);
+    // sub-block-and-group index of the run: the bits of vt above the gap, minus
+    // the column bits (which do not select a twiddle)
+    u32 node = level + (((g.tile_blk0 << u) + vt_high<w, TL>(s, tid)) & (level - 1));
+    if (w >= 6) node = __builtin_amdgcn_readfirstlane(node);  // uniform across the wave
+    load_twiddles<r>(wv + (s << r), tw, node);
   }
 }
 
-template <int TB, int RE, int j>
+template <int S, int CB, int j, class A, bool FWD, bool LAST>
+__device__ __forceinline__ void round_compute(u64* x, const ulonglong2* wv, const ModConst& m,
+                                              const InvLast& il) {
+  constexpr int r = Rounds<S, CB>::r(j);
+  constexpr int SS = kE >> r;
+#pragma unroll
+  for (int s = 0; s < SS; ++s) {
+    if (FWD)
+      fwd_subtree<r, A>(x + (s << r), wv + (s << r), m);
+    else
+      inv_subtree<r, A, LAST>(x + (s << r), wv + (s << r), m, il);
+  }
+}
+
+template <int S, int CB, int TL, int j>
 __device__ __forceinline__ void lds_load_round(u64* x, const u64* lds, u32 tid) {
-  using RD = Rounds<TB, RE>;
-  constexpr int r = RD::r(j);
-  constexpr int w = RD::w(j);
-  constexpr int SS = RD::kE >> r;
+  constexpr int r = Rounds<S, CB>::r(j), w = Rounds<S, CB>::w(j);
+  constexpr int SS = kE >> r;
+  constexpr int kThreads = 1 << (TL - kRE);
 #pragma unroll
   for (int s = 0; s < SS; ++s)
 #pragma unroll
     for (int e = 0; e < (1 << r); ++e)
-      x[(s << r) + e] = lds[lds_slot(tile_index<r, w>(s * RD::kThreads + tid, e))];
+      x[(s << r) + e] = lds[lds_slot(tile_index<r, w>(s * kThreads + tid, e))];
 }
 
-template <int TB, int RE, int j>
+template <int S, int CB, int TL, int j>
 __device__ __forceinline__ void lds_store_round(const u64* x, u64* lds, u32 tid) {
-  using RD = Rounds<TB, RE>;
-  constexpr int r = RD::r(j);
-  constexpr int w = RD::w(j);
-  constexpr int SS = RD::kE >> r;
+  constexpr int r = Rounds<S, CB>::r(j), w = Rounds<S, CB>::w(j);
+  constexpr int SS = kE >> r;
+  constexpr int kThreads = 1 << (TL - kRE);
 #pragma unroll
   for (int s = 0; s < SS; ++s)
 #pragma unroll
     for (int e = 0; e < (1 << r); ++e)
-      lds[lds_slot(tile_index<r, w>(s * RD::kThreads + tid, e))] = x[(s << r) + e];
+      lds[lds_slot(tile_index<r, w>(s * kThreads + tid, e))] = x[(s << r) + e];
 }
 
-// forward rounds J .. NR-1: LDS -> registers -> subtree -> LDS
-template <int TB, int RE, int J, class A>
+// Hand-over of the tile from a round with finest gap 2^w to its neighbour.
+// With w <= 6 a wave (64 consecutive virtual threads) owns one contiguous,
+// aligned run of 512 tile elements in this round AND in every deeper round, so
+// the next reader of those slots is the same wave: the LDS operations of one
+// wave are processed in order and only the compiler has to be kept from
+// reordering.  Transposes across waves (w > 6) need a workgroup barrier, and so
+// does any hand-over involving a short round 0 (r < 3), whose threads own
+// several runs spread over the tile (FULL == false).
+template <int w, bool FULL>
+__device__ __forceinline__ void handover() {
+  if (w > 6 || !FULL) {
+    __syncthreads();
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+// forward rounds J .. NR-1: LDS -> registers -> subtree -> same LDS slots
+template <int S, int CB, int TL, int J, class A>
 __device__ __forceinline__ void fwd_mid_rounds(u64* x, u64* lds, const ulonglong2* tw, u32 tid,
-                                               u32 a0, u32 tile_blk0, const ModConst& m,
+                                               const TileGeom& g, const ModConst& m,
                                                const InvLast& il) {
-  if constexpr (J < Rounds<TB, RE>::NR) {
-    lds_load_round<TB, RE, J>(x, lds, tid);
-    run_round<TB, RE, J, A, true, false>(x, tw, tid, a0, tile_blk0, m, il);
-    __syncthreads();
-    lds_store_round<TB, RE, J>(x, lds, tid);
-    __syncthreads();
-    fwd_mid_rounds<TB, RE, J + 1, A>(x, lds, tw, tid, a0, tile_blk0, m, il);
+  using RD = Rounds<S, CB>;
+  if constexpr (J < RD::NR) {
+    ulonglong2 wv[kE];
+    round_twiddles<S, CB, TL, J>(wv, tw, tid, g);
+    lds_load_round<S, CB, TL, J>(x, lds, tid);
+    round_compute<S, CB, J, A, true, false>(x, wv, m, il);
+    lds_store_round<S, CB, TL, J>(x, lds, tid);
+    handover<RD::w(J), RD::r(J) == kRE>();
+    HX_STAMP(3 + J);
+    fwd_mid_rounds<S, CB, TL, J + 1, A>(x, lds, tw, tid, g, m, il);
   }
 }
 
 // inverse rounds J .. 1 (deepest first)
-template <int TB, int RE, int J, class A>
+template <int S, int CB, int TL, int J, class A>
 __device__ __forceinline__ void inv_mid_rounds(u64* x, u64* lds, const ulonglong2* tw, u32 tid,
-                                               u32 a0, u32 tile_blk0, const ModConst& m,
+                                               const TileGeom& g, const ModConst& m,
                                                const InvLast& il) {
+  using RD = Rounds<S, CB>;
   if constexpr (J >= 1) {
-    lds_load_round<TB, RE, J>(x, lds, tid);
-    run_round<TB, RE, J, A, false, false>(x, tw, tid, a0, tile_blk0, m, il);
-    __syncthreads();
-    lds_store_round<TB, RE, J>(x, lds, tid);
-    __syncthreads();
-    inv_mid_rounds<TB, RE, J - 1, A>(x, lds, tw, tid, a0, tile_blk0, m, il);
+    ulonglong2 wv[kE];
+    round_twiddles<S, CB, TL, J>(wv, tw, tid, g);
+    lds_load_round<S, CB, TL, J>(x, lds, tid);
+    round_compute<S, CB, J, A, false, false>(x, wv, m, il);
+    lds_store_round<S, CB, TL, J>(x, lds, tid);
+    // the next (shallower) round J-1 regroups across waves iff its gap exceeds a wave
+    handover<RD::w(J - 1), RD::r(J - 1) == kRE>();
+    inv_mid_rounds<S, CB, TL, J - 1, A>(x, lds, tw, tid, g, m, il);
   }
 }
 
 // FWD:  global --(round 0)--> LDS --(rounds 1..)--> LDS --> coalesced store
 // INV:  coalesced load --> LDS --(rounds NR-1..1)--> LDS --(round 0)--> global
-template <bool FWD, int TB, int RE, class A>
-__global__ void __launch_bounds__(1 << (kTileLog - RE), (RE == 3 ? 8 : 4))
-block_pass(u64* __restrict__ out, const u64* __restrict__ in,
-           const ulonglong2* __restrict__ tw, ModConst m, u32 log_n, u32 finish, u64 total,
-           u32 vec16, InvLast il) {
-  using RD = Rounds<TB, RE>;
+template <bool FWD, int S, int CB, int TL, class A>
+__global__ void __launch_bounds__(1 << (TL - kRE), 8)
+tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* __restrict__ tw,
+          ModConst m, u32 log_n, u32 finish, u64 total, InvLast il) {
+  using RD = Rounds<S, CB>;
   constexpr int NR = RD::NR;
-  constexpr int kThreads = RD::kThreads;
-  constexpr int kE = RD::kE;
-  __shared__ u64 lds[kLdsWords];
+  constexpr int kTileLog = TL;
+  constexpr int kThreads = 1 << (TL - kRE);
+  __shared__ u64 lds[1 << TL];
   const u32 tid = threadIdx.x;
-  const u64 tile_base = (u64)blockIdx.x << kTileLog;
-  const u32 a0 = log_n - TB;  // heap level of the block roots
-  // index (within its polynomial) of the first 2^TB-block of this tile
-  const u32 tile_blk0 = (u32)((tile_base & ((1ull << log_n) - 1)) >> TB);
+  TileGeom g;
+  bool full_tile;
+  if (CB == 0) {
+    g.base = (u64)blockIdx.x << kTileLog;
+    g.log_row = 0;
+    g.a0 = log_n - S;
+    g.tile_blk0 = (u32)((g.base & ((1ull << log_n) - 1)) >> S);
+    // whole tile inside the batch (always, except for the last tile of a batch
+    // smaller than 4096 elements): lets every guard below fold to a uniform branch
+    full_tile = g.base + (1u << kTileLog) <= total;
+  } else {  // all 2^S rows x 2^CB columns of one polynomial, N >= 4096
+    const u32 tpl = log_n - kTileLog;  // log2(tiles per polynomial)
+    const u64 poly = (u64)blockIdx.x >> tpl;
+    const u32 t = blockIdx.x & ((1u << tpl) - 1);
+    g.base = (poly << log_n) + ((u64)t << CB);
+    g.log_row = log_n - S;
+    g.a0 = 0;
+    g.tile_blk0 = 0;
+    full_tile = true;
+  }
   u64 x[kE];
+  HX_STAMP(0);
 
   if (FWD) {
-    {  // round 0 straight from global memory
+    {  // round 0 straight from global memory; its twiddles are requested first
       constexpr int r = RD::r(0), w = RD::w(0), SS = kE >> r;
+      ulonglong2 wv[kE];
+      round_twiddles<S, CB, TL, 0>(wv, tw, tid, g);
 #pragma unroll
       for (int s = 0; s < SS; ++s)
 #pragma unroll
         for (int e = 0; e < (1 << r); ++e) {
-          const u64 k = tile_base + tile_index<r, w>(s * kThreads + tid, e);
-          x[(s << r) + e] = (k < total) ? in[k] : 0;
+          const u32 p = tile_index<r, w>(s * kThreads + tid, e);
+          x[(s << r) + e] = (full_tile || g.base + p < total) ? in[gaddr<CB>(g, p)] : 0;
         }
-      run_round<TB, RE, 0, A, true, false>(x, tw, tid, a0, tile_blk0, m, il);
-      lds_store_round<TB, RE, 0>(x, lds, tid);
-      __syncthreads();
+      HX_PROFILE_WAIT_VMEM();
+      HX_STAMP(1);
+      round_compute<S, CB, 0, A, true, false>(x, wv, m, il);
+      HX_STAMP(2);
+      lds_store_round<S, CB, TL, 0>(x, lds, tid);
+      handover<RD::w(0), RD::r(0) == kRE>();
+      HX_STAMP(3);
     }
-    fwd_mid_rounds<TB, RE, 1, A>(x, lds, tw, tid, a0, tile_blk0, m, il);
-    // coalesced copy-out, 16 bytes per lane, final reduction fused
+    fwd_mid_rounds<S, CB, TL, 1, A>(x, lds, tw, tid, g, m, il);
+    // copy-out of the run this wave owns after the last round (w = CB <= 6):
+    // 512 tile-contiguous elements, 64 per access; final reduction fused
 #pragma unroll
-    for (int i = 0; i < kE / 2; ++i) {
-      const u32 p = 2 * (i * kThreads + tid);
-      u64 v0 = lds[lds_slot(p)];
-      u64 v1 = lds[lds_slot(p + 1)];
-      if (finish) {
-        v0 = fwd_finish<A>(v0, m, finish == 2);
-        v1 = fwd_finish<A>(v1, m, finish == 2);
-      }
-      if (tile_base + p < total) {
-        if (vec16) {
-          *reinterpret_cast<ulonglong2*>(out + tile_base + p) = make_ulonglong2(v0, v1);
-        } else {  // caller's buffer is only 8-byte aligned
-          out[tile_base + p] = v0;
-          out[tile_base + p + 1] = v1;
-        }
-      }
+    for (int i = 0; i < kE; ++i) {
+      const u32 p = ((tid >> 6) * kE + i) * 64 + (tid & 63);
+      u64 v = lds[lds_slot(p)];
+      if (finish) v = fwd_finish<A>(v, m, finish == 2);
+      if (full_tile || g.base + p < total) out[gaddr<CB>(g, p)] = v;
     }
+    HX_STAMP(8);
+    HX_PROFILE_WAIT_VMEM();
+    HX_STAMP(9);
   } else {
-    // coalesced copy-in
+    // copy-in of the run this wave owns in the deepest round
 #pragma unroll
-    for (int i = 0; i < kE / 2; ++i) {
-      const u32 p = 2 * (i * kThreads + tid);
-      ulonglong2 v = make_ulonglong2(0, 0);
-      if (tile_base + p < total) {
-        if (vec16) {
-          v = *reinterpret_cast<const ulonglong2*>(in + tile_base + p);
-        } else {
-          v.x = in[tile_base + p];
-          v.y = in[tile_base + p + 1];
-        }
-      }
-      lds[lds_slot(p)] = v.x;
-      lds[lds_slot(p + 1)] = v.y;
+    for (int i = 0; i < kE; ++i) {
+      const u32 p = ((tid >> 6) * kE + i) * 64 + (tid & 63);
+      lds[lds_slot(p)] = (full_tile || g.base + p < total) ? in[gaddr<CB>(g, p)] : 0;
     }
-    __syncthreads();
-    inv_mid_rounds<TB, RE, NR - 1, A>(x, lds, tw, tid, a0, tile_blk0, m, il);
-    lds_load_round<TB, RE, 0>(x, lds, tid);
-    if (a0 == 0)
-      run_round<TB, RE, 0, A, false, true>(x, tw, tid, a0, tile_blk0, m, il);
-    else
-      run_round<TB, RE, 0, A, false, false>(x, tw, tid, a0, tile_blk0, m, il);
+    handover<RD::w(NR - 1), RD::r(NR - 1) == kRE>();
+    inv_mid_rounds<S, CB, TL, NR - 1, A>(x, lds, tw, tid, g, m, il);
     {
       constexpr int r = RD::r(0), w = RD::w(0), SS = kE >> r;
+      ulonglong2 wv[kE];
+      round_twiddles<S, CB, TL, 0>(wv, tw, tid, g);
+      lds_load_round<S, CB, TL, 0>(x, lds, tid);
+      if (g.a0 == 0)
+        round_compute<S, CB, 0, A, false, true>(x, wv, m, il);
+      else
+        round_compute<S, CB, 0, A, false, false>(x, wv, m, il);
 #pragma unroll
       for (int s = 0; s < SS; ++s)
 #pragma unroll
         for (int e = 0; e < (1 << r); ++e) {
-          const u64 k = tile_base + tile_index<r, w>(s * kThreads + tid, e);
+          const u32 p = tile_index<r, w>(s * kThreads + tid, e);
           u64 v = x[(s << r) + e];
           if (finish == 2) v = csub(v, m.q);
-          if (k < total) out[k] = v;
+          if (full_tile || g.base + p < total) out[gaddr<CB>(g, p)] = v;
         }
     }
   }
@@ -400,46 +503,35 @@ static hipError_t launch_strided(int R, u64* out, const u64* in, const ulonglong
   return hipGetLastError();
 }
 
-// Experiment knob: HEXL_AMD_BLOCK_RE=3|4 picks the block_pass geometry for
-// 12-stage tiles (default 3: 512 threads x 8 elements).
-static int block_re() {
-  static const int v = [] {
-    const char* e = getenv("HEXL_AMD_BLOCK_RE");
-    return (e && e[0] == '4') ? 4 : 3;
-  }();
-  return v;
-}
-
-template <bool FWD, class A>
-static hipError_t launch_block(int TB, u64* out, const u64* in, const ulonglong2* tw,
-                               const ModConst& m, u32 log_n, u32 finish, u64 batch,
-                               const InvLast& il, hipStream_t st) {
+// Bottom pass: S stages on contiguous sub-blocks (CB = 0), tile of 2^TL elements.
+template <bool FWD, int TL, class A>
+static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2* tw,
+                                const ModConst& m, u32 log_n, u32 finish, u64 batch,
+                                const InvLast& il, hipStream_t st) {
   const u64 total = batch << log_n;
-  const unsigned grid = (unsigned)((total + (1u << kTileLog) - 1) >> kTileLog);
-  const u32 vec16 = (((uintptr_t)out | (uintptr_t)in) & 15) == 0 ? 1u : 0u;
-  ScopedKernelTimer timer(FWD ? "ntt_fwd_block_pass" : "ntt_inv_block_pass", st);
-#define HX_LAUNCH_B(T, RE)                                                              \
-  hipLaunchKernelGGL((block_pass<FWD, T, RE, A>), dim3(grid), dim3(1 << (kTileLog - RE)), 0, \
-                     st, out, in, tw, m, log_n, finish, total, vec16, il)
-  switch (TB) {
-    case 1: HX_LAUNCH_B(1, 4); break;
-    case 2: HX_LAUNCH_B(2, 4); break;
-    case 3: HX_LAUNCH_B(3, 4); break;
-    case 4: HX_LAUNCH_B(4, 4); break;
-    case 5: HX_LAUNCH_B(5, 4); break;
-    case 6: HX_LAUNCH_B(6, 4); break;
-    case 7: HX_LAUNCH_B(7, 4); break;
-    case 8: HX_LAUNCH_B(8, 4); break;
-    case 9: HX_LAUNCH_B(9, 4); break;
-    case 10: HX_LAUNCH_B(10, 4); break;
-    case 11: HX_LAUNCH_B(11, 4); break;
-    case 12:
-      if (block_re() == 3) {
-        HX_LAUNCH_B(12, 3);
-      } else {
-        HX_LAUNCH_B(12, 4);
-      }
-      break;
+  const unsigned grid = (unsigned)((total + (1u << TL) - 1) >> TL);
+  ScopedKernelTimer timer(FWD ? "ntt_fwd_tile_pass_bottom" : "ntt_inv_tile_pass_bottom", st);
+#define HX_LAUNCH_B(T)                                                                    \
+  case T:                                                                                 \
+    if constexpr (T <= TL && (TL == 10 || T >= 9))                                        \
+      hipLaunchKernelGGL((tile_pass<FWD, T, 0, TL, A>), dim3(grid), dim3(1 << (TL - kRE)), 0, \
+                         st, out, in, tw, m, log_n, finish, total, il);                   \
+    else                                                                                  \
+      return hipErrorInvalidValue;                                                        \
+    break;
+  switch (S) {
+    HX_LAUNCH_B(1)
+    HX_LAUNCH_B(2)
+    HX_LAUNCH_B(3)
+    HX_LAUNCH_B(4)
+    HX_LAUNCH_B(5)
+    HX_LAUNCH_B(6)
+    HX_LAUNCH_B(7)
+    HX_LAUNCH_B(8)
+    HX_LAUNCH_B(9)
+    HX_LAUNCH_B(10)
+    HX_LAUNCH_B(11)
+    HX_LAUNCH_B(12)
     default:
       return hipErrorInvalidValue;
   }
@@ -447,77 +539,167 @@ static hipError_t launch_block(int TB, u64* out, const u64* in, const ulonglong2
   return hipGetLastError();
 }
 
-// Lazy range policy: every multiplicand must stay below 2^62, i.e.
-// (4 + 2*20) q (forward) and 64 q (inverse subtrees of up to 5 stages) < 2^62.
-
-
-// Split the `top` leading stages into strided passes of at most 5 stages.
-static int split_top(int top, int* sizes) {
-  int n = 0;
-  if (top <= 0) return 0;
-  if (top <= 5) {
-    sizes[n++] = top;
-    return n;
+// Top pass: the first S stages (heap levels 0..S-1) on tiles of 2^S rows x
+// 2^(TL-S) columns, N >= 2^TL.
+template <bool FWD, int TL, class A>
+static hipError_t launch_top(int S, u64* out, const u64* in, const ulonglong2* tw,
+                             const ModConst& m, u32 log_n, u32 finish, u64 batch,
+                             const InvLast& il, hipStream_t st) {
+  const u64 total = batch << log_n;
+  const unsigned grid = (unsigned)(total >> TL);
+  ScopedKernelTimer timer(FWD ? "ntt_fwd_tile_pass_top" : "ntt_inv_tile_pass_top", st);
+#define HX_LAUNCH_T(T)                                                                      \
+  case T:                                                                                   \
+    if constexpr (T <= TL - 4 && (TL == 10 || T == 8))                                      \
+      hipLaunchKernelGGL((tile_pass<FWD, T, TL - T, TL, A>), dim3(grid),                    \
+                         dim3(1 << (TL - kRE)), 0, st, out, in, tw, m, log_n, finish, total, \
+                         il);                                                               \
+    else                                                                                    \
+      return hipErrorInvalidValue;                                                          \
+    break;
+  switch (S) {
+    HX_LAUNCH_T(1)
+    HX_LAUNCH_T(2)
+    HX_LAUNCH_T(3)
+    HX_LAUNCH_T(4)
+    HX_LAUNCH_T(5)
+    HX_LAUNCH_T(6)
+    HX_LAUNCH_T(7)
+    HX_LAUNCH_T(8)
+    default:
+      return hipErrorInvalidValue;
   }
-  int passes = (top + 3) / 4;
-  int base = top / passes, extra = top % passes;
-  for (int i = 0; i < passes; ++i) sizes[n++] = base + (i < extra ? 1 : 0);
-  return n;
+#undef HX_LAUNCH_T
+  return hipGetLastError();
+}
+
+// Plan of one transform: an optional top tile_pass of `top_tile` stages (or
+// `n_strided` register-only passes), then a bottom tile_pass of `bottom` stages;
+// `tl` = log2 of the tile size both tile passes use.
+struct Plan {
+  int tl;
+  int top_tile;
+  int n_strided;
+  int strided[8];
+  int bottom;
+};
+
+// Default for N >= 2^13: register-only strided pass(es) + a 12-stage bottom
+// tile_pass.  HEXL_AMD_PLAN=tiled selects two LDS-tiled kernels instead (6 + 10
+// stages on 1024-element tiles for N = 2^16); measured within 2% of each other
+// on MI355X, see DESIGN.md.
+static bool plan_strided_requested() {
+  static const bool v = [] {
+    const char* e = getenv("HEXL_AMD_PLAN");
+    return !(e && strcmp(e, "tiled") == 0);
+  }();
+  return v;
+}
+
+static Plan make_plan(int L) {
+  Plan p{};
+  if (L <= 12) {  // one kernel, one HBM round trip
+    p.tl = L <= 10 ? 10 : 12;
+    p.bottom = L;
+    return p;
+  }
+  if (plan_strided_requested() && L >= 13) {
+    p.tl = 12;
+    p.bottom = 12;
+    int top = L - 12;
+    if (top <= 5) {
+      p.strided[p.n_strided++] = top;
+    } else {
+      int passes = (top + 3) / 4;
+      int base = top / passes, extra = top % passes;
+      for (int i = 0; i < passes; ++i) p.strided[p.n_strided++] = base + (i < extra ? 1 : 0);
+    }
+    return p;
+  }
+  if (L <= 16) {  // 1024-element tiles: top <= 6 stages, bottom <= 10
+    p.tl = 10;
+    const int half = (L + 1) / 2;
+    p.bottom = half > L - 6 ? half : L - 6;
+    p.top_tile = L - p.bottom;
+    return p;
+  }
+  // 4096-element tiles: 8-stage top, bottom 9..12
+  p.tl = 12;
+  p.top_tile = 8;
+  p.bottom = L - 8;
+  return p;
 }
 
 template <class A>
 static hipError_t forward_impl(const NttTables& t, u64* result, const u64* operand, u64 batch,
                                u64 out_mf, hipStream_t st) {
-  const int L = (int)t.log_n;
-  const int TB = L < kTileLog ? L : kTileLog;
-  int sizes[8];
-  const int np = split_top(L - TB, sizes);
+  const Plan p = make_plan((int)t.log_n);
   const u64* src = operand;
-  u32 a0 = 0;
   InvLast il{};
-  for (int i = 0; i < np; ++i) {
-    hipError_t e = launch_strided<true, A>(sizes[i], result, src, t.fwd, t.mod, t.log_n, a0, 0,
-                                           batch, il, st);
+  hipError_t e;
+  if (p.top_tile) {
+    e = p.tl == 10 ? launch_top<true, 10, A>(p.top_tile, result, src, t.fwd, t.mod, t.log_n, 0,
+                                             batch, il, st)
+                   : launch_top<true, 12, A>(p.top_tile, result, src, t.fwd, t.mod, t.log_n, 0,
+                                             batch, il, st);
     if (e != hipSuccess) return e;
-    a0 += sizes[i];
     src = result;
   }
-  return launch_block<true, A>(TB, result, src, t.fwd, t.mod, t.log_n, out_mf == 1 ? 2 : 1,
-                               batch, il, st);
+  u32 a0 = 0;
+  for (int i = 0; i < p.n_strided; ++i) {
+    e = launch_strided<true, A>(p.strided[i], result, src, t.fwd, t.mod, t.log_n, a0, 0, batch,
+                                il, st);
+    if (e != hipSuccess) return e;
+    a0 += p.strided[i];
+    src = result;
+  }
+  const u32 fin = out_mf == 1 ? 2 : 1;
+  return p.tl == 10 ? launch_bottom<true, 10, A>(p.bottom, result, src, t.fwd, t.mod, t.log_n,
+                                                 fin, batch, il, st)
+                    : launch_bottom<true, 12, A>(p.bottom, result, src, t.fwd, t.mod, t.log_n,
+                                                 fin, batch, il, st);
 }
 
 template <class A>
 static hipError_t inverse_impl(const NttTables& t, u64* result, const u64* operand, u64 batch,
                                u64 out_mf, hipStream_t st) {
-  const int L = (int)t.log_n;
-  const int TB = L < kTileLog ? L : kTileLog;
-  int sizes[8];
-  const int np = split_top(L - TB, sizes);
+  const Plan p = make_plan((int)t.log_n);
   const u32 fin = out_mf == 1 ? 2 : 1;
-  hipError_t e = launch_block<false, A>(TB, result, operand, t.inv, t.mod, t.log_n,
-                                        np == 0 ? fin : 0, batch, t.inv_last, st);
+  const bool only = !p.top_tile && p.n_strided == 0;
+  hipError_t e =
+      p.tl == 10 ? launch_bottom<false, 10, A>(p.bottom, result, operand, t.inv, t.mod, t.log_n,
+                                               only ? fin : 0, batch, t.inv_last, st)
+                 : launch_bottom<false, 12, A>(p.bottom, result, operand, t.inv, t.mod, t.log_n,
+                                               only ? fin : 0, batch, t.inv_last, st);
   if (e != hipSuccess) return e;
-  u32 a0 = (u32)(L - TB);
-  for (int i = np - 1; i >= 0; --i) {
-    a0 -= sizes[i];
-    e = launch_strided<false, A>(sizes[i], result, result, t.inv, t.mod, t.log_n, a0,
+  u32 a0 = t.log_n - (u32)p.bottom;
+  for (int i = p.n_strided - 1; i >= 0; --i) {
+    a0 -= p.strided[i];
+    e = launch_strided<false, A>(p.strided[i], result, result, t.inv, t.mod, t.log_n, a0,
                                  i == 0 ? fin : 0, batch, t.inv_last, st);
     if (e != hipSuccess) return e;
   }
+  if (p.top_tile)
+    return p.tl == 10 ? launch_top<false, 10, A>(p.top_tile, result, result, t.inv, t.mod,
+                                                 t.log_n, fin, batch, t.inv_last, st)
+                      : launch_top<false, 12, A>(p.top_tile, result, result, t.inv, t.mod,
+                                                 t.log_n, fin, batch, t.inv_last, st);
   return hipSuccess;
 }
 
 hipError_t ntt_forward_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
                               u64 out_mf, hipStream_t st) {
   if (batch == 0) return hipSuccess;
-  if (t.mod.q < kLazyModulusBound) return forward_impl<Lazy>(t, result, operand, batch, out_mf, st);
+  if (t.mod.q < kLazyModulusBound)
+    return forward_impl<Lazy>(t, result, operand, batch, out_mf, st);
   return forward_impl<Strict>(t, result, operand, batch, out_mf, st);
 }
 
 hipError_t ntt_inverse_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
                               u64 out_mf, hipStream_t st) {
   if (batch == 0) return hipSuccess;
-  if (t.mod.q < kLazyModulusBound) return inverse_impl<Lazy>(t, result, operand, batch, out_mf, st);
+  if (t.mod.q < kLazyModulusBound)
+    return inverse_impl<Lazy>(t, result, operand, batch, out_mf, st);
   return inverse_impl<Strict>(t, result, operand, batch, out_mf, st);
 }
 

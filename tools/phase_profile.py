@@ -1,0 +1,50 @@
+"""Developer diagnostic: where does a block_pass workgroup spend its life?
+
+Loads tools/libhexl_amd_phaseprof.so (the product sources built with
+-DHEXL_AMD_PHASE_PROFILE, see tools/build_phaseprof.sh), runs the forward NTT at
+the headline shape and prints, per phase, the mean / p50 / p90 number of shader
+cycles a wave spends between consecutive stamps.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+lib = C.CDLL(os.path.join(HERE, "libhexl_amd_phaseprof.so"))
+vp, u64 = C.c_void_p, C.c_uint64
+lib.hexl_amd_ntt_create.argtypes = [C.POINTER(vp), u64, u64, u64, C.c_int]
+lib.hexl_amd_ntt_forward.argtypes = [vp, vp, vp, u64, u64, u64, vp]
+lib.hexl_amd_debug_set_phase_buf.argtypes = [vp]
+lib.hexl_amd_last_error.restype = C.c_char_p
+
+N, BATCH = 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+Q = 18014398510661633
+plan = vp()
+assert lib.hexl_amd_ntt_create(C.byref(plan), N, Q, 0, 0) == 0, lib.hexl_amd_last_error()
+data = torch.randint(0, Q, (BATCH, N), dtype=torch.int64, device="cuda")
+blocks = BATCH * N // 1024
+stamps = torch.zeros((blocks, 8, 16), dtype=torch.int64, device="cuda")
+for it in range(3):
+    stamps.zero_()
+    torch.cuda.synchronize()
+    lib.hexl_amd_debug_set_phase_buf(vp(stamps.data_ptr()))
+    rc = lib.hexl_amd_ntt_forward(plan, vp(data.data_ptr()), vp(data.data_ptr()), BATCH, 4, 4, None)
+    assert rc == 0, lib.hexl_amd_last_error()
+    torch.cuda.synchronize()
+    lib.hexl_amd_debug_set_phase_buf(None)
+s = stamps.cpu().numpy().astype(np.int64)
+names = {1: "global loads landed", 2: "round 0 compute", 3: "LDS store + block barrier",
+         4: "round 1 (load, compute, store, wave sync)", 5: "round 2", 6: "round 3",
+         8: "copy-out: LDS read, finish, issue stores", 9: "stores acknowledged"}
+order = [0, 1, 2, 3, 4, 5, 6, 8, 9]
+print(f"forward block_pass, batch {BATCH}: per-wave cycles between stamps")
+tot = s[:, :, 9] - s[:, :, 0]
+for a, b in zip(order[:-1], order[1:]):
+    d = (s[:, :, b] - s[:, :, a]).reshape(-1)
+    print(f"  {names[b]:48s} mean {d.mean():9.0f}  p50 {np.percentile(d, 50):9.0f}  "
+          f"p90 {np.percentile(d, 90):9.0f}  ({100.0 * d.mean() / tot.mean():4.1f}%)")
+print(f"  wave lifetime mean {tot.mean():.0f} cycles; kernel span "
+      f"{(s[:, :, 9].max() - s[:, :, 0][s[:, :, 0] > 0].min())} cycles")

@@ -1,0 +1,107 @@
+// ubench3.hip -- ALU-only cost of the register subtrees (no memory, no LDS):
+// cycles per wave-butterfly for the forward / inverse subtree of depth R under
+// the Strict and Lazy arithmetic policies at 4 and 8 waves per SIMD.  This is
+// the instruction-issue roofline of the NTT kernels.
+// Build: hipcc --offload-arch=gfx950 -O3 -Ihexl_amd/csrc tools/ubench3.hip -o tools/ubench3
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#include "modarith.h"
+using namespace hexl_amd;
+
+#define CK(x)                                                                   \
+  do {                                                                          \
+    hipError_t e_ = (x);                                                        \
+    if (e_ != hipSuccess) {                                                     \
+      fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      exit(1);                                                                  \
+    }                                                                           \
+  } while (0)
+
+constexpr int TRIPS = 64;
+
+template <int R, class A, bool FWD>
+__global__ void __launch_bounds__(256) k(u64* out, const ulonglong2* tw, ModConst m, u64* cyc) {
+  constexpr int E = 1 << R;
+  u64 x[E];
+  for (int e = 0; e < E; ++e) x[e] = (threadIdx.x * 977 + e * 131 + 7) % m.q;
+  ulonglong2 w[E];  // E-1 twiddles, held in registers
+  for (int e = 0; e < E; ++e) w[e] = tw[(threadIdx.x & 63) * E + e];
+  u64 t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < TRIPS; ++it) {
+#pragma unroll
+    for (int v = 0; v < R; ++v) {
+      const int half = 1 << (R - 1 - v);
+#pragma unroll
+      for (int g = 0; g < (1 << v); ++g) {
+        const ulonglong2 ww = w[(1 << v) + g];
+#pragma unroll
+        for (int j = 0; j < half; ++j) {
+          if (FWD)
+            fwd_butterfly<A>(x[g * 2 * half + j], x[g * 2 * half + j + half], ww.x, ww.y, m);
+          else
+            inv_butterfly<A>(x[g * 2 * half + j], x[g * 2 * half + j + half], ww.x, ww.y, m,
+                             v);
+        }
+      }
+    }
+    // keep magnitudes bounded across trips (cheap, same for every variant)
+#pragma unroll
+    for (int e = 0; e < E; ++e) x[e] &= (1ull << 56) - 1;
+  }
+  u64 t1 = __builtin_readcyclecounter();
+  u64 acc = 0;
+  for (int e = 0; e < E; ++e) acc += x[e];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int R, class A, bool FWD>
+static void run(const char* name, const ulonglong2* tw, ModConst m) {
+  printf("%-34s", name);
+  for (int wps : {1, 2, 4, 8}) {
+    const int blocks = 256 * wps;
+    u64 *out, *cyc;
+    CK(hipMalloc(&out, (size_t)blocks * 256 * 8));
+    CK(hipMalloc(&cyc, (size_t)blocks * 8));
+    k<R, A, FWD><<<blocks, 256>>>(out, tw, m, cyc);
+    CK(hipDeviceSynchronize());
+    k<R, A, FWD><<<blocks, 256>>>(out, tw, m, cyc);
+    CK(hipDeviceSynchronize());
+    std::vector<u64> h(blocks);
+    CK(hipMemcpy(h.data(), cyc, blocks * 8, hipMemcpyDeviceToHost));
+    double avg = 0;
+    for (auto v : h) avg += v;
+    avg /= blocks;
+    const double bfly = (double)TRIPS * R * (1 << (R - 1));
+    printf("  w%d: %6.1f cyc/bfly/wave (%5.1f per SIMD)", wps, avg / bfly, avg / bfly / wps);
+    CK(hipFree(out));
+    CK(hipFree(cyc));
+  }
+  printf("\n");
+}
+
+int main() {
+  const u64 q = 18014398510661633ull;
+  ModConst m{q, 2 * q, 0 - q, (u64)((((unsigned __int128)1) << 64) / q)};
+  std::vector<ulonglong2> h(64 * 16);
+  for (size_t i = 0; i < h.size(); ++i) {
+    u64 W = (0x9E3779B97F4A7C15ull * (i + 1)) % q;
+    h[i].x = W;
+    h[i].y = (u64)((((unsigned __int128)W) << 63) / q);
+  }
+  ulonglong2* tw;
+  CK(hipMalloc(&tw, h.size() * sizeof(ulonglong2)));
+  CK(hipMemcpy(tw, h.data(), h.size() * sizeof(ulonglong2), hipMemcpyHostToDevice));
+  run<3, Lazy, true>("fwd subtree R=3 Lazy", tw, m);
+  run<4, Lazy, true>("fwd subtree R=4 Lazy", tw, m);
+  run<3, Strict, true>("fwd subtree R=3 Strict", tw, m);
+  run<4, Strict, true>("fwd subtree R=4 Strict", tw, m);
+  run<3, Lazy, false>("inv subtree R=3 Lazy (no ladder)", tw, m);
+  run<4, Lazy, false>("inv subtree R=4 Lazy (no ladder)", tw, m);
+  run<3, Strict, false>("inv subtree R=3 Strict", tw, m);
+  return 0;
+}

@@ -120,8 +120,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from hexl_amd.sharding import max_over_ranks, shard_range, units_by_prime
+
+    # weak scaling: `world` RNS primes x `batch` polynomials; the flat (prime, poly)
+    # unit range is cut into contiguous per-rank shards -> rank g owns prime g
     batch = args.batch
-    q = PRIMES[rank % len(PRIMES)]
+    begin, end = shard_range(world * batch, world, rank)
+    (prime_idx, first_poly, count), = units_by_prime(begin, end, batch)
+    assert (first_poly, count) == (0, batch)
+    q = PRIMES[prime_idx % len(PRIMES)]
     ntt = hx.NTT(N, q)
     data = torch.empty((batch, N), dtype=torch.int64, device="cuda")
     hx.fill_splitmix(data, N, batch, 1 + rank * batch, q)
@@ -144,10 +151,7 @@ def main():
     # fwd followed by inv is the identity: the data must be back where it started
     assert torch.equal(check, data[:2]), "round trip mismatch inside the timed region"
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, dist, device="cuda")
 
     ntts = 2 * batch * args.steps * world
     value = ntts / elapsed

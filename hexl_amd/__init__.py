@@ -55,6 +55,7 @@ def _load():
 
     sig("hexl_amd_last_error", C.c_char_p)
     sig("hexl_amd_device_count", ci, C.POINTER(ci))
+    sig("hexl_amd_pointer_is_device", ci, vp)
     sig("hexl_amd_ntt_create", ci, C.POINTER(vp), u64, u64, u64, ci)
     sig("hexl_amd_ntt_destroy", ci, vp)
     sig("hexl_amd_ntt_degree", u64, vp)
@@ -100,7 +101,8 @@ lib = _load()
 
 # Every symbol include/hexl_amd.h declares (checked by tests/test_capi_symbols.py)
 C_ABI_SYMBOLS = [
-    "hexl_amd_last_error", "hexl_amd_device_count", "hexl_amd_ntt_create",
+    "hexl_amd_last_error", "hexl_amd_device_count", "hexl_amd_pointer_is_device",
+    "hexl_amd_ntt_create",
     "hexl_amd_ntt_destroy", "hexl_amd_ntt_degree", "hexl_amd_ntt_modulus",
     "hexl_amd_ntt_root_of_unity", "hexl_amd_ntt_device", "hexl_amd_ntt_table",
     "hexl_amd_ntt_forward", "hexl_amd_ntt_inverse", "hexl_amd_ntt_forward_rns",

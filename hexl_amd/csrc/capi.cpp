@@ -116,6 +116,17 @@ int hexl_amd_device_count(int* count) {
   return HEXL_AMD_OK;
 }
 
+int hexl_amd_pointer_is_device(const void* p) {
+  if (!p) return 0;
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // unregistered host memory reports an error: clear it
+    return 0;
+  }
+  return (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged) ? 1 : 0;
+}
+
 int hexl_amd_ntt_check_arguments(uint64_t degree, uint64_t modulus) {
   return nt::ntt_check_arguments(degree, modulus) ? 1 : 0;
 }

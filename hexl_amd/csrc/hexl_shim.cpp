@@ -1,0 +1,272 @@
+// hexl_shim.cpp -- namespace intel::hexl over the C-ABI of include/hexl_amd.h.
+//
+// This translation unit is the whole of libhexl.so: it includes no HIP header
+// and calls nothing but the functions declared in hexl_amd.h, which is the
+// proof that the C-ABI is a sufficient drop-in boundary for the reference's
+// NTT / Eltwise* / number-theory API.  Errors reported by the C-ABI (contract
+// violations, HIP failures, no GPU) become std::runtime_error -- the reference
+// throws the same type from HEXL_CHECK in debug builds
+// (hexl/include/hexl/util/check.hpp:19-34) and has undefined behaviour in
+// release builds.
+#include <mutex>
+#include <stdexcept>
+#include <string>
+
+#include "hexl/hexl.hpp"
+#include "hexl_amd.h"
+
+namespace intel {
+namespace hexl {
+
+AllocatorStrategyPtr mallocStrategy = AllocatorStrategyPtr(new MallocStrategy);
+
+namespace {
+
+void check(int rc) {
+  if (rc != HEXL_AMD_OK) throw std::runtime_error(std::string("hexl: ") + hexl_amd_last_error());
+}
+
+using Table = AlignedVector64<uint64_t>;
+
+}  // namespace
+
+// ---------------------------------------------------------------- number theory
+uint64_t ReverseBits(uint64_t x, uint64_t bit_width) { return hexl_amd_reverse_bits(x, bit_width); }
+uint64_t InverseMod(uint64_t x, uint64_t modulus) {
+  HEXL_CHECK(x % modulus != 0, x << " does not have a InverseMod");
+  return hexl_amd_inverse_mod(x, modulus);
+}
+uint64_t MultiplyMod(uint64_t x, uint64_t y, uint64_t modulus) {
+  HEXL_CHECK(modulus != 0, "modulus == 0");
+  return hexl_amd_multiply_mod(x, y, modulus);
+}
+uint64_t MultiplyMod(uint64_t x, uint64_t y, uint64_t y_precon, uint64_t modulus) {
+  const uint64_t r = x * y - MultiplyUInt64Hi<64>(x, y_precon) * modulus;
+  return r >= modulus ? r - modulus : r;
+}
+uint64_t AddUIntMod(uint64_t x, uint64_t y, uint64_t modulus) {
+  const uint64_t s = x + y;
+  return s >= modulus ? s - modulus : s;
+}
+uint64_t SubUIntMod(uint64_t x, uint64_t y, uint64_t modulus) {
+  const uint64_t d = x + modulus - y;
+  return d >= modulus ? d - modulus : d;
+}
+uint64_t PowMod(uint64_t base, uint64_t exp, uint64_t modulus) {
+  return hexl_amd_pow_mod(base, exp, modulus);
+}
+bool IsPrimitiveRoot(uint64_t root, uint64_t degree, uint64_t modulus) {
+  return hexl_amd_is_primitive_root(root, degree, modulus) != 0;
+}
+uint64_t GeneratePrimitiveRoot(uint64_t degree, uint64_t modulus) {
+  return hexl_amd_generate_primitive_root(degree, modulus);
+}
+uint64_t MinimalPrimitiveRoot(uint64_t degree, uint64_t modulus) {
+  return hexl_amd_minimal_primitive_root(degree, modulus);
+}
+bool IsPrime(uint64_t n) { return hexl_amd_is_prime(n) != 0; }
+std::vector<uint64_t> GeneratePrimes(size_t num_primes, size_t bit_size, bool prefer_small_primes,
+                                     size_t ntt_size) {
+  std::vector<uint64_t> out(num_primes);
+  const size_t found = hexl_amd_generate_primes(out.data(), num_primes, bit_size,
+                                                prefer_small_primes ? 1 : 0, ntt_size);
+  if (found != num_primes) throw std::runtime_error("hexl: Failed to find enough primes");
+  return out;
+}
+
+// ---------------------------------------------------------------- NTT
+struct NTT::State {
+  hexl_amd_ntt* plan = nullptr;
+  uint64_t degree = 0, q = 0, w = 0;
+  AlignedAllocator<uint64_t, 64> alloc;
+  // index: 0..6 as hexl_amd_ntt_table; 7..10 the AVX512-layout variants
+  mutable Table tables[11];
+  mutable std::once_flag once[11];
+
+  explicit State(std::shared_ptr<AllocatorBase> a)
+      : alloc(a),
+        tables{Table(alloc), Table(alloc), Table(alloc), Table(alloc), Table(alloc), Table(alloc),
+               Table(alloc), Table(alloc), Table(alloc), Table(alloc), Table(alloc)} {}
+  ~State() { hexl_amd_ntt_destroy(plan); }
+
+  const Table& base_table(int which) const {
+    std::call_once(once[which], [&] {
+      const uint64_t* p = hexl_amd_ntt_table(plan, which);
+      tables[which].assign(p, p + degree);
+    });
+    return tables[which];
+  }
+
+  // Root powers with entries [N/8, N/4) repeated 4x and [N/4, N/2) repeated 2x
+  // (hexl/ntt/ntt-internal.cpp:77-111) and their Barrett factors.
+  const Table& avx_table(int idx, uint64_t shift) const {
+    std::call_once(once[idx], [&] {
+      const Table& R = base_table(0);
+      Table v(alloc);
+      const size_t n = degree;
+      for (size_t i = 0; i < n / 8; ++i) v.push_back(R[i]);
+      for (size_t i = n / 8; i < n / 4; ++i)
+        for (int k = 0; k < 4; ++k) v.push_back(R[i]);
+      for (size_t i = n / 4; i < n / 2; ++i)
+        for (int k = 0; k < 2; ++k) v.push_back(R[i]);
+      for (size_t i = n / 2; i < n; ++i) v.push_back(R[i]);
+      if (n < 8) v.assign(R.begin(), R.end());
+      if (shift)
+        for (auto& x : v) x = hexl_amd_multiply_factor(x, shift, q);
+      tables[idx] = std::move(v);
+    });
+    return tables[idx];
+  }
+};
+
+const NTT::State& NTT::state() const {
+  if (!m_state) throw std::runtime_error("hexl: NTT object is empty");
+  return *m_state;
+}
+
+NTT::NTT(uint64_t degree, uint64_t q, uint64_t root_of_unity,
+         std::shared_ptr<AllocatorBase> alloc_ptr)
+    : m_state(std::make_shared<State>(alloc_ptr)) {
+  check(hexl_amd_ntt_create(&m_state->plan, degree, q, root_of_unity, -1));
+  m_state->degree = degree;
+  m_state->q = q;
+  m_state->w = hexl_amd_ntt_root_of_unity(m_state->plan);
+  // the reference fills its tables in the constructor through the allocator
+  // (test/test-ntt.cpp:168-200 observes the allocation); do the same for the
+  // four tables the transforms are defined by
+  m_state->base_table(0);
+  m_state->base_table(2);
+  m_state->base_table(3);
+  m_state->base_table(6);
+}
+
+NTT::NTT(uint64_t degree, uint64_t q, std::shared_ptr<AllocatorBase> alloc_ptr)
+    : NTT(degree, q, uint64_t{0} /* 0 selects MinimalPrimitiveRoot(2N, q) */, alloc_ptr) {}
+
+bool NTT::CheckArguments(uint64_t degree, uint64_t modulus) {
+  return hexl_amd_ntt_check_arguments(degree, modulus) != 0;
+}
+
+void NTT::ComputeForwardBatch(uint64_t* result, const uint64_t* operand, uint64_t batch,
+                              uint64_t input_mod_factor, uint64_t output_mod_factor) {
+  const State& s = state();
+  if (hexl_amd_pointer_is_device(operand) && hexl_amd_pointer_is_device(result)) {
+    check(hexl_amd_ntt_forward(s.plan, result, operand, batch, input_mod_factor,
+                               output_mod_factor, nullptr));
+  } else {
+    check(hexl_amd_ntt_forward_host(s.plan, result, operand, batch, input_mod_factor,
+                                    output_mod_factor));
+  }
+}
+
+void NTT::ComputeInverseBatch(uint64_t* result, const uint64_t* operand, uint64_t batch,
+                              uint64_t input_mod_factor, uint64_t output_mod_factor) {
+  const State& s = state();
+  if (hexl_amd_pointer_is_device(operand) && hexl_amd_pointer_is_device(result)) {
+    check(hexl_amd_ntt_inverse(s.plan, result, operand, batch, input_mod_factor,
+                               output_mod_factor, nullptr));
+  } else {
+    check(hexl_amd_ntt_inverse_host(s.plan, result, operand, batch, input_mod_factor,
+                                    output_mod_factor));
+  }
+}
+
+void NTT::ComputeForward(uint64_t* result, const uint64_t* operand, uint64_t input_mod_factor,
+                         uint64_t output_mod_factor) {
+  ComputeForwardBatch(result, operand, 1, input_mod_factor, output_mod_factor);
+}
+
+void NTT::ComputeInverse(uint64_t* result, const uint64_t* operand, uint64_t input_mod_factor,
+                         uint64_t output_mod_factor) {
+  ComputeInverseBatch(result, operand, 1, input_mod_factor, output_mod_factor);
+}
+
+uint64_t NTT::GetMinimalRootOfUnity() const { return state().w; }
+uint64_t NTT::GetDegree() const { return state().degree; }
+uint64_t NTT::GetModulus() const { return state().q; }
+
+const Table& NTT::GetRootOfUnityPowers() const { return state().base_table(0); }
+const Table& NTT::GetPrecon32RootOfUnityPowers() const { return state().base_table(1); }
+const Table& NTT::GetPrecon64RootOfUnityPowers() const { return state().base_table(2); }
+const Table& NTT::GetInvRootOfUnityPowers() const { return state().base_table(3); }
+const Table& NTT::GetPrecon32InvRootOfUnityPowers() const { return state().base_table(4); }
+const Table& NTT::GetPrecon52InvRootOfUnityPowers() const { return state().base_table(5); }
+const Table& NTT::GetPrecon64InvRootOfUnityPowers() const { return state().base_table(6); }
+const Table& NTT::GetAVX512RootOfUnityPowers() const { return state().avx_table(7, 0); }
+const Table& NTT::GetAVX512Precon32RootOfUnityPowers() const { return state().avx_table(8, 32); }
+const Table& NTT::GetAVX512Precon52RootOfUnityPowers() const { return state().avx_table(9, 52); }
+const Table& NTT::GetAVX512Precon64RootOfUnityPowers() const { return state().avx_table(10, 64); }
+
+// ---------------------------------------------------------------- Eltwise
+namespace {
+
+bool on_device(const void* a, const void* b, const void* c) {
+  return hexl_amd_pointer_is_device(a) && (!b || hexl_amd_pointer_is_device(b)) &&
+         (!c || hexl_amd_pointer_is_device(c));
+}
+
+}  // namespace
+
+void EltwiseAddMod(uint64_t* result, const uint64_t* operand1, const uint64_t* operand2,
+                   uint64_t n, uint64_t modulus) {
+  if (on_device(result, operand1, operand2))
+    check(hexl_amd_eltwise_add_mod(result, operand1, operand2, n, modulus, nullptr));
+  else
+    check(hexl_amd_eltwise_host(0, result, operand1, operand2, 0, n, modulus, 1, 1));
+}
+
+void EltwiseAddMod(uint64_t* result, const uint64_t* operand1, uint64_t operand2, uint64_t n,
+                   uint64_t modulus) {
+  if (on_device(result, operand1, nullptr))
+    check(hexl_amd_eltwise_add_mod_scalar(result, operand1, operand2, n, modulus, nullptr));
+  else
+    check(hexl_amd_eltwise_host(1, result, operand1, nullptr, operand2, n, modulus, 1, 1));
+}
+
+void EltwiseSubMod(uint64_t* result, const uint64_t* operand1, const uint64_t* operand2,
+                   uint64_t n, uint64_t modulus) {
+  if (on_device(result, operand1, operand2))
+    check(hexl_amd_eltwise_sub_mod(result, operand1, operand2, n, modulus, nullptr));
+  else
+    check(hexl_amd_eltwise_host(2, result, operand1, operand2, 0, n, modulus, 1, 1));
+}
+
+void EltwiseSubMod(uint64_t* result, const uint64_t* operand1, uint64_t operand2, uint64_t n,
+                   uint64_t modulus) {
+  if (on_device(result, operand1, nullptr))
+    check(hexl_amd_eltwise_sub_mod_scalar(result, operand1, operand2, n, modulus, nullptr));
+  else
+    check(hexl_amd_eltwise_host(3, result, operand1, nullptr, operand2, n, modulus, 1, 1));
+}
+
+void EltwiseMultMod(uint64_t* result, const uint64_t* operand1, const uint64_t* operand2,
+                    uint64_t n, uint64_t modulus, uint64_t input_mod_factor) {
+  if (on_device(result, operand1, operand2))
+    check(hexl_amd_eltwise_mult_mod(result, operand1, operand2, n, modulus, input_mod_factor,
+                                    nullptr));
+  else
+    check(hexl_amd_eltwise_host(4, result, operand1, operand2, 0, n, modulus, input_mod_factor,
+                                1));
+}
+
+void EltwiseFMAMod(uint64_t* result, const uint64_t* arg1, uint64_t arg2, const uint64_t* arg3,
+                   uint64_t n, uint64_t modulus, uint64_t input_mod_factor) {
+  if (on_device(result, arg1, arg3))
+    check(hexl_amd_eltwise_fma_mod(result, arg1, arg2, arg3, n, modulus, input_mod_factor,
+                                   nullptr));
+  else
+    check(hexl_amd_eltwise_host(5, result, arg1, arg3, arg2, n, modulus, input_mod_factor, 1));
+}
+
+void EltwiseReduceMod(uint64_t* result, const uint64_t* operand, uint64_t n, uint64_t modulus,
+                      uint64_t input_mod_factor, uint64_t output_mod_factor) {
+  if (on_device(result, operand, nullptr))
+    check(hexl_amd_eltwise_reduce_mod(result, operand, n, modulus, input_mod_factor,
+                                      output_mod_factor, nullptr));
+  else
+    check(hexl_amd_eltwise_host(6, result, operand, nullptr, 0, n, modulus, input_mod_factor,
+                                output_mod_factor));
+}
+
+}  // namespace hexl
+}  // namespace intel

@@ -1,0 +1,41 @@
+"""Batch sharding of independent (prime, polynomial) transforms over ranks.
+
+The hot path has no data dependence between polynomials, so multi-GPU is a pure
+partition of the flat unit index ``u = prime * polys_per_prime + poly`` into
+contiguous ranges, one per rank (the per-modulus loop of
+hexl/experimental/seal/key-switch-internal.cpp:52-90 is the in-tree caller with
+this shape).  No collective touches the data path; ``torch.distributed`` is used
+only for the barrier and the max-over-ranks timing of the benchmark.
+"""
+
+
+def shard_range(total_units, world_size, rank):
+    """Contiguous [begin, end) of the flat unit index owned by ``rank``."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    begin = rank * total_units // world_size
+    end = (rank + 1) * total_units // world_size
+    return begin, end
+
+
+def units_by_prime(begin, end, polys_per_prime):
+    """Split a unit range into [(prime_index, first_poly, count), ...]."""
+    out = []
+    u = begin
+    while u < end:
+        prime = u // polys_per_prime
+        first = u % polys_per_prime
+        count = min(end - u, polys_per_prime - first)
+        out.append((prime, first, count))
+        u += count
+    return out
+
+
+def max_over_ranks(seconds, dist=None, device=None):
+    """Elapsed time of the slowest rank (the whole job's time)."""
+    if dist is None or not dist.is_initialized():
+        return seconds
+    import torch
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,19 @@
+// hexl/hexl.hpp -- umbrella header of the MI355X-native HEXL hot path
+// (reference: hexl/include/hexl/hexl.hpp:6-26).  The experimental SEAL / FFT-like
+// / logging headers of the reference are outside this build's scope.
+#pragma once
+
+#include "hexl/eltwise/eltwise-add-mod.hpp"
+#include "hexl/eltwise/eltwise-fma-mod.hpp"
+#include "hexl/eltwise/eltwise-mult-mod.hpp"
+#include "hexl/eltwise/eltwise-reduce-mod.hpp"
+#include "hexl/eltwise/eltwise-sub-mod.hpp"
+#include "hexl/ntt/ntt.hpp"
+#include "hexl/number-theory/number-theory.hpp"
+#include "hexl/util/aligned-allocator.hpp"
+#include "hexl/util/allocator.hpp"
+#include "hexl/util/check.hpp"
+#include "hexl/util/compiler.hpp"
+#include "hexl/util/defines.hpp"
+#include "hexl/util/types.hpp"
+#include "hexl/util/util.hpp"

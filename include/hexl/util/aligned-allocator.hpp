@@ -1,0 +1,73 @@
+// hexl/util/aligned-allocator.hpp -- 64-byte aligned std::vector over a pluggable
+// AllocatorBase (reference: hexl/include/hexl/util/aligned-allocator.hpp:18-107).
+#pragma once
+#include <cstdint>
+#include <cstdlib>
+#include <memory>
+#include <vector>
+
+#include "hexl/util/allocator.hpp"
+#include "hexl/util/defines.hpp"
+
+namespace intel {
+namespace hexl {
+
+/// Default strategy: malloc / free.
+struct MallocStrategy : AllocatorBase {
+  void* allocate(size_t bytes_count) final { return std::malloc(bytes_count); }
+  void deallocate(void* p, size_t) final { std::free(p); }
+};
+
+using AllocatorStrategyPtr = std::shared_ptr<AllocatorBase>;
+extern AllocatorStrategyPtr mallocStrategy;
+
+/// std-compatible allocator returning Alignment-byte aligned storage carved out
+/// of blocks obtained from an AllocatorBase.  The pointer to the enclosing block
+/// is kept in the word just below the aligned address.
+template <typename T, uint64_t Alignment>
+class AlignedAllocator {
+ public:
+  template <typename, uint64_t>
+  friend class AlignedAllocator;
+  using value_type = T;
+
+  explicit AlignedAllocator(AllocatorStrategyPtr strategy = nullptr) noexcept
+      : m_strategy(strategy ? std::move(strategy) : mallocStrategy) {}
+  AlignedAllocator(const AlignedAllocator&) = default;
+  AlignedAllocator& operator=(const AlignedAllocator&) = default;
+  template <typename U>
+  AlignedAllocator(const AlignedAllocator<U, Alignment>& other) : m_strategy(other.m_strategy) {}
+
+  template <typename U>
+  struct rebind {
+    using other = AlignedAllocator<U, Alignment>;
+  };
+  bool operator==(const AlignedAllocator&) { return true; }
+  bool operator!=(const AlignedAllocator&) { return false; }
+
+  T* allocate(size_t n) {
+    static_assert((Alignment & (Alignment - 1)) == 0, "Alignment must be a power of two");
+    const size_t payload = sizeof(T) * n;
+    const size_t block = payload + Alignment + sizeof(void*);
+    char* raw = static_cast<char*>(m_strategy->allocate(block));
+    if (!raw) return nullptr;
+    uintptr_t addr = reinterpret_cast<uintptr_t>(raw + sizeof(void*));
+    addr = (addr + Alignment - 1) & ~static_cast<uintptr_t>(Alignment - 1);
+    reinterpret_cast<void**>(addr)[-1] = raw;
+    return reinterpret_cast<T*>(addr);
+  }
+
+  void deallocate(T* p, size_t n) {
+    if (!p) return;
+    m_strategy->deallocate(reinterpret_cast<void**>(p)[-1], n);
+  }
+
+ private:
+  AllocatorStrategyPtr m_strategy;
+};
+
+template <typename T>
+using AlignedVector64 = std::vector<T, AlignedAllocator<T, 64> >;
+
+}  // namespace hexl
+}  // namespace intel

@@ -52,6 +52,11 @@ const char* hexl_amd_last_error(void);
 /* Number of visible HIP devices (0 and HEXL_AMD_ERR_NO_DEVICE if none). */
 int hexl_amd_device_count(int* count);
 
+/* 1 if `p` points to device (or managed) memory of a visible HIP device, 0 for
+ * ordinary host memory.  Used by the intel::hexl shim to route a call either
+ * straight to the kernels or through the *_host staging entry points. */
+int hexl_amd_pointer_is_device(const void* p);
+
 /* ---------------------------------------------------------------------------
  * NTT plan == the state of one intel::hexl::NTT object
  * (hexl/include/hexl/ntt/ntt.hpp:22-293; ctors hexl/ntt/ntt-internal.cpp:24-52;

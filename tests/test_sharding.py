@@ -1,0 +1,76 @@
+"""Multi-rank path on CPU (gloo, world_size 2): the (prime, poly) units are
+partitioned over ranks with no data-path collective; every unit is transformed
+exactly once and the gathered result equals the single-process result.  The
+arithmetic is done by the oracle here (no GPU in this container); on the GPU
+box the same partition drives the HIP path (bench.py --gpus N)."""
+import os
+
+import numpy as np
+import pytest
+
+from hexl_amd.sharding import max_over_ranks, shard_range, units_by_prime
+
+N, POLYS, PRIMES_BITS = 256, 6, 30
+
+
+def test_shard_range_covers_exactly_once():
+    for total in (0, 1, 7, 8, 32768, 4096 * 3 + 5):
+        for world in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(world):
+                b, e = shard_range(total, world, r)
+                seen += list(range(b, e))
+            assert seen == list(range(total))
+    # BASELINE configs[3]: 8 primes x 4096 polys over 8 GPUs -> one prime per GPU
+    for g in range(8):
+        b, e = shard_range(8 * 4096, 8, g)
+        assert units_by_prime(b, e, 4096) == [(g, 0, 4096)]
+    # 2 GPUs -> four primes each
+    assert units_by_prime(*shard_range(8 * 4096, 2, 1), 4096) == [(k, 0, 4096) for k in (4, 5, 6, 7)]
+    assert units_by_prime(3, 9, 4) == [(0, 3, 1), (1, 0, 4), (2, 0, 1)]
+
+
+def _worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    from oracle import hexl_oracle as ho
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    primes = ho.generate_primes(3, PRIMES_BITS, True, N)
+    total = len(primes) * POLYS
+    b, e = shard_range(total, world, rank)
+    mine = []
+    for prime, first, count in units_by_prime(b, e, POLYS):
+        ntt = ho.NTT(N, primes[prime])
+        for p in range(first, first + count):
+            x = ho.fill_splitmix(N, 1000 * prime + p, primes[prime])
+            mine.append(ntt.forward(x, 1, 1))
+    mine = np.stack(mine) if mine else np.zeros((0, N), dtype=np.uint64)
+    # timing reduction used by bench.py: the job time is the slowest rank's
+    t = max_over_ranks(1.0 + rank, dist)
+    assert t == float(world)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (b, e, mine))
+    if rank == 0:
+        np.save(os.path.join(out_dir, "gathered.npy"), np.concatenate([g[2] for g in gathered]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_two_rank_gloo_partition_matches_single_process(tmp_path, world):
+    import torch.multiprocessing as mp
+
+    from oracle import hexl_oracle as ho
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(os.path.join(str(tmp_path), "gathered.npy"))
+    primes = ho.generate_primes(3, PRIMES_BITS, True, N)
+    ref = []
+    for k, q in enumerate(primes):
+        ntt = ho.NTT(N, q)
+        for p in range(POLYS):
+            ref.append(ntt.forward(ho.fill_splitmix(N, 1000 * k + p, q), 1, 1))
+    assert (got == np.stack(ref)).all()

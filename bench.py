@@ -163,6 +163,17 @@ def main():
     alg_bytes = 16.0 * N * batch  # this kernel reads and writes every polynomial once
     achieved = alg_bytes / (kern_avg[dominant] * 1e-3) / 1e9
 
+    # HBM bytes per launch of the dominant kernel from the committed PMC profile
+    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 read
+    # correction: profiles/r1_pmc_summary.md); null if the profile does not cover it
+    traffic = None
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")))
+        if batch == BATCH:
+            traffic = prof["by_bench_kernel_family"].get(dominant)
+    except (OSError, KeyError, ValueError):
+        pass
+
     if rank == 0:
         out = {
             "metric": "Fwd+Inv NTTs/sec, N=65536 q~55b batch=4096",
@@ -180,7 +191,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": dominant, "achieved": achieved,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_kernel_ms": kern_avg,
                 "note": ("per-kernel HIP-event timing on the launch stream inside the timed "

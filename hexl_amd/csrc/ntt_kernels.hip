@@ -267,7 +267,11 @@ __device__ __forceinline__ u64 gaddr(const TileGeom& g, u32 p) {
 }
 
 // Twiddles of round j for every sub-run this thread owns in that round.
-template <int S, int CB, int TL, int j>
+// Wave-uniform twiddles (gap >= 64) are fetched up front with scalar loads (no
+// VGPR cost).  Per-lane twiddles are fetched up front too unless HOIST is false:
+// the persistent kernel leaves them to the compiler's per-stage loads because the
+// registers are needed for the next tile's prefetch.
+template <int S, int CB, int TL, int j, bool HOIST = true>
 __device__ __forceinline__ void round_twiddles(ulonglong2* wv, const ulonglong2* __restrict__ tw,
                                                u32 tid, const TileGeom& g) {
   using RD = Rounds<S, CB>;
@@ -375,53 +379,85 @@ __device__ __forceinline__ void inv_mid_rounds(u64* x, u64* lds, const ulonglong
   }
 }
 
-// FWD:  global --(round 0)--> LDS --(rounds 1..)--> LDS --> coalesced store
-// INV:  coalesced load --> LDS --(rounds NR-1..1)--> LDS --(round 0)--> global
-template <bool FWD, int S, int CB, int TL, class A>
-__global__ void __launch_bounds__(1 << (TL - kRE), 8)
-tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* __restrict__ tw,
-          ModConst m, u32 log_n, u32 finish, u64 total, InvLast il) {
-  using RD = Rounds<S, CB>;
-  constexpr int NR = RD::NR;
-  constexpr int kTileLog = TL;
-  constexpr int kThreads = 1 << (TL - kRE);
-  __shared__ u64 lds[1 << TL];
-  const u32 tid = threadIdx.x;
+template <int S, int CB, int TL>
+__device__ __forceinline__ TileGeom make_geom(u32 tile, u32 log_n) {
   TileGeom g;
-  bool full_tile;
   if (CB == 0) {
-    g.base = (u64)blockIdx.x << kTileLog;
+    g.base = (u64)tile << TL;
     g.log_row = 0;
     g.a0 = log_n - S;
     g.tile_blk0 = (u32)((g.base & ((1ull << log_n) - 1)) >> S);
-    // whole tile inside the batch (always, except for the last tile of a batch
-    // smaller than 4096 elements): lets every guard below fold to a uniform branch
-    full_tile = g.base + (1u << kTileLog) <= total;
-  } else {  // all 2^S rows x 2^CB columns of one polynomial, N >= 4096
-    const u32 tpl = log_n - kTileLog;  // log2(tiles per polynomial)
-    const u64 poly = (u64)blockIdx.x >> tpl;
-    const u32 t = blockIdx.x & ((1u << tpl) - 1);
+  } else {  // all 2^S rows x 2^CB columns of one polynomial, N >= 2^TL
+    const u32 tpl = log_n - TL;  // log2(tiles per polynomial)
+    const u64 poly = (u64)tile >> tpl;
+    const u32 t = tile & ((1u << tpl) - 1);
     g.base = (poly << log_n) + ((u64)t << CB);
     g.log_row = log_n - S;
     g.a0 = 0;
     g.tile_blk0 = 0;
-    full_tile = true;
   }
+  return g;
+}
+
+// The 8 elements a thread fetches from global memory for a tile: forward = its
+// round-0 set, inverse = its slice of the run its wave owns in the deepest round.
+template <bool FWD, int S, int CB, int TL>
+__device__ __forceinline__ u32 fetch_index(u32 tid, int i) {
+  using RD = Rounds<S, CB>;
+  if (FWD) {
+    constexpr int r = RD::r(0), w = RD::w(0);
+    const int s = i >> r, e = i & ((1 << r) - 1);
+    return tile_index<r, w>(((u32)s << (TL - kRE)) + tid, e);
+  }
+  return ((tid >> 6) * kE + i) * 64 + (tid & 63);
+}
+
+// GUARD: the batch may end inside the tile (only possible for CB == 0 and a batch
+// smaller than / not a multiple of the tile); otherwise every access is in range.
+template <bool FWD, int S, int CB, int TL, bool GUARD>
+__device__ __forceinline__ void fetch_tile(u64* x, const u64* __restrict__ in, u32 tid,
+                                           const TileGeom& g, u64 total) {
+#pragma unroll
+  for (int i = 0; i < kE; ++i) {
+    const u32 p = fetch_index<FWD, S, CB, TL>(tid, i);
+    if (GUARD)
+      x[i] = (g.base + p < total) ? in[gaddr<CB>(g, p)] : 0;
+    else
+      x[i] = in[gaddr<CB>(g, p)];
+  }
+}
+
+// One workgroup per tile.  (A persistent variant -- each workgroup looping over
+// tiles with the next tile's loads prefetched into dead registers -- was built
+// and measured in round 1: it was 14 % SLOWER, because the four workgroups of a
+// CU then march in lockstep and the phase diversity that overlaps one
+// workgroup's memory waits with another's arithmetic is lost.  See DESIGN.md.)
+//
+// FWD:  global --(round 0)--> LDS --(rounds 1..)--> LDS --> coalesced store
+// INV:  coalesced load --> LDS --(rounds NR-1..1)--> LDS --(round 0)--> global
+// Occupancy target: 8 waves per SIMD (<= 64 VGPRs) for the shapes large transforms
+// use; the short bottom passes of small N (several sub-runs per thread in round
+// 0) would spill under that cap and get 6 (<= 80 VGPRs).
+template <int S, int CB>
+constexpr int min_waves() { return (S >= 10 || CB > 0) ? 8 : 6; }
+
+template <bool FWD, int S, int CB, int TL, bool GUARD, class A>
+__global__ void __launch_bounds__(1 << (TL - kRE), (min_waves<S, CB>()))
+tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* __restrict__ tw,
+          ModConst m, u32 log_n, u32 finish, u64 total, InvLast il) {
+  using RD = Rounds<S, CB>;
+  constexpr int NR = RD::NR;
+  __shared__ u64 lds[1 << TL];
+  const u32 tid = threadIdx.x;
+  const TileGeom g = make_geom<S, CB, TL>(blockIdx.x, log_n);
   u64 x[kE];
   HX_STAMP(0);
 
   if (FWD) {
     {  // round 0 straight from global memory; its twiddles are requested first
-      constexpr int r = RD::r(0), w = RD::w(0), SS = kE >> r;
       ulonglong2 wv[kE];
       round_twiddles<S, CB, TL, 0>(wv, tw, tid, g);
-#pragma unroll
-      for (int s = 0; s < SS; ++s)
-#pragma unroll
-        for (int e = 0; e < (1 << r); ++e) {
-          const u32 p = tile_index<r, w>(s * kThreads + tid, e);
-          x[(s << r) + e] = (full_tile || g.base + p < total) ? in[gaddr<CB>(g, p)] : 0;
-        }
+      fetch_tile<true, S, CB, TL, GUARD>(x, in, tid, g, total);
       HX_PROFILE_WAIT_VMEM();
       HX_STAMP(1);
       round_compute<S, CB, 0, A, true, false>(x, wv, m, il);
@@ -438,18 +474,16 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
       const u32 p = ((tid >> 6) * kE + i) * 64 + (tid & 63);
       u64 v = lds[lds_slot(p)];
       if (finish) v = fwd_finish<A>(v, m, finish == 2);
-      if (full_tile || g.base + p < total) out[gaddr<CB>(g, p)] = v;
+      if (!GUARD || g.base + p < total) out[gaddr<CB>(g, p)] = v;
     }
     HX_STAMP(8);
     HX_PROFILE_WAIT_VMEM();
     HX_STAMP(9);
   } else {
     // copy-in of the run this wave owns in the deepest round
+    fetch_tile<false, S, CB, TL, GUARD>(x, in, tid, g, total);
 #pragma unroll
-    for (int i = 0; i < kE; ++i) {
-      const u32 p = ((tid >> 6) * kE + i) * 64 + (tid & 63);
-      lds[lds_slot(p)] = (full_tile || g.base + p < total) ? in[gaddr<CB>(g, p)] : 0;
-    }
+    for (int i = 0; i < kE; ++i) lds[lds_slot(fetch_index<false, S, CB, TL>(tid, i))] = x[i];
     handover<RD::w(NR - 1), RD::r(NR - 1) == kRE>();
     inv_mid_rounds<S, CB, TL, NR - 1, A>(x, lds, tw, tid, g, m, il);
     {
@@ -465,10 +499,10 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
       for (int s = 0; s < SS; ++s)
 #pragma unroll
         for (int e = 0; e < (1 << r); ++e) {
-          const u32 p = tile_index<r, w>(s * kThreads + tid, e);
+          const u32 p = tile_index<r, w>(s * (1 << (TL - kRE)) + tid, e);
           u64 v = x[(s << r) + e];
           if (finish == 2) v = csub(v, m.q);
-          if (full_tile || g.base + p < total) out[gaddr<CB>(g, p)] = v;
+          if (!GUARD || g.base + p < total) out[gaddr<CB>(g, p)] = v;
         }
     }
   }
@@ -510,12 +544,21 @@ static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2
                                 const InvLast& il, hipStream_t st) {
   const u64 total = batch << log_n;
   const unsigned grid = (unsigned)((total + (1u << TL) - 1) >> TL);
+  const bool guard = (total & ((1u << TL) - 1)) != 0;  // the batch ends inside the last tile
   ScopedKernelTimer timer(FWD ? "ntt_fwd_tile_pass_bottom" : "ntt_inv_tile_pass_bottom", st);
 #define HX_LAUNCH_B(T)                                                                    \
   case T:                                                                                 \
     if constexpr (T <= TL && (TL == 10 || T >= 9))                                        \
-      hipLaunchKernelGGL((tile_pass<FWD, T, 0, TL, A>), dim3(grid), dim3(1 << (TL - kRE)), 0, \
-                         st, out, in, tw, m, log_n, finish, total, il);                   \
+    {                                                                                     \
+      if (guard)                                                                          \
+        hipLaunchKernelGGL((tile_pass<FWD, T, 0, TL, true, A>), dim3(grid),               \
+                           dim3(1 << (TL - kRE)), 0, st, out, in, tw, m, log_n, finish,   \
+                           total, il);                                                    \
+      else                                                                                \
+        hipLaunchKernelGGL((tile_pass<FWD, T, 0, TL, false, A>), dim3(grid),              \
+                           dim3(1 << (TL - kRE)), 0, st, out, in, tw, m, log_n, finish,   \
+                           total, il);                                                    \
+    }                                                                                     \
     else                                                                                  \
       return hipErrorInvalidValue;                                                        \
     break;
@@ -551,7 +594,7 @@ static hipError_t launch_top(int S, u64* out, const u64* in, const ulonglong2* t
 #define HX_LAUNCH_T(T)                                                                      \
   case T:                                                                                   \
     if constexpr (T <= TL - 4 && (TL == 10 || T == 8))                                      \
-      hipLaunchKernelGGL((tile_pass<FWD, T, TL - T, TL, A>), dim3(grid),                    \
+      hipLaunchKernelGGL((tile_pass<FWD, T, TL - T, TL, false, A>), dim3(grid),             \
                          dim3(1 << (TL - kRE)), 0, st, out, in, tw, m, log_n, finish, total, \
                          il);                                                               \
     else                                                                                    \

@@ -23,7 +23,8 @@ except ImportError:  # pure ctypes use without torch: the system ROCm runtime
     _torch_first = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "lib", "libhexl_amd.so")
+# HEXL_AMD_LIB: developer override to A/B an experimental build of the same C-ABI
+_LIB_PATH = os.environ.get("HEXL_AMD_LIB") or os.path.join(_HERE, "lib", "libhexl_amd.so")
 
 __all__ = [
     "NTT", "EltwiseAddMod", "EltwiseSubMod", "EltwiseMultMod", "EltwiseFMAMod",
@@ -238,7 +239,7 @@ class NTT:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and lib is not None:  # `lib` is already gone at interpreter shutdown
             lib.hexl_amd_ntt_destroy(h)
 
     @staticmethod

@@ -212,7 +212,10 @@ strided_pass(u64* __restrict__ out, const u64* __restrict__ in,
 // (8 KiB of LDS, 128 threads = 2 waves, 16 workgroups per CU) for N <= 2^16, 12 ->
 // 4096 elements (32 KiB, 512 threads, 4 workgroups per CU) for larger N.  Either
 // way a thread holds 8 elements, a round is 3 stages, and 32 waves fit a CU.
-constexpr int kRE = 3;  // 8 elements per thread
+#ifndef HEXL_AMD_RE
+#define HEXL_AMD_RE 3
+#endif
+constexpr int kRE = HEXL_AMD_RE;  // log2 elements per thread (3: the shipped geometry)
 constexpr int kE = 1 << kRE;
 constexpr int kMaxTileLog = 12;
 
@@ -343,6 +346,14 @@ __device__ __forceinline__ void handover() {
   }
 }
 
+// Experiment switch: after the last forward round a thread holds 8 consecutive
+// coefficients (64 bytes); store them directly (4 x 16 B per lane, 64-byte lane
+// stride) instead of transposing through LDS for fully coalesced stores.
+#ifndef HEXL_AMD_DIRECT_OUT
+#define HEXL_AMD_DIRECT_OUT 0
+#endif
+constexpr bool kDirectOut = HEXL_AMD_DIRECT_OUT != 0;
+
 // forward rounds J .. NR-1: LDS -> registers -> subtree -> same LDS slots
 template <int S, int CB, int TL, int J, class A>
 __device__ __forceinline__ void fwd_mid_rounds(u64* x, u64* lds, const ulonglong2* tw, u32 tid,
@@ -354,6 +365,9 @@ __device__ __forceinline__ void fwd_mid_rounds(u64* x, u64* lds, const ulonglong
     round_twiddles<S, CB, TL, J>(wv, tw, tid, g);
     lds_load_round<S, CB, TL, J>(x, lds, tid);
     round_compute<S, CB, J, A, true, false>(x, wv, m, il);
+    if constexpr (kDirectOut && J == RD::NR - 1 && CB == 0 && RD::r(J) == kRE) {
+      return;  // the caller stores the 8 contiguous results straight from registers
+    }
     lds_store_round<S, CB, TL, J>(x, lds, tid);
     handover<RD::w(J), RD::r(J) == kRE>();
     HX_STAMP(3 + J);
@@ -467,6 +481,23 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
       HX_STAMP(3);
     }
     fwd_mid_rounds<S, CB, TL, 1, A>(x, lds, tw, tid, g, m, il);
+    if constexpr (kDirectOut && NR > 1 && CB == 0) {
+      u64* dst = out + g.base + (u64)tid * kE;
+#pragma unroll
+      for (int e = 0; e < kE; ++e)
+        if (finish) x[e] = fwd_finish<A>(x[e], m, finish == 2);
+      if (!GUARD || g.base + (u64)tid * kE < total) {
+        if ((reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+#pragma unroll
+          for (int e = 0; e < kE; e += 2)
+            *reinterpret_cast<ulonglong2*>(dst + e) = make_ulonglong2(x[e], x[e + 1]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < kE; ++e) dst[e] = x[e];
+        }
+      }
+      return;
+    }
     // copy-out of the run this wave owns after the last round (w = CB <= 6):
     // 512 tile-contiguous elements, 64 per access; final reduction fused
 #pragma unroll
@@ -649,7 +680,14 @@ static Plan make_plan(int L) {
   if (plan_strided_requested() && L >= 13) {
     p.tl = 12;
     p.bottom = 12;
-    int top = L - 12;
+    // experiment knob: HEXL_AMD_BOTTOM=9..12 stages for the bottom tile_pass
+    static const int bottom_override = [] {
+      const char* e = getenv("HEXL_AMD_BOTTOM");
+      return e ? atoi(e) : 0;
+    }();
+    if (bottom_override >= 9 && bottom_override <= 12 && L - bottom_override >= 1)
+      p.bottom = bottom_override;
+    int top = L - p.bottom;
     if (top <= 5) {
       p.strided[p.n_strided++] = top;
     } else {

@@ -286,7 +286,9 @@ __device__ __forceinline__ void round_twiddles(ulonglong2* wv, const ulonglong2*
     // sub-block-and-group index of the run: the bits of vt above the gap, minus
     // the column bits (which do not select a twiddle)
     u32 node = level + (((g.tile_blk0 << u) + vt_high<w, TL>(s, tid)) & (level - 1));
+#ifndef HX_EXP_NO_SCALAR_TW  // developer experiment: per-lane loads for every twiddle
     if (w >= 6) node = __builtin_amdgcn_readfirstlane(node);  // uniform across the wave
+#endif
     load_twiddles<r>(wv + (s << r), tw, node);
   }
 }
@@ -296,6 +298,10 @@ __device__ __forceinline__ void round_compute(u64* x, const ulonglong2* wv, cons
                                               const InvLast& il) {
   constexpr int r = Rounds<S, CB>::r(j);
   constexpr int SS = kE >> r;
+#ifdef HX_EXP_NOCOMPUTE  // developer experiment: data movement only
+  x[0] += wv[1].x;
+  return;
+#endif
 #pragma unroll
   for (int s = 0; s < SS; ++s) {
     if (FWD)
@@ -434,10 +440,14 @@ __device__ __forceinline__ void fetch_tile(u64* x, const u64* __restrict__ in, u
 #pragma unroll
   for (int i = 0; i < kE; ++i) {
     const u32 p = fetch_index<FWD, S, CB, TL>(tid, i);
+#ifdef HX_EXP_NOMEM  // developer experiment: no global traffic
+    x[i] = (u64)p * 0x9E3779B97F4A7C15ULL >> 10;
+#else
     if (GUARD)
       x[i] = (g.base + p < total) ? in[gaddr<CB>(g, p)] : 0;
     else
       x[i] = in[gaddr<CB>(g, p)];
+#endif
   }
 }
 
@@ -449,6 +459,9 @@ __device__ __forceinline__ void fetch_tile(u64* x, const u64* __restrict__ in, u
 //
 // FWD:  global --(round 0)--> LDS --(rounds 1..)--> LDS --> coalesced store
 // INV:  coalesced load --> LDS --(rounds NR-1..1)--> LDS --(round 0)--> global
+constexpr u32 kCUs = 256;                        // MI355X
+constexpr u32 kFirstWave = kCUs * 4;             // workgroups resident at launch (TL = 12)
+
 // Occupancy target: 8 waves per SIMD (<= 64 VGPRs) for the shapes large transforms
 // use; the short bottom passes of small N (several sub-runs per thread in round
 // 0) would spill under that cap and get 6 (<= 80 VGPRs).
@@ -458,11 +471,24 @@ constexpr int min_waves() { return (S >= 10 || CB > 0) ? 8 : 6; }
 template <bool FWD, int S, int CB, int TL, bool GUARD, class A>
 __global__ void __launch_bounds__(1 << (TL - kRE), (min_waves<S, CB>()))
 tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* __restrict__ tw,
-          ModConst m, u32 log_n, u32 finish, u64 total, InvLast il) {
+          ModConst m, u32 log_n, u32 finish, u64 total, u32 stagger, InvLast il) {
   using RD = Rounds<S, CB>;
   constexpr int NR = RD::NR;
   __shared__ u64 lds[1 << TL];
   const u32 tid = threadIdx.x;
+  // De-phasing of the first generation of workgroups.  All workgroups of a CU
+  // start together and take the same time, so without this they stay in lockstep
+  // for the whole launch (all loading, then all computing, ...) and memory time
+  // and arithmetic time add instead of overlapping.  The k-th workgroup a CU
+  // receives at launch sleeps k * stagger * ~8k cycles once; later generations
+  // inherit the offset because a slot is refilled when its workgroup retires.
+  if (stagger) {
+    const u32 resident = gridDim.x < kFirstWave ? gridDim.x : kFirstWave;
+    if (blockIdx.x < resident) {
+      const u32 k = (blockIdx.x / kCUs) % (kFirstWave / kCUs);
+      for (u32 i = 0; i < k * stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+  }
   const TileGeom g = make_geom<S, CB, TL>(blockIdx.x, log_n);
   u64 x[kE];
   HX_STAMP(0);
@@ -505,7 +531,11 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
       const u32 p = ((tid >> 6) * kE + i) * 64 + (tid & 63);
       u64 v = lds[lds_slot(p)];
       if (finish) v = fwd_finish<A>(v, m, finish == 2);
+#ifdef HX_EXP_NOMEM
+      if (v == 0x123456789ULL) out[gaddr<CB>(g, p)] = v;  // keeps the value live, ~never stores
+#else
       if (!GUARD || g.base + p < total) out[gaddr<CB>(g, p)] = v;
+#endif
     }
     HX_STAMP(8);
     HX_PROFILE_WAIT_VMEM();
@@ -533,7 +563,11 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
           const u32 p = tile_index<r, w>(s * (1 << (TL - kRE)) + tid, e);
           u64 v = x[(s << r) + e];
           if (finish == 2) v = csub(v, m.q);
+#ifdef HX_EXP_NOMEM
+          if (v == 0x123456789ULL) out[gaddr<CB>(g, p)] = v;
+#else
           if (!GUARD || g.base + p < total) out[gaddr<CB>(g, p)] = v;
+#endif
         }
     }
   }
@@ -568,6 +602,14 @@ static hipError_t launch_strided(int R, u64* out, const u64* in, const ulonglong
   return hipGetLastError();
 }
 
+static u32 stagger_setting() {
+  static const u32 v = [] {
+    const char* e = getenv("HEXL_AMD_STAGGER");
+    return e ? (u32)atoi(e) : 0u;
+  }();
+  return v;
+}
+
 // Bottom pass: S stages on contiguous sub-blocks (CB = 0), tile of 2^TL elements.
 template <bool FWD, int TL, class A>
 static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2* tw,
@@ -579,16 +621,16 @@ static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2
   ScopedKernelTimer timer(FWD ? "ntt_fwd_tile_pass_bottom" : "ntt_inv_tile_pass_bottom", st);
 #define HX_LAUNCH_B(T)                                                                    \
   case T:                                                                                 \
-    if constexpr (T <= TL && (TL == 10 || T >= 9))                                        \
+    if constexpr (T <= TL && (TL <= 10 || T >= 9))                                        \
     {                                                                                     \
       if (guard)                                                                          \
         hipLaunchKernelGGL((tile_pass<FWD, T, 0, TL, true, A>), dim3(grid),               \
                            dim3(1 << (TL - kRE)), 0, st, out, in, tw, m, log_n, finish,   \
-                           total, il);                                                    \
+                           total, stagger_setting(), il);                                 \
       else                                                                                \
         hipLaunchKernelGGL((tile_pass<FWD, T, 0, TL, false, A>), dim3(grid),              \
                            dim3(1 << (TL - kRE)), 0, st, out, in, tw, m, log_n, finish,   \
-                           total, il);                                                    \
+                           total, stagger_setting(), il);                                 \
     }                                                                                     \
     else                                                                                  \
       return hipErrorInvalidValue;                                                        \
@@ -624,10 +666,10 @@ static hipError_t launch_top(int S, u64* out, const u64* in, const ulonglong2* t
   ScopedKernelTimer timer(FWD ? "ntt_fwd_tile_pass_top" : "ntt_inv_tile_pass_top", st);
 #define HX_LAUNCH_T(T)                                                                      \
   case T:                                                                                   \
-    if constexpr (T <= TL - 4 && (TL == 10 || T == 8))                                      \
+    if constexpr (T <= TL - 4 && (TL == 10 || T >= 7))                                      \
       hipLaunchKernelGGL((tile_pass<FWD, T, TL - T, TL, false, A>), dim3(grid),             \
                          dim3(1 << (TL - kRE)), 0, st, out, in, tw, m, log_n, finish, total, \
-                         il);                                                               \
+                         stagger_setting(), il);                                            \
     else                                                                                    \
       return hipErrorInvalidValue;                                                          \
     break;
@@ -651,7 +693,8 @@ static hipError_t launch_top(int S, u64* out, const u64* in, const ulonglong2* t
 // `n_strided` register-only passes), then a bottom tile_pass of `bottom` stages;
 // `tl` = log2 of the tile size both tile passes use.
 struct Plan {
-  int tl;
+  int tl;      // tile size (log2) of the bottom pass
+  int tl_top;  // tile size of the top tile pass (0: same as tl)
   int top_tile;
   int n_strided;
   int strided[8];
@@ -675,6 +718,19 @@ static Plan make_plan(int L) {
   if (L <= 12) {  // one kernel, one HBM round trip
     p.tl = L <= 10 ? 10 : 12;
     p.bottom = L;
+    return p;
+  }
+  static const bool wave9 = [] {
+    const char* e = getenv("HEXL_AMD_PLAN");
+    return e && strcmp(e, "wave9") == 0;
+  }();
+  if (wave9 && L >= 16 && L <= 17) {
+    // experiment: 7/8-stage top on 4096-element tiles + 9-stage bottom on
+    // 512-element tiles (one wave per tile: no workgroup barrier at all)
+    p.tl = 9;
+    p.tl_top = 12;
+    p.bottom = 9;
+    p.top_tile = L - 9;
     return p;
   }
   if (plan_strided_requested() && L >= 13) {
@@ -711,6 +767,23 @@ static Plan make_plan(int L) {
   return p;
 }
 
+template <bool FWD, class A>
+static hipError_t launch_top_tl(int tl, int S, u64* out, const u64* in, const ulonglong2* tw,
+                                const ModConst& m, u32 log_n, u32 finish, u64 batch,
+                                const InvLast& il, hipStream_t st) {
+  if (tl == 10) return launch_top<FWD, 10, A>(S, out, in, tw, m, log_n, finish, batch, il, st);
+  return launch_top<FWD, 12, A>(S, out, in, tw, m, log_n, finish, batch, il, st);
+}
+
+template <bool FWD, class A>
+static hipError_t launch_bottom_tl(int tl, int S, u64* out, const u64* in, const ulonglong2* tw,
+                                   const ModConst& m, u32 log_n, u32 finish, u64 batch,
+                                   const InvLast& il, hipStream_t st) {
+  if (tl == 9) return launch_bottom<FWD, 9, A>(S, out, in, tw, m, log_n, finish, batch, il, st);
+  if (tl == 10) return launch_bottom<FWD, 10, A>(S, out, in, tw, m, log_n, finish, batch, il, st);
+  return launch_bottom<FWD, 12, A>(S, out, in, tw, m, log_n, finish, batch, il, st);
+}
+
 template <class A>
 static hipError_t forward_impl(const NttTables& t, u64* result, const u64* operand, u64 batch,
                                u64 out_mf, hipStream_t st) {
@@ -719,10 +792,8 @@ static hipError_t forward_impl(const NttTables& t, u64* result, const u64* opera
   InvLast il{};
   hipError_t e;
   if (p.top_tile) {
-    e = p.tl == 10 ? launch_top<true, 10, A>(p.top_tile, result, src, t.fwd, t.mod, t.log_n, 0,
-                                             batch, il, st)
-                   : launch_top<true, 12, A>(p.top_tile, result, src, t.fwd, t.mod, t.log_n, 0,
-                                             batch, il, st);
+    e = launch_top_tl<true, A>(p.tl_top ? p.tl_top : p.tl, p.top_tile, result, src, t.fwd, t.mod,
+                               t.log_n, 0, batch, il, st);
     if (e != hipSuccess) return e;
     src = result;
   }
@@ -735,10 +806,8 @@ static hipError_t forward_impl(const NttTables& t, u64* result, const u64* opera
     src = result;
   }
   const u32 fin = out_mf == 1 ? 2 : 1;
-  return p.tl == 10 ? launch_bottom<true, 10, A>(p.bottom, result, src, t.fwd, t.mod, t.log_n,
-                                                 fin, batch, il, st)
-                    : launch_bottom<true, 12, A>(p.bottom, result, src, t.fwd, t.mod, t.log_n,
-                                                 fin, batch, il, st);
+  return launch_bottom_tl<true, A>(p.tl, p.bottom, result, src, t.fwd, t.mod, t.log_n, fin, batch,
+                                   il, st);
 }
 
 template <class A>
@@ -747,11 +816,8 @@ static hipError_t inverse_impl(const NttTables& t, u64* result, const u64* opera
   const Plan p = make_plan((int)t.log_n);
   const u32 fin = out_mf == 1 ? 2 : 1;
   const bool only = !p.top_tile && p.n_strided == 0;
-  hipError_t e =
-      p.tl == 10 ? launch_bottom<false, 10, A>(p.bottom, result, operand, t.inv, t.mod, t.log_n,
-                                               only ? fin : 0, batch, t.inv_last, st)
-                 : launch_bottom<false, 12, A>(p.bottom, result, operand, t.inv, t.mod, t.log_n,
-                                               only ? fin : 0, batch, t.inv_last, st);
+  hipError_t e = launch_bottom_tl<false, A>(p.tl, p.bottom, result, operand, t.inv, t.mod, t.log_n,
+                                            only ? fin : 0, batch, t.inv_last, st);
   if (e != hipSuccess) return e;
   u32 a0 = t.log_n - (u32)p.bottom;
   for (int i = p.n_strided - 1; i >= 0; --i) {
@@ -761,10 +827,8 @@ static hipError_t inverse_impl(const NttTables& t, u64* result, const u64* opera
     if (e != hipSuccess) return e;
   }
   if (p.top_tile)
-    return p.tl == 10 ? launch_top<false, 10, A>(p.top_tile, result, result, t.inv, t.mod,
-                                                 t.log_n, fin, batch, t.inv_last, st)
-                      : launch_top<false, 12, A>(p.top_tile, result, result, t.inv, t.mod,
-                                                 t.log_n, fin, batch, t.inv_last, st);
+    return launch_top_tl<false, A>(p.tl_top ? p.tl_top : p.tl, p.top_tile, result, result, t.inv,
+                                   t.mod, t.log_n, fin, batch, t.inv_last, st);
   return hipSuccess;
 }
 

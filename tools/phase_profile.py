@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-lib = C.CDLL(os.path.join(HERE, "libhexl_amd_phaseprof.so"))
+lib = C.CDLL(os.environ.get("PHASE_LIB") or os.path.join(HERE, "libhexl_amd_phaseprof.so"))
 vp, u64 = C.c_void_p, C.c_uint64
 lib.hexl_amd_ntt_create.argtypes = [C.POINTER(vp), u64, u64, u64, C.c_int]
 lib.hexl_amd_ntt_forward.argtypes = [vp, vp, vp, u64, u64, u64, vp]
@@ -25,7 +25,7 @@ Q = 18014398510661633
 plan = vp()
 assert lib.hexl_amd_ntt_create(C.byref(plan), N, Q, 0, 0) == 0, lib.hexl_amd_last_error()
 data = torch.randint(0, Q, (BATCH, N), dtype=torch.int64, device="cuda")
-blocks = BATCH * N // 1024
+blocks = BATCH * N // 4096
 stamps = torch.zeros((blocks, 8, 16), dtype=torch.int64, device="cuda")
 for it in range(3):
     stamps.zero_()

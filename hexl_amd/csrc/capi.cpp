@@ -222,10 +222,7 @@ int hexl_amd_ntt_create(hexl_amd_ntt** out, uint64_t degree, uint64_t modulus,
   }
   p->t.fwd = p->d_fwd;
   p->t.inv = p->d_inv;
-  p->t.mod.q = q;
-  p->t.mod.two_q = q << 1;
-  p->t.mod.neg_q = 0 - q;
-  p->t.mod.barrett = nt::multiply_factor(1, 64, q);
+  p->t.mod = make_mod_const(q);
   p->t.log_n = p->log_n;
   p->t.inv_last = il;
   *out = p;

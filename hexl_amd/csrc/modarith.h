@@ -1,7 +1,10 @@
 // modarith.h -- word-sized modular arithmetic for gfx950 device code.
-// Integer VALU only.  Measured issue cost on MI355X (tools/ubench.hip):
-// v_mad_u64_u32 / v_mul_lo_u32 / v_mul_hi_u32 and every 64-bit add/compare
-// ~4 cycles per wave, 32-bit add/cndmask/v_mad_u32_u24 ~2.
+// Integer VALU only.  Measured issue rate on MI355X (tools/ubench.hip, wall
+// clock): a SIMD retires one simple wave64 VALU instruction (32-bit add, shift,
+// cndmask, v_lshl_add_u64) per ~3 cycles and one multiply-class instruction
+// (v_mad_u64_u32, v_mul_lo/hi_u32, v_mad_u32_u24) per ~5 cycles, and two waves
+// per SIMD already saturate it.  The NTT kernels are bound by this rate, so the
+// butterflies below are written for minimum instruction count.
 //
 // Semantics follow the reference's scalar primitives
 // (hexl/include/hexl/number-theory/number-theory.hpp:127-141 MultiplyModLazy,
@@ -10,17 +13,18 @@
 //
 //   Strict (any q < 2^62): the reference's invariants -- forward values in
 //     [0,4q) with one conditional subtraction per butterfly, inverse values in
-//     [0,2q).
-//   Lazy (q < 2^56): the 64-bit word has >= 8 spare bits, so the forward
-//     network never subtracts conditionally (values grow by at most 2q per
-//     stage: < (4 + 2 log2 N) q < 2^62) and is reduced once at the end with a
-//     single-word Barrett step; the inverse network skips the conditional
-//     subtractions inside each register subtree (growth 2x per stage, at most
-//     32q) and restores [0,2q) at subtree exit.  Because every multiplicand
-//     is below 2^62 the Shoup factor is kept with 63 fractional bits and the
-//     product is written as a chain of v_mad_u64_u32 that cannot overflow
-//     (mul_lazy63): 10 multiplies and ~9 other VALU per butterfly instead of
-//     ~37 instructions.
+//     [0,2q); 64-bit Shoup factors; ~37 instructions per butterfly.
+//   Lazy (q < 2^56): the 64-bit word has >= 8 spare bits.  Values are kept
+//     DOUBLED (D = 2x) between the first load and the last store of a
+//     transform, Shoup factors carry 63 fractional bits, and the quotient
+//     estimate drops the lowest partial product, so a lazy product is
+//     T2 = D*W - Q*2q in [0,6q) (= 2 * (x*W mod q + {0,1,2}q)) from 9 chained
+//     v_mad_u64_u32 and 2 moves.  The forward network never subtracts
+//     conditionally (doubled values grow by at most 6q per stage: at most
+//     (8 + 6*17) q < 2^63) and is reduced once at the end; the inverse network
+//     skips the conditional subtractions inside each register subtree and
+//     restores [0,8q) at subtree exit.  14 (forward) / 15 (inverse)
+//     instructions per butterfly.
 // Both produce the same canonical outputs; lazy outputs stay inside the
 // reference's ranges ([0,4q) forward, [0,2q) inverse).
 #pragma once
@@ -58,119 +62,177 @@ HX_HD u64 mul_lazy(u64 x, u64 W, u64 Wp, u64 q) {
   return x * W - Q * q;
 }
 
-// Per-modulus constants every kernel receives.
+// Per-modulus constants every kernel receives (host: make_mod_const).
 struct ModConst {
   u64 q;
   u64 two_q;
-  u64 neg_q;    // 2^64 - q
-  u64 barrett;  // floor(2^64 / q): single-word Barrett factor (lazy policy only)
+  // Lazy policy only:
+  u64 neg_two_q;  // 2^64 - 2q
+  u64 six_q;
+  u32 fin_mul;    // floor(2^(31 + fin_shift) / q)
+  u32 fin_shift;  // floor(log2 q)
 };
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+inline ModConst make_mod_const(u64 q) {
+  ModConst m;
+  m.q = q;
+  m.two_q = q << 1;
+  m.neg_two_q = 0 - (q << 1);
+  m.six_q = 6 * q;  // only meaningful (and only read) for q < 2^56
+  u32 b = 0;
+  while (b < 63 && (q >> (b + 1)) != 0) ++b;
+  m.fin_shift = b;
+  m.fin_mul = (u32)((((unsigned __int128)1) << (31 + b)) / q);
+  return m;
+}
+#endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define HX_OPAQUE(v) asm("" : "+v"(v))
+HX_HD u32 mul_hi32(u32 a, u32 b) { return __umulhi(a, b); }
 #else
 #define HX_OPAQUE(v) (void)0
+HX_HD u32 mul_hi32(u32 a, u32 b) { return (u32)(((u64)a * b) >> 32); }
 #endif
 
-// Lazy-policy product for x < 2^62: W63 = floor(W * 2^63 / q) and
-// Q = floor(2x * W63 / 2^64); x*W - Q*q lies in [0, 2q).  With 2x < 2^63 and
-// W63 < 2^63 the middle column a1*b0 + a0*b1 + hi(a0*b0) stays below 2^64, so
-// it is two chained v_mad_u64_u32 without carry handling.  The low 64 bits of
-// x*W + Q*(-q) are two more chained mads for bits 0..63 of the low products and
-// a four-mad chain whose low word is the sum of the cross terms.  HX_OPAQUE
-// keeps the compiler from narrowing that chain to v_mul_lo_u32 + adds.
-HX_HD u64 mul_lazy63(u64 x, u64 W, u64 W63, u64 neg_q) {
-  const u64 x2 = x << 1;
-  const u32 a0 = (u32)x2, a1 = (u32)(x2 >> 32);
+// Lazy-policy product on doubled values.  D = 2x < 2^63, W < q < 2^56,
+// W63 = floor(W * 2^63 / q).  Returns  acc + T2  (mod 2^64) where
+//   T2 = D*W - Q*2q,   Q ~ floor(D * W63 / 2^64).
+// With the exact quotient T2 = 2*(x*W - floor(x*W63/2^63)*q) lies in [0,4q)
+// (x*W63/2^63 underestimates x*W/q by less than x/2^63 < 1/2).  EXACT == false
+// leaves the partial product lo(D)*lo(W63) out of the quotient, which lowers Q by
+// at most one more: T2 in [0,6q).  The middle column a1*b0 + a0*b1 (+ hi(a0*b0))
+// stays below 2^64 because both factors are below 2^63, so the quotient is three
+// chained v_mad_u64_u32; the low 64 bits of D*W + Q*(-2q) are two chained mads
+// for the low x low products (seeded with `acc`, which makes the butterfly's
+// addition free) and a four-mad chain whose low word is the sum of the cross
+// terms.  HX_OPAQUE keeps the compiler from narrowing that chain to v_mul_lo_u32
+// + adds.
+template <bool EXACT>
+HX_HD u64 mul_add_lazy2(u64 acc, u64 D, u64 W, u64 W63, u64 neg_two_q) {
+  const u32 a0 = (u32)D, a1 = (u32)(D >> 32);
   const u32 b0 = (u32)W63, b1 = (u32)(W63 >> 32);
-#if defined(__HIP_DEVICE_COMPILE__)
-  const u32 m = __umulhi(a0, b0);
-#else
-  const u32 m = (u32)(((u64)a0 * b0) >> 32);
-#endif
-  u64 S = (u64)a1 * b0 + m;
+  u64 S = (u64)a1 * b0 + (EXACT ? mul_hi32(a0, b0) : 0u);
   S = (u64)a0 * b1 + S;
   const u64 Q = (u64)a1 * b1 + (S >> 32);
-  const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
   const u32 w0 = (u32)W, w1 = (u32)(W >> 32);
   const u32 q0 = (u32)Q, q1 = (u32)(Q >> 32);
-  const u32 n0 = (u32)neg_q, n1 = (u32)(neg_q >> 32);
-  u64 lo = (u64)x0 * w0;
+  const u32 n0 = (u32)neg_two_q, n1 = (u32)(neg_two_q >> 32);
+  u64 lo = (u64)a0 * w0 + acc;
   lo = (u64)q0 * n0 + lo;
-  u64 c = (u64)x0 * w1;
+  u64 c = (u64)a0 * w1;
   HX_OPAQUE(c);
-  c = (u64)x1 * w0 + c;
+  c = (u64)a1 * w0 + c;
   HX_OPAQUE(c);
   c = (u64)q0 * n1 + c;
   HX_OPAQUE(c);
   c = (u64)q1 * n0 + c;
   HX_OPAQUE(c);
-  return lo + ((u64)(u32)c << 32);
+  u32 hi = (u32)(lo >> 32) + (u32)c;
+  HX_OPAQUE(hi);  // one v_add_u32, not a 64-bit add of a shifted pair
+  return ((u64)hi << 32) | (u32)lo;
 }
 
-struct Strict {  // any q < 2^62; tables hold floor(W * 2^64 / q)
+struct Strict {  // any q < 2^62; tables hold floor(W * 2^64 / q); plain values
   static constexpr bool kLazy = false;
-  static HX_HD u64 mul(u64 x, u64 W, u64 Wp, const ModConst& m) {
-    return mul_lazy(x, W, Wp, m.q);
-  }
 };
-struct Lazy {  // q < 2^56; tables hold floor(W * 2^63 / q); multiplicands < 2^62
+struct Lazy {  // q < 2^56; tables hold floor(W * 2^63 / q); doubled values
   static constexpr bool kLazy = true;
-  static HX_HD u64 mul(u64 x, u64 W, u64 Wp, const ModConst& m) {
-    return mul_lazy63(x, W, Wp, m.neg_q);
-  }
 };
 
+// Value as held inside a transform <-> value in the caller's buffer.
+template <class A>
+HX_HD u64 to_internal(u64 x) { return A::kLazy ? x << 1 : x; }
+
 // Forward (Cooley-Tukey) Harvey butterfly.
-// Strict: x,y in [0,4q) -> [0,4q).  Lazy: x < B*q -> x', y' < (B+2)*q.
+// Strict: x,y in [0,4q) -> [0,4q).
+// Lazy (doubled): x, y < B*q -> x', y' < (B+6)*q;  y' = 2x + 6q - x'.
 template <class A>
 HX_HD void fwd_butterfly(u64& x, u64& y, u64 W, u64 Wp, const ModConst& m) {
-  const u64 tx = A::kLazy ? x : csub(x, m.two_q);
-  const u64 T = A::mul(y, W, Wp, m);
-  x = tx + T;
-  y = tx + m.two_q - T;
+  if (A::kLazy) {
+    const u64 xs = mul_add_lazy2<false>(x, y, W, Wp, m.neg_two_q);
+    y = (x << 1) + m.six_q - xs;
+    x = xs;
+  } else {
+    const u64 tx = csub(x, m.two_q);
+    const u64 T = mul_lazy(y, W, Wp, m.q);
+    x = tx + T;
+    y = tx + m.two_q - T;
+  }
 }
 
 // End of the forward network: bring a value to [0,q) (canonical) or leave it in
 // the reference's lazy range [0,4q).
+// Lazy: D = 2x < 2^(b+8) with b = floor(log2 q) (x < 55q); the quotient x/q fits
+// in 7 bits, so it is estimated from the top 8 bits of x with one 32-bit
+// multiply: Qe = hi32((D >> b) * floor(2^(31+b)/q)) is floor(x/q) or one less,
+// r2 = D - Qe*2q in [0,4q).
 template <class A>
 HX_HD u64 fwd_finish(u64 x, const ModConst& m, bool canonical) {
   if (A::kLazy) {
-    x = x - mul_hi64(x, m.barrett) * m.q;  // [0, 2q), BarrettReduce64<2>
-    return canonical ? csub(x, m.q) : x;
+    const u32 qe = mul_hi32((u32)(x >> m.fin_shift), m.fin_mul);
+    u64 r2 = x + (u64)qe * m.neg_two_q;
+    if (canonical) r2 = csub(r2, m.two_q);
+    return r2 >> 1;
   }
   return canonical ? csub(csub(x, m.two_q), m.q) : x;
 }
 
-// Inverse (Gentleman-Sande) Harvey butterfly at depth `k` of a register
-// subtree (k = 0 for the first stage the subtree runs).
-// Strict: x,y in [0,2q) -> [0,2q).  Lazy: x,y < 2q*2^k -> x' < 2q*2^(k+1),
-// y' in [0,2q); the offset added before subtracting y is 2q*2^k.
-template <class A>
+// Inverse (Gentleman-Sande) Harvey butterfly at depth `k` of a lazy run (k = 0
+// for the first stage after values were last bounded).
+// Strict: x,y in [0,2q) -> [0,2q).
+// Lazy (doubled): x,y < 8q*2^k -> x' < 8q*2^(k+1), y' in [0,6q); the offset added
+// before subtracting y is 8q*2^k.  BOUND restores x' < 8q (k must be 0).
+template <class A, bool BOUND = false>
 HX_HD void inv_butterfly(u64& x, u64& y, u64 W, u64 Wp, const ModConst& m, int k) {
   const u64 s = x + y;
-  const u64 d = x + (A::kLazy ? (m.two_q << k) : m.two_q) - y;
-  x = A::kLazy ? s : csub(s, m.two_q);
-  y = A::mul(d, W, Wp, m);
+  if (A::kLazy) {
+    const u64 d = x + (m.two_q << (k + 2)) - y;
+    x = BOUND ? csub(s, m.two_q << 2) : s;
+    y = mul_add_lazy2<false>(0, d, W, Wp, m.neg_two_q);
+  } else {
+    const u64 d = x + m.two_q - y;
+    x = csub(s, m.two_q);
+    y = mul_lazy(d, W, Wp, m.q);
+  }
 }
 
 // Last inverse stage with N^{-1} folded in (ntt-radix-2.cpp:490-509):
-// x' = (x+y) * n1, y' = (x-y) * n1W, both lazy in [0,2q).  The sum needs no
-// conditional subtraction first because mul_lazy accepts any 64-bit input.
+// x' = (x+y) * n1, y' = (x-y) * n1W.  The sum needs no conditional subtraction
+// first because the lazy products accept it as it is.  Strict: [0,2q).  Lazy:
+// the exact quotient is used here, so the doubled results lie in [0,4q).
 template <class A>
 HX_HD void inv_butterfly_last(u64& x, u64& y, u64 n1, u64 n1p, u64 n1w, u64 n1wp,
                               const ModConst& m, int k) {
   const u64 s = x + y;
-  const u64 d = x + (A::kLazy ? (m.two_q << k) : m.two_q) - y;
-  x = A::mul(s, n1, n1p, m);
-  y = A::mul(d, n1w, n1wp, m);
+  if (A::kLazy) {
+    const u64 d = x + (m.two_q << (k + 2)) - y;
+    x = mul_add_lazy2<true>(0, s, n1, n1p, m.neg_two_q);
+    y = mul_add_lazy2<true>(0, d, n1w, n1wp, m.neg_two_q);
+  } else {
+    const u64 d = x + m.two_q - y;
+    x = mul_lazy(s, n1, n1p, m.q);
+    y = mul_lazy(d, n1w, n1wp, m.q);
+  }
 }
 
-// Lazy policy, subtree exit: element with `lz` leading X-steps is < 2q * 2^lz.
+// End of the inverse network: v is an output of inv_butterfly_last.
+template <class A>
+HX_HD u64 inv_finish(u64 v, const ModConst& m, bool canonical) {
+  if (A::kLazy) {
+    if (canonical) v = csub(v, m.two_q);
+    return v >> 1;
+  }
+  return canonical ? csub(v, m.q) : v;
+}
+
+// Lazy policy, end of a lazy run: an element that was the sum in the last `lz`
+// stages of the run is < 8q * 2^lz (doubled); bring it back below 8q.
 template <int LZ>
 HX_HD u64 inv_ladder(u64 x, const ModConst& m) {
 #pragma unroll
-  for (int t = LZ - 1; t >= 0; --t) x = csub(x, m.two_q << t);
+  for (int t = LZ - 1; t >= 0; --t) x = csub(x, m.two_q << (t + 2));
   return x;
 }
 

@@ -71,6 +71,12 @@ extern "C" int hexl_amd_debug_set_phase_buf(void* buf) {
 #define HX_PROFILE_WAIT_VMEM()
 #endif
 
+// Kernel `flags` argument.  Bits 0-1: 0 = more passes follow, 1 = this pass ends
+// the network (lazy output range), 2 = ends the network with canonical output in
+// [0,q).  Bit 2: this pass starts the network (its input is the caller's data).
+constexpr u32 kFinishMask = 3;
+constexpr u32 kFirstPass = 4;
+
 // ---------------------------------------------------------------------------
 // Register subtrees
 // ---------------------------------------------------------------------------
@@ -114,7 +120,9 @@ constexpr int leading_zeros(int e, int R) {
 template <int R, int E0, class A>
 struct InvLadder {
   static __device__ __forceinline__ void run(u64* x, const ModConst& m) {
-    x[E0] = inv_ladder<leading_zeros(E0, R)>(x[E0], m);
+    constexpr int kRun = R > 4 ? 4 : R;  // stages of the final lazy run
+    constexpr int kLz = leading_zeros(E0, R) < kRun ? leading_zeros(E0, R) : kRun;
+    x[E0] = inv_ladder<kLz>(x[E0], m);
     InvLadder<R, E0 + 1, A>::run(x, m);
   }
 };
@@ -125,15 +133,20 @@ struct InvLadder<R, (1 << R), A> {
 
 // R inverse stages (deepest level first).  With LAST the v == 0 stage is the
 // root of the whole transform and folds N^-1 in (ntt-radix-2.cpp:490-509).
-// Lazy policy: no conditional subtraction inside the subtree, [0,2q) restored
-// at exit (not needed after LAST, whose outputs are both lazy products).
+// Lazy policy: no conditional subtraction inside the subtree, the bound 8q is
+// restored at exit (not needed after LAST, whose outputs are both lazy
+// products).  A lazy run is at most 4 stages deep (8q * 2^4 must stay below
+// 2^63 for q < 2^56); a 5-stage subtree bounds the sums of its first stage.
 template <int R, class A, bool LAST>
 __device__ __forceinline__ void inv_subtree(u64* x, const ulonglong2* wv, const ModConst& m,
                                             const InvLast& il) {
+  constexpr int kBounded = (A::kLazy && R > 4) ? R - 4 : 0;
+  static_assert(R <= 5, "lazy inverse run too deep");
 #pragma unroll
   for (int v = R - 1; v >= 0; --v) {
     const int half = 1 << (R - 1 - v);
-    const int k = R - 1 - v;
+    const int t = R - 1 - v;  // execution order
+    const int k = t < kBounded ? 0 : t - kBounded;
 #pragma unroll
     for (int g = 0; g < (1 << v); ++g) {
       if (LAST && v == 0) {
@@ -143,8 +156,14 @@ __device__ __forceinline__ void inv_subtree(u64* x, const ulonglong2* wv, const 
       } else {
         const ulonglong2 w = wv[(1 << v) + g];
 #pragma unroll
-        for (int j = 0; j < half; ++j)
-          inv_butterfly<A>(x[g * 2 * half + j], x[g * 2 * half + j + half], w.x, w.y, m, k);
+        for (int j = 0; j < half; ++j) {
+          if (t < kBounded)
+            inv_butterfly<A, true>(x[g * 2 * half + j], x[g * 2 * half + j + half], w.x, w.y, m,
+                                   0);
+          else
+            inv_butterfly<A, false>(x[g * 2 * half + j], x[g * 2 * half + j + half], w.x, w.y, m,
+                                    k);
+        }
       }
     }
   }
@@ -161,9 +180,10 @@ __device__ __forceinline__ void inv_subtree(u64* x, const ulonglong2* wv, const 
 template <bool FWD, int R, class A>
 __global__ void __launch_bounds__(256)
 strided_pass(u64* __restrict__ out, const u64* __restrict__ in,
-             const ulonglong2* __restrict__ tw, ModConst m, u32 log_n, u32 a0, u32 finish,
+             const ulonglong2* __restrict__ tw, ModConst m, u32 log_n, u32 a0, u32 flags,
              u64 items, InvLast il) {
   constexpr int E = 1 << R;
+  const u32 finish = flags & kFinishMask;
   const u64 wi = (u64)blockIdx.x * 256 + threadIdx.x;
   if (wi >= items) return;
   const u32 log_s = log_n - a0 - R;
@@ -181,9 +201,11 @@ strided_pass(u64* __restrict__ out, const u64* __restrict__ in,
   u64 x[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) x[e] = in[base + ((u64)e << log_s)];
+  if (flags & kFirstPass) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) x[e] = to_internal<A>(x[e]);
+  }
 
-  // finish: 0 = more passes follow, 1 = end of the network (lazy output range),
-  // 2 = end of the network, canonical output in [0,q)
   if (FWD) {
     fwd_subtree<R, A>(x, wv, m);
     if (finish) {
@@ -196,9 +218,9 @@ strided_pass(u64* __restrict__ out, const u64* __restrict__ in,
     } else {
       inv_subtree<R, A, false>(x, wv, m, il);
     }
-    if (finish == 2) {
+    if (finish) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) x[e] = csub(x[e], m.q);
+      for (int e = 0; e < E; ++e) x[e] = inv_finish<A>(x[e], m, finish == 2);
     }
   }
 #pragma unroll
@@ -434,9 +456,9 @@ __device__ __forceinline__ u32 fetch_index(u32 tid, int i) {
 
 // GUARD: the batch may end inside the tile (only possible for CB == 0 and a batch
 // smaller than / not a multiple of the tile); otherwise every access is in range.
-template <bool FWD, int S, int CB, int TL, bool GUARD>
+template <bool FWD, int S, int CB, int TL, bool GUARD, class A>
 __device__ __forceinline__ void fetch_tile(u64* x, const u64* __restrict__ in, u32 tid,
-                                           const TileGeom& g, u64 total) {
+                                           const TileGeom& g, u64 total, bool first) {
 #pragma unroll
   for (int i = 0; i < kE; ++i) {
     const u32 p = fetch_index<FWD, S, CB, TL>(tid, i);
@@ -448,6 +470,10 @@ __device__ __forceinline__ void fetch_tile(u64* x, const u64* __restrict__ in, u
     else
       x[i] = in[gaddr<CB>(g, p)];
 #endif
+  }
+  if (first) {
+#pragma unroll
+    for (int i = 0; i < kE; ++i) x[i] = to_internal<A>(x[i]);
   }
 }
 
@@ -471,9 +497,11 @@ constexpr int min_waves() { return (S >= 10 || CB > 0) ? 8 : 6; }
 template <bool FWD, int S, int CB, int TL, bool GUARD, class A>
 __global__ void __launch_bounds__(1 << (TL - kRE), (min_waves<S, CB>()))
 tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* __restrict__ tw,
-          ModConst m, u32 log_n, u32 finish, u64 total, u32 stagger, InvLast il) {
+          ModConst m, u32 log_n, u32 flags, u64 total, u32 stagger, InvLast il) {
   using RD = Rounds<S, CB>;
   constexpr int NR = RD::NR;
+  const u32 finish = flags & kFinishMask;
+  const bool first = (flags & kFirstPass) != 0;
   __shared__ u64 lds[1 << TL];
   const u32 tid = threadIdx.x;
   // De-phasing of the first generation of workgroups.  All workgroups of a CU
@@ -497,7 +525,7 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
     {  // round 0 straight from global memory; its twiddles are requested first
       ulonglong2 wv[kE];
       round_twiddles<S, CB, TL, 0>(wv, tw, tid, g);
-      fetch_tile<true, S, CB, TL, GUARD>(x, in, tid, g, total);
+      fetch_tile<true, S, CB, TL, GUARD, A>(x, in, tid, g, total, first);
       HX_PROFILE_WAIT_VMEM();
       HX_STAMP(1);
       round_compute<S, CB, 0, A, true, false>(x, wv, m, il);
@@ -542,7 +570,7 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
     HX_STAMP(9);
   } else {
     // copy-in of the run this wave owns in the deepest round
-    fetch_tile<false, S, CB, TL, GUARD>(x, in, tid, g, total);
+    fetch_tile<false, S, CB, TL, GUARD, A>(x, in, tid, g, total, first);
 #pragma unroll
     for (int i = 0; i < kE; ++i) lds[lds_slot(fetch_index<false, S, CB, TL>(tid, i))] = x[i];
     handover<RD::w(NR - 1), RD::r(NR - 1) == kRE>();
@@ -562,7 +590,7 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
         for (int e = 0; e < (1 << r); ++e) {
           const u32 p = tile_index<r, w>(s * (1 << (TL - kRE)) + tid, e);
           u64 v = x[(s << r) + e];
-          if (finish == 2) v = csub(v, m.q);
+          if (finish) v = inv_finish<A>(v, m, finish == 2);
 #ifdef HX_EXP_NOMEM
           if (v == 0x123456789ULL) out[gaddr<CB>(g, p)] = v;
 #else
@@ -791,23 +819,26 @@ static hipError_t forward_impl(const NttTables& t, u64* result, const u64* opera
   const u64* src = operand;
   InvLast il{};
   hipError_t e;
+  u32 first = kFirstPass;  // consumed by whichever pass runs first
   if (p.top_tile) {
     e = launch_top_tl<true, A>(p.tl_top ? p.tl_top : p.tl, p.top_tile, result, src, t.fwd, t.mod,
-                               t.log_n, 0, batch, il, st);
+                               t.log_n, first, batch, il, st);
     if (e != hipSuccess) return e;
     src = result;
+    first = 0;
   }
   u32 a0 = 0;
   for (int i = 0; i < p.n_strided; ++i) {
-    e = launch_strided<true, A>(p.strided[i], result, src, t.fwd, t.mod, t.log_n, a0, 0, batch,
-                                il, st);
+    e = launch_strided<true, A>(p.strided[i], result, src, t.fwd, t.mod, t.log_n, a0, first,
+                                batch, il, st);
     if (e != hipSuccess) return e;
     a0 += p.strided[i];
     src = result;
+    first = 0;
   }
   const u32 fin = out_mf == 1 ? 2 : 1;
-  return launch_bottom_tl<true, A>(p.tl, p.bottom, result, src, t.fwd, t.mod, t.log_n, fin, batch,
-                                   il, st);
+  return launch_bottom_tl<true, A>(p.tl, p.bottom, result, src, t.fwd, t.mod, t.log_n, fin | first,
+                                   batch, il, st);
 }
 
 template <class A>
@@ -817,7 +848,7 @@ static hipError_t inverse_impl(const NttTables& t, u64* result, const u64* opera
   const u32 fin = out_mf == 1 ? 2 : 1;
   const bool only = !p.top_tile && p.n_strided == 0;
   hipError_t e = launch_bottom_tl<false, A>(p.tl, p.bottom, result, operand, t.inv, t.mod, t.log_n,
-                                            only ? fin : 0, batch, t.inv_last, st);
+                                            kFirstPass | (only ? fin : 0), batch, t.inv_last, st);
   if (e != hipSuccess) return e;
   u32 a0 = t.log_n - (u32)p.bottom;
   for (int i = p.n_strided - 1; i >= 0; --i) {

@@ -1,0 +1,256 @@
+// host_arith_check.cpp -- CPU check of hexl_amd/csrc/modarith.h (the host path of
+// the very functions the HIP kernels inline) against the oracle.
+//
+// The transform networks are replayed stage by stage with the device butterflies:
+// forward = plain radix-2 Cooley-Tukey order; inverse = Gentleman-Sande order cut
+// into lazy runs exactly like the kernels cut it (rounds of <= 3 stages in a tile
+// pass, <= 5 in a strided pass), tracking for every element the number of stages
+// since it was last bounded.  Every intermediate is checked against the range the
+// policy promises (doubled values < 2^63, run exit < 8q) and the outputs against
+// the oracle, bit for bit.
+//
+// Build/run: see tests/test_host_arith.py.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "modarith.h"
+
+extern "C" {
+#include "hexl_oracle.h"
+}
+
+using namespace hexl_amd;
+
+static int g_fail = 0;
+static int g_cases = 0;
+#define EXPECT(c, ...)                 \
+  do {                                 \
+    if (!(c)) {                        \
+      if (g_fail < 20) {               \
+        fprintf(stderr, __VA_ARGS__);  \
+        fprintf(stderr, "\n");         \
+      }                                \
+      ++g_fail;                        \
+    }                                  \
+  } while (0)
+
+static u64 rng_state = 0x1234567ull;
+static u64 rnd() {
+  u64 z = (rng_state += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+template <class A>
+static void check(u64 n, u64 q, const std::vector<int>& inv_runs, u64 in_mf_f, u64 in_mf_i) {
+  int L = 0;
+  while ((1ull << L) < n) ++L;
+  const u64 shoup = A::kLazy ? 63 : 64;
+  std::vector<u64> R(n), Rp(n), Ri_stage(n), Rip_stage(n);
+  ho_ntt_tables(n, q, ho_minimal_primitive_root(2 * n, q), R.data(), Rp.data(), Ri_stage.data(),
+                Rip_stage.data());
+  std::vector<u64> W(n), Wp(n), V(n), Vp(n);  // heap order, forward and inverse
+  for (u64 i = 1; i < n; ++i) {
+    W[i] = R[i];
+    Wp[i] = ho_multiply_factor(W[i], shoup, q);
+    V[i] = ho_inverse_mod(R[i], q);
+    Vp[i] = ho_multiply_factor(V[i], shoup, q);
+  }
+  const ModConst m = make_mod_const(q);
+  ++g_cases;
+  const u64 lim = A::kLazy ? (1ull << 63) : ~0ull;
+
+  for (int canonical = 0; canonical < 2; ++canonical) {
+    // ---------------- forward
+    std::vector<u64> in(n), ref(n), x(n);
+    for (auto& v : in) v = rnd() % (in_mf_f * q);
+    // adversarial values at the range ends
+    in[0] = in_mf_f * q - 1;
+    in[1] = 0;
+    in[n - 1] = in_mf_f * q - 1;
+    ho_ntt_forward_radix2(ref.data(), in.data(), n, q, R.data(), Rp.data(), in_mf_f, 1);
+    for (u64 i = 0; i < n; ++i) x[i] = to_internal<A>(in[i]);
+    for (int s = 0; s < L; ++s) {
+      const u64 mgroups = 1ull << s, t = n >> (s + 1);
+      for (u64 i = 0; i < mgroups; ++i)
+        for (u64 j = 0; j < t; ++j) {
+          u64& a = x[2 * i * t + j];
+          u64& b = x[2 * i * t + j + t];
+          fwd_butterfly<A>(a, b, W[mgroups + i], Wp[mgroups + i], m);
+          EXPECT(a < lim && b < lim, "fwd range: stage %d", s);
+          if (A::kLazy)
+            EXPECT(a < (8 + 6 * (u64)(s + 1)) * q && b < (8 + 6 * (u64)(s + 1)) * q,
+                   "fwd lazy bound: stage %d", s);
+          else
+            EXPECT(a < 4 * q && b < 4 * q, "fwd strict bound: stage %d", s);
+        }
+    }
+    for (u64 i = 0; i < n; ++i) {
+      const u64 r = fwd_finish<A>(x[i], m, canonical);
+      if (canonical)
+        EXPECT(r == ref[i], "fwd canonical mismatch at %llu: %llu vs %llu",
+               (unsigned long long)i, (unsigned long long)r, (unsigned long long)ref[i]);
+      else
+        EXPECT(r < 4 * q && r % q == ref[i], "fwd lazy mismatch at %llu", (unsigned long long)i);
+    }
+
+    // ---------------- inverse
+    for (auto& v : in) v = rnd() % (in_mf_i * q);
+    in[0] = in_mf_i * q - 1;
+    in[1] = in_mf_i * q - 1;
+    in[2] = 0;
+    ho_ntt_inverse_radix2(ref.data(), in.data(), n, q, Ri_stage.data(), Rip_stage.data(), in_mf_i,
+                          1);
+    for (u64 i = 0; i < n; ++i) x[i] = to_internal<A>(in[i]);
+    std::vector<int> depth(n, 0);  // lazy stages since the element was last bounded
+    const u64 n1 = ho_inverse_mod(n, q), n1w = ho_multiply_mod(n1, V[1], q);
+    const u64 n1p = ho_multiply_factor(n1, shoup, q), n1wp = ho_multiply_factor(n1w, shoup, q);
+    int stage = L - 1;  // heap level of the stage to run; deepest first
+    for (size_t ri = 0; ri < inv_runs.size() && stage >= 0; ++ri) {
+      int len = inv_runs[ri];
+      if (len > stage + 1) len = stage + 1;
+      const int bounded = (A::kLazy && len > 4) ? len - 4 : 0;
+      for (int tt = 0; tt < len; ++tt, --stage) {
+        const int k = tt < bounded ? 0 : tt - bounded;
+        const u64 mgroups = 1ull << stage, t = n >> (stage + 1);
+        for (u64 i = 0; i < mgroups; ++i)
+          for (u64 j = 0; j < t; ++j) {
+            const u64 ia = 2 * i * t + j, ib = ia + t;
+            if (A::kLazy) EXPECT(depth[ia] <= k && depth[ib] <= k, "inv depth bookkeeping");
+            if (stage == 0) {
+              inv_butterfly_last<A>(x[ia], x[ib], n1, n1p, n1w, n1wp, m, k);
+            } else if (tt < bounded) {
+              inv_butterfly<A, true>(x[ia], x[ib], V[mgroups + i], Vp[mgroups + i], m, 0);
+              depth[ia] = 0;
+              depth[ib] = 0;
+            } else {
+              inv_butterfly<A, false>(x[ia], x[ib], V[mgroups + i], Vp[mgroups + i], m, k);
+              depth[ia] = k + 1;
+              depth[ib] = 0;
+            }
+            EXPECT(x[ia] < lim && x[ib] < lim, "inv range: stage %d", stage);
+          }
+      }
+      if (stage >= 0 && A::kLazy) {  // run exit: ladder
+        for (u64 i = 0; i < n; ++i) {
+          switch (depth[i]) {
+            case 0: break;
+            case 1: x[i] = inv_ladder<1>(x[i], m); break;
+            case 2: x[i] = inv_ladder<2>(x[i], m); break;
+            case 3: x[i] = inv_ladder<3>(x[i], m); break;
+            case 4: x[i] = inv_ladder<4>(x[i], m); break;
+            default: EXPECT(false, "depth %d", depth[i]);
+          }
+          depth[i] = 0;
+          EXPECT(x[i] < 8 * q, "inv run exit bound");
+        }
+      } else if (stage >= 0) {
+        for (u64 i = 0; i < n; ++i) EXPECT(x[i] < 2 * q, "inv strict bound");
+      }
+    }
+    EXPECT(stage == -1, "runs do not cover the network");
+    for (u64 i = 0; i < n; ++i) {
+      const u64 r = inv_finish<A>(x[i], m, canonical);
+      if (canonical)
+        EXPECT(r == ref[i], "inv canonical mismatch at %llu: %llu vs %llu",
+               (unsigned long long)i, (unsigned long long)r, (unsigned long long)ref[i]);
+      else
+        EXPECT(r < 2 * q && r % q == ref[i], "inv lazy mismatch at %llu", (unsigned long long)i);
+    }
+  }
+}
+
+// The lazy product on its own, at the edges of its domain: D even, D < 2^63.
+static void check_product(u64 q) {
+  const ModConst m = make_mod_const(q);
+  u64 worst = 0;
+  for (int it = 0; it < 400000; ++it) {
+    u64 D, W;
+    switch (it & 7) {
+      case 0: D = (1ull << 63) - 2; break;
+      case 1: D = ((1ull << 63) - 2) - 2 * (rnd() % 1024); break;
+      case 2: D = 2 * (rnd() % 1024); break;
+      case 3: D = (rnd() | 0xFFFFFFFFull) & ((1ull << 63) - 2); break;   // low word all ones
+      case 4: D = (rnd() & ~0xFFFFFFFFull) & ((1ull << 63) - 2); break;  // low word zero
+      default: D = rnd() & ((1ull << 63) - 2); break;
+    }
+    switch ((it >> 3) & 3) {
+      case 0: W = q - 1 - rnd() % 4; break;
+      case 1: W = 1 + rnd() % 4; break;
+      default: W = rnd() % q; break;
+    }
+    const u64 W63 = ho_multiply_factor(W, 63, q);
+    const u64 x = D >> 1;
+    const u64 want = (u64)(((unsigned __int128)x * W) % q);
+    const u64 acc = rnd();
+    const u64 t_apx = mul_add_lazy2<false>(acc, D, W, W63, m.neg_two_q) - acc;
+    const u64 t_ex = mul_add_lazy2<true>(0, D, W, W63, m.neg_two_q);
+    EXPECT(t_apx < 6 * q && (t_apx & 1) == 0 && (t_apx >> 1) % q == want, "approximate product");
+    EXPECT(t_ex < 4 * q && (t_ex & 1) == 0 && (t_ex >> 1) % q == want, "exact product");
+    if (t_apx > worst) worst = t_apx;
+  }
+  // forward finish over its whole input range: doubled values below 128q
+  for (int it = 0; it < 400000; ++it) {
+    u64 x = rnd() % (64 * q);
+    if ((it & 15) == 0) x = 64 * q - 1 - (rnd() & 7);
+    if ((it & 15) == 1) x = (rnd() & 63) * q + ((it & 16) ? 0 : q - 1);
+    EXPECT(fwd_finish<Lazy>(x << 1, m, true) == x % q, "fwd_finish canonical");
+    const u64 r = fwd_finish<Lazy>(x << 1, m, false);
+    EXPECT(r < 2 * q && r % q == x % q, "fwd_finish lazy");
+  }
+  (void)worst;
+}
+
+int main() {
+  u64 primes[8];
+  for (int bits : {3, 9, 16, 31, 32, 33, 48, 54, 55}) {
+    const size_t got = ho_generate_primes(primes, 2, bits, 1, 2);
+    for (size_t pi = 0; pi < got; ++pi) check_product(primes[pi]);
+    const size_t got2 = ho_generate_primes(primes, 1, bits, 0, 2);
+    for (size_t pi = 0; pi < got2; ++pi) check_product(primes[pi]);
+  }
+  struct Case {
+    u64 n;
+    int bits;
+  };
+  // moduli at both ends of the lazy range and beyond it (strict only)
+  const Case lazy_cases[] = {{16, 10}, {64, 20}, {1024, 30}, {4096, 31}, {4096, 32},
+                             {4096, 48}, {8192, 54}, {65536, 54}, {65536, 55}, {131072, 55}};
+  const std::vector<std::vector<int>> run_sets = {
+      {3, 3, 3, 3, 4, 4},     // tile rounds + strided 4 (+4)
+      {3, 3, 3, 3, 5},        // 17 = 12 + 5: five-stage strided subtree
+      {1, 3, 3, 3, 3, 3, 3},  // short first round
+      {2, 3, 3, 3, 2, 4, 4},
+      {3, 3, 3, 3, 3, 3}};
+  for (const Case& c : lazy_cases) {
+    const size_t got = ho_generate_primes(primes, 2, c.bits, 1, c.n);
+    for (size_t pi = 0; pi < got; ++pi)
+      for (const auto& runs : run_sets) {
+        check<Lazy>(c.n, primes[pi], runs, 4, 2);
+        check<Lazy>(c.n, primes[pi], runs, 1, 1);
+        check<Strict>(c.n, primes[pi], runs, 4, 2);
+      }
+  }
+  // the largest primes below 2^56 (GeneratePrimes(., 55, false, .) walks downwards)
+  {
+    const size_t got = ho_generate_primes(primes, 2, 55, 0, 65536);
+    for (size_t pi = 0; pi < got; ++pi) {
+      check<Lazy>(65536, primes[pi], run_sets[0], 4, 2);
+      check<Lazy>(65536, primes[pi], run_sets[1], 4, 2);
+    }
+  }
+  {
+    const size_t got = ho_generate_primes(primes, 2, 60, 0, 4096);
+    for (size_t pi = 0; pi < got; ++pi) check<Strict>(4096, primes[pi], run_sets[0], 4, 2);
+    const size_t got2 = ho_generate_primes(primes, 1, 61, 1, 4096);
+    for (size_t pi = 0; pi < got2; ++pi) check<Strict>(4096, primes[pi], run_sets[0], 4, 2);
+  }
+  if (g_fail) {
+    fprintf(stderr, "host_arith_check: %d failures\n", g_fail);
+    return 1;
+  }
+  printf("host_arith_check OK (%d network replays)\n", g_cases);
+  return 0;
+}

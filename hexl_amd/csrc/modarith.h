@@ -55,6 +55,14 @@ HX_HD u64 mul_hi64(u64 a, u64 b) {
 // x - m if x >= m else x   (x < 2m)
 HX_HD u64 csub(u64 x, u64 m) { return x >= m ? x - m : x; }
 
+// Same for x, m < 2^63 (every lazy-policy value): x + (-m) is one v_lshl_add_u64
+// and the selection tests the sign of its high word -- no 64-bit compare, no
+// carry chain.  neg_m = 2^64 - m.
+HX_HD u64 csub_neg(u64 x, u64 neg_m) {
+  const u64 t = x + neg_m;
+  return (int32_t)(u32)(t >> 32) < 0 ? x : t;
+}
+
 // Shoup / Harvey lazy product: x*W - floor(x*Wp / 2^64)*q  in [0, 2q) for ANY
 // 64-bit x, W < q, Wp = floor(W * 2^64 / q).
 HX_HD u64 mul_lazy(u64 x, u64 W, u64 Wp, u64 q) {
@@ -173,7 +181,7 @@ HX_HD u64 fwd_finish(u64 x, const ModConst& m, bool canonical) {
   if (A::kLazy) {
     const u32 qe = mul_hi32((u32)(x >> m.fin_shift), m.fin_mul);
     u64 r2 = x + (u64)qe * m.neg_two_q;
-    if (canonical) r2 = csub(r2, m.two_q);
+    if (canonical) r2 = csub_neg(r2, m.neg_two_q);
     return r2 >> 1;
   }
   return canonical ? csub(csub(x, m.two_q), m.q) : x;
@@ -189,7 +197,7 @@ HX_HD void inv_butterfly(u64& x, u64& y, u64 W, u64 Wp, const ModConst& m, int k
   const u64 s = x + y;
   if (A::kLazy) {
     const u64 d = x + (m.two_q << (k + 2)) - y;
-    x = BOUND ? csub(s, m.two_q << 2) : s;
+    x = BOUND ? csub_neg(s, m.neg_two_q << 2) : s;
     y = mul_add_lazy2<false>(0, d, W, Wp, m.neg_two_q);
   } else {
     const u64 d = x + m.two_q - y;
@@ -221,19 +229,23 @@ HX_HD void inv_butterfly_last(u64& x, u64& y, u64 n1, u64 n1p, u64 n1w, u64 n1wp
 template <class A>
 HX_HD u64 inv_finish(u64 v, const ModConst& m, bool canonical) {
   if (A::kLazy) {
-    if (canonical) v = csub(v, m.two_q);
+    if (canonical) v = csub_neg(v, m.neg_two_q);
     return v >> 1;
   }
   return canonical ? csub(v, m.q) : v;
 }
 
 // Lazy policy, end of a lazy run: an element that was the sum in the last `lz`
-// stages of the run is < 8q * 2^lz (doubled); bring it back below 8q.
+// stages of the run is < 8q * 2^lz (doubled); bring it back below 8q.  One
+// conditional subtraction for lz == 1; for longer runs the 8-bit quotient
+// estimate of fwd_finish (value < 128q) lands in [0,4q) in five instructions.
 template <int LZ>
 HX_HD u64 inv_ladder(u64 x, const ModConst& m) {
-#pragma unroll
-  for (int t = LZ - 1; t >= 0; --t) x = csub(x, m.two_q << (t + 2));
-  return x;
+  static_assert(LZ <= 4, "lazy run too long");
+  if (LZ == 0) return x;
+  if (LZ == 1) return csub_neg(x, m.neg_two_q << 2);
+  const u32 qe = mul_hi32((u32)(x >> m.fin_shift), m.fin_mul);
+  return x + (u64)qe * m.neg_two_q;
 }
 
 }  // namespace hexl_amd

@@ -285,10 +285,25 @@ struct TileGeom {
   u32 tile_blk0;  // index within its polynomial of the tile's first sub-block
 };
 
+// Global address of tile element p = p0 + dp, split into a per-thread 32-bit byte
+// offset (from p0) and a wave-uniform 64-bit part (tile base + dp, dp a
+// compile-time multiple of 2^CB): the uniform part lives in SGPRs and the access
+// is `global_load/store v, v_off, s[base]` with no per-element vector arithmetic.
 template <int CB>
-__device__ __forceinline__ u64 gaddr(const TileGeom& g, u32 p) {
-  if (CB == 0) return g.base + p;
-  return g.base + ((u64)(p >> CB) << g.log_row) + (p & ((1u << CB) - 1));
+__device__ __forceinline__ u32 tile_byte_offset(const TileGeom& g, u32 p0) {
+  if (CB == 0) return p0 << 3;
+  return (((p0 >> CB) << g.log_row) + (p0 & ((1u << CB) - 1))) << 3;
+}
+template <int CB>
+__device__ __forceinline__ u64 tile_uniform_offset(const TileGeom& g, u32 dp) {
+  if (CB == 0) return g.base + dp;
+  return g.base + ((u64)(dp >> CB) << g.log_row);
+}
+__device__ __forceinline__ u64 load_global(const u64* uniform_base, u32 byte_off) {
+  return *reinterpret_cast<const u64*>(reinterpret_cast<const char*>(uniform_base) + byte_off);
+}
+__device__ __forceinline__ void store_global(u64* uniform_base, u32 byte_off, u64 v) {
+  *reinterpret_cast<u64*>(reinterpret_cast<char*>(uniform_base) + byte_off) = v;
 }
 
 // Twiddles of round j for every sub-run this thread owns in that round.
@@ -333,16 +348,24 @@ __device__ __forceinline__ void round_compute(u64* x, const ulonglong2* wv, cons
   }
 }
 
+// LDS byte address of a slot.  lds_slot is linear over XOR and the fields of a
+// tile index are disjoint bit ranges, so the address of element e of a thread is
+// (address of its element 0) ^ (compile-time constant): one v_xor per access.
+__device__ __forceinline__ u64& lds_at(u64* lds, u32 byte_addr) {
+  return *reinterpret_cast<u64*>(reinterpret_cast<char*>(lds) + byte_addr);
+}
+
 template <int S, int CB, int TL, int j>
-__device__ __forceinline__ void lds_load_round(u64* x, const u64* lds, u32 tid) {
+__device__ __forceinline__ void lds_load_round(u64* x, u64* lds, u32 tid) {
   constexpr int r = Rounds<S, CB>::r(j), w = Rounds<S, CB>::w(j);
   constexpr int SS = kE >> r;
   constexpr int kThreads = 1 << (TL - kRE);
 #pragma unroll
-  for (int s = 0; s < SS; ++s)
+  for (int s = 0; s < SS; ++s) {
+    const u32 a0 = lds_slot(tile_index<r, w>(s * kThreads + tid, 0)) << 3;
 #pragma unroll
-    for (int e = 0; e < (1 << r); ++e)
-      x[(s << r) + e] = lds[lds_slot(tile_index<r, w>(s * kThreads + tid, e))];
+    for (int e = 0; e < (1 << r); ++e) x[(s << r) + e] = lds_at(lds, a0 ^ (lds_slot((u32)e << w) << 3));
+  }
 }
 
 template <int S, int CB, int TL, int j>
@@ -351,10 +374,11 @@ __device__ __forceinline__ void lds_store_round(const u64* x, u64* lds, u32 tid)
   constexpr int SS = kE >> r;
   constexpr int kThreads = 1 << (TL - kRE);
 #pragma unroll
-  for (int s = 0; s < SS; ++s)
+  for (int s = 0; s < SS; ++s) {
+    const u32 a0 = lds_slot(tile_index<r, w>(s * kThreads + tid, 0)) << 3;
 #pragma unroll
-    for (int e = 0; e < (1 << r); ++e)
-      lds[lds_slot(tile_index<r, w>(s * kThreads + tid, e))] = x[(s << r) + e];
+    for (int e = 0; e < (1 << r); ++e) lds_at(lds, a0 ^ (lds_slot((u32)e << w) << 3)) = x[(s << r) + e];
+  }
 }
 
 // Hand-over of the tile from a round with finest gap 2^w to its neighbour.
@@ -374,14 +398,6 @@ __device__ __forceinline__ void handover() {
   }
 }
 
-// Experiment switch: after the last forward round a thread holds 8 consecutive
-// coefficients (64 bytes); store them directly (4 x 16 B per lane, 64-byte lane
-// stride) instead of transposing through LDS for fully coalesced stores.
-#ifndef HEXL_AMD_DIRECT_OUT
-#define HEXL_AMD_DIRECT_OUT 0
-#endif
-constexpr bool kDirectOut = HEXL_AMD_DIRECT_OUT != 0;
-
 // forward rounds J .. NR-1: LDS -> registers -> subtree -> same LDS slots
 template <int S, int CB, int TL, int J, class A>
 __device__ __forceinline__ void fwd_mid_rounds(u64* x, u64* lds, const ulonglong2* tw, u32 tid,
@@ -393,9 +409,6 @@ __device__ __forceinline__ void fwd_mid_rounds(u64* x, u64* lds, const ulonglong
     round_twiddles<S, CB, TL, J>(wv, tw, tid, g);
     lds_load_round<S, CB, TL, J>(x, lds, tid);
     round_compute<S, CB, J, A, true, false>(x, wv, m, il);
-    if constexpr (kDirectOut && J == RD::NR - 1 && CB == 0 && RD::r(J) == kRE) {
-      return;  // the caller stores the 8 contiguous results straight from registers
-    }
     lds_store_round<S, CB, TL, J>(x, lds, tid);
     handover<RD::w(J), RD::r(J) == kRE>();
     HX_STAMP(3 + J);
@@ -441,40 +454,61 @@ __device__ __forceinline__ TileGeom make_geom(u32 tile, u32 log_n) {
   return g;
 }
 
-// The 8 elements a thread fetches from global memory for a tile: forward = its
-// round-0 set, inverse = its slice of the run its wave owns in the deepest round.
-template <bool FWD, int S, int CB, int TL>
-__device__ __forceinline__ u32 fetch_index(u32 tid, int i) {
+// Tile index of the i-th element a thread moves between global memory and its
+// registers, as (per-thread p0, uniform dp).  ROUND0: the thread's round-0 set
+// (forward fetch, inverse store); otherwise its slice of the 512-element run its
+// wave owns in the deepest round (inverse fetch, forward store), 64 per access.
+template <bool ROUND0, int S, int CB, int TL>
+__device__ __forceinline__ u32 xfer_p0(u32 tid, int i) {
   using RD = Rounds<S, CB>;
-  if (FWD) {
+  if (ROUND0) {
     constexpr int r = RD::r(0), w = RD::w(0);
-    const int s = i >> r, e = i & ((1 << r) - 1);
-    return tile_index<r, w>(((u32)s << (TL - kRE)) + tid, e);
+    return tile_index<r, w>(((u32)(i >> r) << (TL - kRE)) + tid, 0);
   }
-  return ((tid >> 6) * kE + i) * 64 + (tid & 63);
+  return ((tid >> 6) << (kRE + 6)) + (tid & 63);
+}
+template <bool ROUND0, int S, int CB>
+__device__ __forceinline__ constexpr u32 xfer_dp(int i) {
+  using RD = Rounds<S, CB>;
+  return ROUND0 ? (u32)(i & ((1 << RD::r(0)) - 1)) << RD::w(0) : (u32)i << 6;
 }
 
 // GUARD: the batch may end inside the tile (only possible for CB == 0 and a batch
 // smaller than / not a multiple of the tile); otherwise every access is in range.
-template <bool FWD, int S, int CB, int TL, bool GUARD, class A>
+template <bool ROUND0, int S, int CB, int TL, bool GUARD, class A>
 __device__ __forceinline__ void fetch_tile(u64* x, const u64* __restrict__ in, u32 tid,
                                            const TileGeom& g, u64 total, bool first) {
 #pragma unroll
   for (int i = 0; i < kE; ++i) {
-    const u32 p = fetch_index<FWD, S, CB, TL>(tid, i);
+    const u32 p0 = xfer_p0<ROUND0, S, CB, TL>(tid, i);
+    const u32 dp = xfer_dp<ROUND0, S, CB>(i);
 #ifdef HX_EXP_NOMEM  // developer experiment: no global traffic
-    x[i] = (u64)p * 0x9E3779B97F4A7C15ULL >> 10;
+    x[i] = (u64)(p0 + dp) * 0x9E3779B97F4A7C15ULL >> 10;
 #else
+    const u64* src = in + tile_uniform_offset<CB>(g, dp);
     if (GUARD)
-      x[i] = (g.base + p < total) ? in[gaddr<CB>(g, p)] : 0;
+      x[i] = (g.base + p0 + dp < total) ? load_global(src, tile_byte_offset<CB>(g, p0)) : 0;
     else
-      x[i] = in[gaddr<CB>(g, p)];
+      x[i] = load_global(src, tile_byte_offset<CB>(g, p0));
 #endif
   }
   if (first) {
 #pragma unroll
     for (int i = 0; i < kE; ++i) x[i] = to_internal<A>(x[i]);
   }
+}
+
+template <bool ROUND0, int S, int CB, int TL, bool GUARD>
+__device__ __forceinline__ void store_elem(u64* __restrict__ out, u32 tid, int i, u64 v,
+                                           const TileGeom& g, u64 total) {
+  const u32 p0 = xfer_p0<ROUND0, S, CB, TL>(tid, i);
+  const u32 dp = xfer_dp<ROUND0, S, CB>(i);
+#ifdef HX_EXP_NOMEM
+  if (v == 0x123456789ULL) out[g.base + p0 + dp] = v;  // keeps the value live, ~never stores
+#else
+  if (!GUARD || g.base + p0 + dp < total)
+    store_global(out + tile_uniform_offset<CB>(g, dp), tile_byte_offset<CB>(g, p0), v);
+#endif
 }
 
 // One workgroup per tile.  (A persistent variant -- each workgroup looping over
@@ -485,8 +519,8 @@ __device__ __forceinline__ void fetch_tile(u64* x, const u64* __restrict__ in, u
 //
 // FWD:  global --(round 0)--> LDS --(rounds 1..)--> LDS --> coalesced store
 // INV:  coalesced load --> LDS --(rounds NR-1..1)--> LDS --(round 0)--> global
-constexpr u32 kCUs = 256;                        // MI355X
-constexpr u32 kFirstWave = kCUs * 4;             // workgroups resident at launch (TL = 12)
+// (A one-off sleep de-phasing the first generation of workgroups was measured
+// too: no effect -- the kernel is bound by VALU issue, not by phase alignment.)
 
 // Occupancy target: 8 waves per SIMD (<= 64 VGPRs) for the shapes large transforms
 // use; the short bottom passes of small N (several sub-runs per thread in round
@@ -497,26 +531,13 @@ constexpr int min_waves() { return (S >= 10 || CB > 0) ? 8 : 6; }
 template <bool FWD, int S, int CB, int TL, bool GUARD, class A>
 __global__ void __launch_bounds__(1 << (TL - kRE), (min_waves<S, CB>()))
 tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* __restrict__ tw,
-          ModConst m, u32 log_n, u32 flags, u64 total, u32 stagger, InvLast il) {
+          ModConst m, u32 log_n, u32 flags, u64 total, InvLast il) {
   using RD = Rounds<S, CB>;
   constexpr int NR = RD::NR;
   const u32 finish = flags & kFinishMask;
   const bool first = (flags & kFirstPass) != 0;
   __shared__ u64 lds[1 << TL];
   const u32 tid = threadIdx.x;
-  // De-phasing of the first generation of workgroups.  All workgroups of a CU
-  // start together and take the same time, so without this they stay in lockstep
-  // for the whole launch (all loading, then all computing, ...) and memory time
-  // and arithmetic time add instead of overlapping.  The k-th workgroup a CU
-  // receives at launch sleeps k * stagger * ~8k cycles once; later generations
-  // inherit the offset because a slot is refilled when its workgroup retires.
-  if (stagger) {
-    const u32 resident = gridDim.x < kFirstWave ? gridDim.x : kFirstWave;
-    if (blockIdx.x < resident) {
-      const u32 k = (blockIdx.x / kCUs) % (kFirstWave / kCUs);
-      for (u32 i = 0; i < k * stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-  }
   const TileGeom g = make_geom<S, CB, TL>(blockIdx.x, log_n);
   u64 x[kE];
   HX_STAMP(0);
@@ -525,7 +546,7 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
     {  // round 0 straight from global memory; its twiddles are requested first
       ulonglong2 wv[kE];
       round_twiddles<S, CB, TL, 0>(wv, tw, tid, g);
-      fetch_tile<true, S, CB, TL, GUARD, A>(x, in, tid, g, total, first);
+      fetch_tile<true, S, CB, TL, GUARD, A>(x, in, tid, g, total, first);  // round-0 set
       HX_PROFILE_WAIT_VMEM();
       HX_STAMP(1);
       round_compute<S, CB, 0, A, true, false>(x, wv, m, il);
@@ -535,35 +556,16 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
       HX_STAMP(3);
     }
     fwd_mid_rounds<S, CB, TL, 1, A>(x, lds, tw, tid, g, m, il);
-    if constexpr (kDirectOut && NR > 1 && CB == 0) {
-      u64* dst = out + g.base + (u64)tid * kE;
-#pragma unroll
-      for (int e = 0; e < kE; ++e)
-        if (finish) x[e] = fwd_finish<A>(x[e], m, finish == 2);
-      if (!GUARD || g.base + (u64)tid * kE < total) {
-        if ((reinterpret_cast<uintptr_t>(out) & 15) == 0) {
-#pragma unroll
-          for (int e = 0; e < kE; e += 2)
-            *reinterpret_cast<ulonglong2*>(dst + e) = make_ulonglong2(x[e], x[e + 1]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < kE; ++e) dst[e] = x[e];
-        }
-      }
-      return;
-    }
     // copy-out of the run this wave owns after the last round (w = CB <= 6):
     // 512 tile-contiguous elements, 64 per access; final reduction fused
+    {
+      const u32 a0 = lds_slot(xfer_p0<false, S, CB, TL>(tid, 0)) << 3;
 #pragma unroll
-    for (int i = 0; i < kE; ++i) {
-      const u32 p = ((tid >> 6) * kE + i) * 64 + (tid & 63);
-      u64 v = lds[lds_slot(p)];
-      if (finish) v = fwd_finish<A>(v, m, finish == 2);
-#ifdef HX_EXP_NOMEM
-      if (v == 0x123456789ULL) out[gaddr<CB>(g, p)] = v;  // keeps the value live, ~never stores
-#else
-      if (!GUARD || g.base + p < total) out[gaddr<CB>(g, p)] = v;
-#endif
+      for (int i = 0; i < kE; ++i) {
+        u64 v = lds_at(lds, a0 ^ (lds_slot(xfer_dp<false, S, CB>(i)) << 3));
+        if (finish) v = fwd_finish<A>(v, m, finish == 2);
+        store_elem<false, S, CB, TL, GUARD>(out, tid, i, v, g, total);
+      }
     }
     HX_STAMP(8);
     HX_PROFILE_WAIT_VMEM();
@@ -571,12 +573,14 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
   } else {
     // copy-in of the run this wave owns in the deepest round
     fetch_tile<false, S, CB, TL, GUARD, A>(x, in, tid, g, total, first);
+    {
+      const u32 a0 = lds_slot(xfer_p0<false, S, CB, TL>(tid, 0)) << 3;
 #pragma unroll
-    for (int i = 0; i < kE; ++i) lds[lds_slot(fetch_index<false, S, CB, TL>(tid, i))] = x[i];
+      for (int i = 0; i < kE; ++i) lds_at(lds, a0 ^ (lds_slot(xfer_dp<false, S, CB>(i)) << 3)) = x[i];
+    }
     handover<RD::w(NR - 1), RD::r(NR - 1) == kRE>();
     inv_mid_rounds<S, CB, TL, NR - 1, A>(x, lds, tw, tid, g, m, il);
     {
-      constexpr int r = RD::r(0), w = RD::w(0), SS = kE >> r;
       ulonglong2 wv[kE];
       round_twiddles<S, CB, TL, 0>(wv, tw, tid, g);
       lds_load_round<S, CB, TL, 0>(x, lds, tid);
@@ -585,18 +589,11 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
       else
         round_compute<S, CB, 0, A, false, false>(x, wv, m, il);
 #pragma unroll
-      for (int s = 0; s < SS; ++s)
-#pragma unroll
-        for (int e = 0; e < (1 << r); ++e) {
-          const u32 p = tile_index<r, w>(s * (1 << (TL - kRE)) + tid, e);
-          u64 v = x[(s << r) + e];
-          if (finish) v = inv_finish<A>(v, m, finish == 2);
-#ifdef HX_EXP_NOMEM
-          if (v == 0x123456789ULL) out[gaddr<CB>(g, p)] = v;
-#else
-          if (!GUARD || g.base + p < total) out[gaddr<CB>(g, p)] = v;
-#endif
-        }
+      for (int i = 0; i < kE; ++i) {
+        u64 v = x[i];
+        if (finish) v = inv_finish<A>(v, m, finish == 2);
+        store_elem<true, S, CB, TL, GUARD>(out, tid, i, v, g, total);
+      }
     }
   }
 }
@@ -630,14 +627,6 @@ static hipError_t launch_strided(int R, u64* out, const u64* in, const ulonglong
   return hipGetLastError();
 }
 
-static u32 stagger_setting() {
-  static const u32 v = [] {
-    const char* e = getenv("HEXL_AMD_STAGGER");
-    return e ? (u32)atoi(e) : 0u;
-  }();
-  return v;
-}
-
 // Bottom pass: S stages on contiguous sub-blocks (CB = 0), tile of 2^TL elements.
 template <bool FWD, int TL, class A>
 static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2* tw,
@@ -654,11 +643,11 @@ static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2
       if (guard)                                                                          \
         hipLaunchKernelGGL((tile_pass<FWD, T, 0, TL, true, A>), dim3(grid),               \
                            dim3(1 << (TL - kRE)), 0, st, out, in, tw, m, log_n, finish,   \
-                           total, stagger_setting(), il);                                 \
+                           total, il);                                 \
       else                                                                                \
         hipLaunchKernelGGL((tile_pass<FWD, T, 0, TL, false, A>), dim3(grid),              \
                            dim3(1 << (TL - kRE)), 0, st, out, in, tw, m, log_n, finish,   \
-                           total, stagger_setting(), il);                                 \
+                           total, il);                                 \
     }                                                                                     \
     else                                                                                  \
       return hipErrorInvalidValue;                                                        \
@@ -697,7 +686,7 @@ static hipError_t launch_top(int S, u64* out, const u64* in, const ulonglong2* t
     if constexpr (T <= TL - 4 && (TL == 10 || T >= 7))                                      \
       hipLaunchKernelGGL((tile_pass<FWD, T, TL - T, TL, false, A>), dim3(grid),             \
                          dim3(1 << (TL - kRE)), 0, st, out, in, tw, m, log_n, finish, total, \
-                         stagger_setting(), il);                                            \
+                         il);                                                               \
     else                                                                                    \
       return hipErrorInvalidValue;                                                          \
     break;
@@ -812,10 +801,10 @@ static hipError_t launch_bottom_tl(int tl, int S, u64* out, const u64* in, const
   return launch_bottom<FWD, 12, A>(S, out, in, tw, m, log_n, finish, batch, il, st);
 }
 
+// One transform of `batch` polynomials on stream `st`.
 template <class A>
-static hipError_t forward_impl(const NttTables& t, u64* result, const u64* operand, u64 batch,
-                               u64 out_mf, hipStream_t st) {
-  const Plan p = make_plan((int)t.log_n);
+static hipError_t forward_seq(const NttTables& t, const Plan& p, u64* result, const u64* operand,
+                              u64 batch, u64 out_mf, hipStream_t st) {
   const u64* src = operand;
   InvLast il{};
   hipError_t e;
@@ -842,9 +831,8 @@ static hipError_t forward_impl(const NttTables& t, u64* result, const u64* opera
 }
 
 template <class A>
-static hipError_t inverse_impl(const NttTables& t, u64* result, const u64* operand, u64 batch,
-                               u64 out_mf, hipStream_t st) {
-  const Plan p = make_plan((int)t.log_n);
+static hipError_t inverse_seq(const NttTables& t, const Plan& p, u64* result, const u64* operand,
+                              u64 batch, u64 out_mf, hipStream_t st) {
   const u32 fin = out_mf == 1 ? 2 : 1;
   const bool only = !p.top_tile && p.n_strided == 0;
   hipError_t e = launch_bottom_tl<false, A>(p.tl, p.bottom, result, operand, t.inv, t.mod, t.log_n,
@@ -863,20 +851,33 @@ static hipError_t inverse_impl(const NttTables& t, u64* result, const u64* opera
   return hipSuccess;
 }
 
+// (Round-1 experiment, removed: cutting the batch into chunks that alternate
+// between the caller's stream and an internal one, so that the HBM-bound strided
+// pass of chunk k+1 runs concurrently with the VALU-bound tile pass of chunk k.
+// rocprofv3 timelines showed the kernels do overlap, but each slows the other by
+// exactly the time it gains: 3.64 ms per step against 3.57 ms back to back.)
+template <bool FWD, class A>
+static hipError_t transform_impl(const NttTables& t, u64* result, const u64* operand, u64 batch,
+                                 u64 out_mf, hipStream_t st) {
+  const Plan p = make_plan((int)t.log_n);
+  return FWD ? forward_seq<A>(t, p, result, operand, batch, out_mf, st)
+             : inverse_seq<A>(t, p, result, operand, batch, out_mf, st);
+}
+
 hipError_t ntt_forward_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
                               u64 out_mf, hipStream_t st) {
   if (batch == 0) return hipSuccess;
   if (t.mod.q < kLazyModulusBound)
-    return forward_impl<Lazy>(t, result, operand, batch, out_mf, st);
-  return forward_impl<Strict>(t, result, operand, batch, out_mf, st);
+    return transform_impl<true, Lazy>(t, result, operand, batch, out_mf, st);
+  return transform_impl<true, Strict>(t, result, operand, batch, out_mf, st);
 }
 
 hipError_t ntt_inverse_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
                               u64 out_mf, hipStream_t st) {
   if (batch == 0) return hipSuccess;
   if (t.mod.q < kLazyModulusBound)
-    return inverse_impl<Lazy>(t, result, operand, batch, out_mf, st);
-  return inverse_impl<Strict>(t, result, operand, batch, out_mf, st);
+    return transform_impl<false, Lazy>(t, result, operand, batch, out_mf, st);
+  return transform_impl<false, Strict>(t, result, operand, batch, out_mf, st);
 }
 
 }  // namespace hexl_amd

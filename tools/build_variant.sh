@@ -4,6 +4,10 @@
 # HEXL_AMD_LIB in hexl_amd/__init__.py).
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
+# SRC_ROOT=<dir> builds another checkout's sources (e.g. a `git worktree` of an
+# older commit) for same-box A/B timing.
+ROOT=${SRC_ROOT:-$ROOT}
+OUT=$(cd "$(dirname "$0")" && pwd)
 NAME=$1; shift
 T=$(mktemp -d)
 for f in ntt_kernels.hip eltwise_kernels.hip; do
@@ -16,6 +20,6 @@ for f in capi.cpp number_theory.cpp; do
     -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -c $ROOT/hexl_amd/csrc/$f -o $T/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/libhexl_amd_$NAME.so $T/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libhexl_amd_$NAME.so $T/*.o
 rm -rf $T
 echo built tools/libhexl_amd_$NAME.so

@@ -1,0 +1,14 @@
+"""Two headline steps (for kernel-trace timelines)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import hexl_amd as hx
+N, B = 65536, 4096
+q = 18014398510661633
+ntt = hx.NTT(N, q)
+x = torch.empty((B, N), dtype=torch.int64, device="cuda")
+hx.fill_splitmix(x, N, B, 1, q)
+for _ in range(2):
+    ntt.ComputeForward(x, x, 1, 1)
+    ntt.ComputeInverse(x, x, 1, 1)
+torch.cuda.synchronize()

@@ -16,26 +16,28 @@
 // Everything is built from a register-resident "subtree": a thread owns 2^r
 // elements and runs r stages on them with no communication.
 //
-//   tile_pass<S, CB>  One workgroup (512 threads x 8 elements) owns a tile of
-//     4096 elements = 32 KiB of LDS and runs S stages on it as ceil(S/3)
-//     subtree rounds separated by LDS transposes.  The 12 tile-index bits are
-//     [ sub-block | S transformed bits | CB column bits ]:
-//       CB = 0      the tile is 4096 contiguous coefficients = 4096 >> S whole
-//                   sub-blocks of the heap level a0 = log2(N) - S ("bottom"
-//                   stages; N <= 4096 is this kernel alone);
-//       CB = 12 - S the tile is all 2^S rows x 2^CB adjacent columns of one
-//                   polynomial, rows N >> S apart ("top" stages, a0 = 0); a
-//                   row segment is 2^CB * 8 >= 128 contiguous bytes.
-//     N = 2^16 is top(S=8, CB=4) + bottom(S=8): two HBM round trips, both
-//     kernels with the same 8 stages of arithmetic per byte moved.
-//     LDS slots are XOR-swizzled so that every ds_read_b64 / ds_write_b64
-//     pattern of every round is bank-conflict free; rounds whose gap is <= 64
-//     elements exchange data inside one wave and need no workgroup barrier.
-//     The output reduction (forward) / N^-1 scaling (inverse) is fused into the
-//     last store.
 //   strided_pass<R>   register-only pass (no LDS): each thread owns one column,
-//     elements N >> (a0 + R) apart.  Kept as the alternative top pass
-//     (HEXL_AMD_PLAN=strided: 4 + 12 stages for N = 2^16).
+//     2^R elements N >> (a0 + R) apart, lanes = adjacent columns (coalesced),
+//     twiddles wave-uniform (scalar loads).  HBM-bound: 0.70 ms for 4 GiB in +
+//     4 GiB out.  The default top pass for N >= 2^13 (4 + 12 stages for N = 2^16).
+//   tile_pass<S, CB, TL>  One workgroup (2^(TL-3) threads x 8 elements) owns a tile
+//     of 2^TL elements in LDS (TL = 12: 32 KiB, 4 workgroups = 32 waves per CU) and
+//     runs S stages on it as ceil(S/3) subtree rounds separated by LDS
+//     transposes.  The tile-index bits are [ sub-block | S stage bits | CB column
+//     bits ]:
+//       CB = 0      the tile is 2^TL contiguous coefficients = whole sub-blocks of
+//                   heap level log2(N) - S ("bottom" stages; N <= 4096 is this
+//                   kernel alone, one HBM round trip);
+//       CB = TL - S all 2^S rows x 2^CB adjacent columns of one polynomial ("top"
+//                   stages of the HEXL_AMD_PLAN=tiled alternative).
+//     LDS slots are XOR-swizzled so that every ds_read_b64 / ds_write_b64 pattern
+//     of every round is bank-conflict free (SQ_LDS_BANK_CONFLICT = 0); the swizzle
+//     is linear over XOR, so an element's address is its thread's base address
+//     XOR a compile-time constant.  Rounds whose gap is <= 64 elements exchange
+//     data inside one wave and need no workgroup barrier.  The doubling on entry
+//     and the output reduction / N^-1 scaling are fused into the first load and
+//     the last store of a transform.
+//     Bound by VALU issue (integer multiplies), not by HBM: see DESIGN.md.
 //
 // Values stay lazy as in the reference's Harvey butterflies
 // (hexl/ntt/ntt-default.hpp:28-42, :112-125); see modarith.h for the two range
@@ -260,6 +262,16 @@ struct Rounds {
   static constexpr int r(int j) { return j == 0 ? R0 : kRE; }
   static constexpr int u(int j) { return j == 0 ? 0 : R0 + (j - 1) * kRE; }
   static constexpr int w(int j) { return CB + S - u(j) - r(j); }
+  // Twiddles of round j are per-lane vector loads (gap < one wave) or wave-uniform
+  // scalar loads.
+  static constexpr bool vec(int j) { return w(j) < 6; }
+  // Software pipelining of the twiddle fetch: wave-uniform twiddles (SGPRs, no
+  // VGPR cost) of a round are requested before the arithmetic of the round
+  // executed just before it.  (Doing the same for per-lane twiddles needs 28 more
+  // VGPRs during a round and spills under the 64-VGPR cap of 8 waves per SIMD.)
+  // Forward executes rounds 0..NR-1, inverse NR-1..0.
+  static constexpr bool pre_fwd(int j) { return j >= 1 && j < NR && !vec(j); }
+  static constexpr bool pre_inv(int j) { return j >= 0 && j <= NR - 2 && !vec(j); }
 };
 
 // Tile index of element e of virtual thread vt in a round with r stages whose
@@ -398,39 +410,53 @@ __device__ __forceinline__ void handover() {
   }
 }
 
-// forward rounds J .. NR-1: LDS -> registers -> subtree -> same LDS slots
+// forward rounds J .. NR-1: LDS -> registers -> subtree -> same LDS slots.
+// `pre` holds the twiddles of round J when Rounds::pre_fwd(J).
 template <int S, int CB, int TL, int J, class A>
 __device__ __forceinline__ void fwd_mid_rounds(u64* x, u64* lds, const ulonglong2* tw, u32 tid,
                                                const TileGeom& g, const ModConst& m,
-                                               const InvLast& il) {
+                                               const InvLast& il, const ulonglong2* pre) {
   using RD = Rounds<S, CB>;
   if constexpr (J < RD::NR) {
-    ulonglong2 wv[kE];
-    round_twiddles<S, CB, TL, J>(wv, tw, tid, g);
+    ulonglong2 wv[kE], wn[kE];
+    const ulonglong2* w = pre;
+    if constexpr (!RD::pre_fwd(J)) {
+      round_twiddles<S, CB, TL, J>(wv, tw, tid, g);
+      w = wv;
+    }
     lds_load_round<S, CB, TL, J>(x, lds, tid);
-    round_compute<S, CB, J, A, true, false>(x, wv, m, il);
+    if constexpr (RD::pre_fwd(J + 1)) round_twiddles<S, CB, TL, J + 1>(wn, tw, tid, g);
+    round_compute<S, CB, J, A, true, false>(x, w, m, il);
     lds_store_round<S, CB, TL, J>(x, lds, tid);
     handover<RD::w(J), RD::r(J) == kRE>();
     HX_STAMP(3 + J);
-    fwd_mid_rounds<S, CB, TL, J + 1, A>(x, lds, tw, tid, g, m, il);
+    fwd_mid_rounds<S, CB, TL, J + 1, A>(x, lds, tw, tid, g, m, il, wn);
   }
 }
 
-// inverse rounds J .. 1 (deepest first)
+// inverse rounds J .. 1 (deepest first).  `pre` holds the twiddles of round J when
+// J == NR-1 or Rounds::pre_inv(J); `pre0` receives those of round 0 when
+// Rounds::pre_inv(0).
 template <int S, int CB, int TL, int J, class A>
 __device__ __forceinline__ void inv_mid_rounds(u64* x, u64* lds, const ulonglong2* tw, u32 tid,
                                                const TileGeom& g, const ModConst& m,
-                                               const InvLast& il) {
+                                               const InvLast& il, const ulonglong2* pre,
+                                               ulonglong2* pre0) {
   using RD = Rounds<S, CB>;
   if constexpr (J >= 1) {
-    ulonglong2 wv[kE];
-    round_twiddles<S, CB, TL, J>(wv, tw, tid, g);
+    ulonglong2 wv[kE], wn[kE];
+    const ulonglong2* w = pre;
+    if constexpr (J != RD::NR - 1 && !RD::pre_inv(J)) {
+      round_twiddles<S, CB, TL, J>(wv, tw, tid, g);
+      w = wv;
+    }
     lds_load_round<S, CB, TL, J>(x, lds, tid);
-    round_compute<S, CB, J, A, false, false>(x, wv, m, il);
+    if constexpr (RD::pre_inv(J - 1)) round_twiddles<S, CB, TL, J - 1>(J == 1 ? pre0 : wn, tw, tid, g);
+    round_compute<S, CB, J, A, false, false>(x, w, m, il);
     lds_store_round<S, CB, TL, J>(x, lds, tid);
     // the next (shallower) round J-1 regroups across waves iff its gap exceeds a wave
     handover<RD::w(J - 1), RD::r(J - 1) == kRE>();
-    inv_mid_rounds<S, CB, TL, J - 1, A>(x, lds, tw, tid, g, m, il);
+    inv_mid_rounds<S, CB, TL, J - 1, A>(x, lds, tw, tid, g, m, il, wn, pre0);
   }
 }
 
@@ -543,10 +569,12 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
   HX_STAMP(0);
 
   if (FWD) {
+    ulonglong2 wn[kE];  // twiddles of round 1 when requested ahead
     {  // round 0 straight from global memory; its twiddles are requested first
       ulonglong2 wv[kE];
       round_twiddles<S, CB, TL, 0>(wv, tw, tid, g);
       fetch_tile<true, S, CB, TL, GUARD, A>(x, in, tid, g, total, first);  // round-0 set
+      if constexpr (RD::pre_fwd(1)) round_twiddles<S, CB, TL, 1>(wn, tw, tid, g);
       HX_PROFILE_WAIT_VMEM();
       HX_STAMP(1);
       round_compute<S, CB, 0, A, true, false>(x, wv, m, il);
@@ -555,7 +583,7 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
       handover<RD::w(0), RD::r(0) == kRE>();
       HX_STAMP(3);
     }
-    fwd_mid_rounds<S, CB, TL, 1, A>(x, lds, tw, tid, g, m, il);
+    fwd_mid_rounds<S, CB, TL, 1, A>(x, lds, tw, tid, g, m, il, wn);
     // copy-out of the run this wave owns after the last round (w = CB <= 6):
     // 512 tile-contiguous elements, 64 per access; final reduction fused
     {
@@ -571,7 +599,10 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
     HX_PROFILE_WAIT_VMEM();
     HX_STAMP(9);
   } else {
-    // copy-in of the run this wave owns in the deepest round
+    // copy-in of the run this wave owns in the deepest round; the twiddles of that
+    // round are requested first
+    ulonglong2 wtop[kE], w0[kE];
+    if constexpr (NR > 1) round_twiddles<S, CB, TL, NR - 1>(wtop, tw, tid, g);
     fetch_tile<false, S, CB, TL, GUARD, A>(x, in, tid, g, total, first);
     {
       const u32 a0 = lds_slot(xfer_p0<false, S, CB, TL>(tid, 0)) << 3;
@@ -579,15 +610,14 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
       for (int i = 0; i < kE; ++i) lds_at(lds, a0 ^ (lds_slot(xfer_dp<false, S, CB>(i)) << 3)) = x[i];
     }
     handover<RD::w(NR - 1), RD::r(NR - 1) == kRE>();
-    inv_mid_rounds<S, CB, TL, NR - 1, A>(x, lds, tw, tid, g, m, il);
+    inv_mid_rounds<S, CB, TL, NR - 1, A>(x, lds, tw, tid, g, m, il, wtop, w0);
     {
-      ulonglong2 wv[kE];
-      round_twiddles<S, CB, TL, 0>(wv, tw, tid, g);
+      if constexpr (!RD::pre_inv(0)) round_twiddles<S, CB, TL, 0>(w0, tw, tid, g);
       lds_load_round<S, CB, TL, 0>(x, lds, tid);
       if (g.a0 == 0)
-        round_compute<S, CB, 0, A, false, true>(x, wv, m, il);
+        round_compute<S, CB, 0, A, false, true>(x, w0, m, il);
       else
-        round_compute<S, CB, 0, A, false, false>(x, wv, m, il);
+        round_compute<S, CB, 0, A, false, false>(x, w0, m, il);
 #pragma unroll
       for (int i = 0; i < kE; ++i) {
         u64 v = x[i];
@@ -710,8 +740,7 @@ static hipError_t launch_top(int S, u64* out, const u64* in, const ulonglong2* t
 // `n_strided` register-only passes), then a bottom tile_pass of `bottom` stages;
 // `tl` = log2 of the tile size both tile passes use.
 struct Plan {
-  int tl;      // tile size (log2) of the bottom pass
-  int tl_top;  // tile size of the top tile pass (0: same as tl)
+  int tl;      // tile size (log2) of the tile passes
   int top_tile;
   int n_strided;
   int strided[8];
@@ -735,19 +764,6 @@ static Plan make_plan(int L) {
   if (L <= 12) {  // one kernel, one HBM round trip
     p.tl = L <= 10 ? 10 : 12;
     p.bottom = L;
-    return p;
-  }
-  static const bool wave9 = [] {
-    const char* e = getenv("HEXL_AMD_PLAN");
-    return e && strcmp(e, "wave9") == 0;
-  }();
-  if (wave9 && L >= 16 && L <= 17) {
-    // experiment: 7/8-stage top on 4096-element tiles + 9-stage bottom on
-    // 512-element tiles (one wave per tile: no workgroup barrier at all)
-    p.tl = 9;
-    p.tl_top = 12;
-    p.bottom = 9;
-    p.top_tile = L - 9;
     return p;
   }
   if (plan_strided_requested() && L >= 13) {
@@ -796,7 +812,6 @@ template <bool FWD, class A>
 static hipError_t launch_bottom_tl(int tl, int S, u64* out, const u64* in, const ulonglong2* tw,
                                    const ModConst& m, u32 log_n, u32 finish, u64 batch,
                                    const InvLast& il, hipStream_t st) {
-  if (tl == 9) return launch_bottom<FWD, 9, A>(S, out, in, tw, m, log_n, finish, batch, il, st);
   if (tl == 10) return launch_bottom<FWD, 10, A>(S, out, in, tw, m, log_n, finish, batch, il, st);
   return launch_bottom<FWD, 12, A>(S, out, in, tw, m, log_n, finish, batch, il, st);
 }
@@ -810,7 +825,7 @@ static hipError_t forward_seq(const NttTables& t, const Plan& p, u64* result, co
   hipError_t e;
   u32 first = kFirstPass;  // consumed by whichever pass runs first
   if (p.top_tile) {
-    e = launch_top_tl<true, A>(p.tl_top ? p.tl_top : p.tl, p.top_tile, result, src, t.fwd, t.mod,
+    e = launch_top_tl<true, A>(p.tl, p.top_tile, result, src, t.fwd, t.mod,
                                t.log_n, first, batch, il, st);
     if (e != hipSuccess) return e;
     src = result;
@@ -846,7 +861,7 @@ static hipError_t inverse_seq(const NttTables& t, const Plan& p, u64* result, co
     if (e != hipSuccess) return e;
   }
   if (p.top_tile)
-    return launch_top_tl<false, A>(p.tl_top ? p.tl_top : p.tl, p.top_tile, result, result, t.inv,
+    return launch_top_tl<false, A>(p.tl, p.top_tile, result, result, t.inv,
                                    t.mod, t.log_n, fin, batch, t.inv_last, st);
   return hipSuccess;
 }

@@ -81,8 +81,7 @@ struct ModConst {
   u32 fin_shift;  // floor(log2 q)
 };
 
-#if !defined(__HIP_DEVICE_COMPILE__)
-inline ModConst make_mod_const(u64 q) {
+inline ModConst make_mod_const(u64 q) {  // host only
   ModConst m;
   m.q = q;
   m.two_q = q << 1;
@@ -94,7 +93,6 @@ inline ModConst make_mod_const(u64 q) {
   m.fin_mul = (u32)((((unsigned __int128)1) << (31 + b)) / q);
   return m;
 }
-#endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define HX_OPAQUE(v) asm("" : "+v"(v))

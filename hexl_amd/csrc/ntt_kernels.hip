@@ -79,6 +79,16 @@ extern "C" int hexl_amd_debug_set_phase_buf(void* buf) {
 constexpr u32 kFinishMask = 3;
 constexpr u32 kFirstPass = 4;
 
+// Global access as wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte
+// offset: `global_load/store v, v_off, s[base]`, no 64-bit vector address math and
+// no address registers kept live between the load and the in-place store.
+__device__ __forceinline__ u64 load_global(const u64* uniform_base, u32 byte_off) {
+  return *reinterpret_cast<const u64*>(reinterpret_cast<const char*>(uniform_base) + byte_off);
+}
+__device__ __forceinline__ void store_global(u64* uniform_base, u32 byte_off, u64 v) {
+  *reinterpret_cast<u64*>(reinterpret_cast<char*>(uniform_base) + byte_off) = v;
+}
+
 // ---------------------------------------------------------------------------
 // Register subtrees
 // ---------------------------------------------------------------------------
@@ -167,9 +177,95 @@ __device__ __forceinline__ void inv_subtree(u64* x, const ulonglong2* wv, const 
                                     k);
         }
       }
+      // Deep subtrees: stop the scheduler from interleaving every butterfly of a
+      // stage (it would keep all their temporaries live at once and spill).
+      if (R >= 4) __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (A::kLazy && !LAST) InvLadder<R, 0, A>::run(x, m);
+}
+
+// One level of a subtree on its own, groups [G0, G1): used by the 5-stage strided
+// pass, which fetches its 31 wave-uniform twiddles in four batches of <= 8 (each
+// requested one batch ahead of its use) because all of them at once do not fit
+// the SGPR file.
+template <int R, int V, int G0, int G1, class A>
+__device__ __forceinline__ void fwd_level(u64* x, const ulonglong2* wl, const ModConst& m) {
+  constexpr int half = 1 << (R - 1 - V);
+#pragma unroll
+  for (int g = G0; g < G1; ++g)
+#pragma unroll
+    for (int j = 0; j < half; ++j)
+      fwd_butterfly<A>(x[g * 2 * half + j], x[g * 2 * half + j + half], wl[g - G0].x, wl[g - G0].y,
+                       m);
+}
+
+// Inverse level V at lazy depth K; BOUND as in inv_butterfly; LAST folds N^-1 in
+// (then V == 0).
+template <int R, int V, int G0, int G1, class A, bool BOUND, bool LAST>
+__device__ __forceinline__ void inv_level(u64* x, const ulonglong2* wl, const ModConst& m,
+                                          const InvLast& il, int k) {
+  constexpr int half = 1 << (R - 1 - V);
+#pragma unroll
+  for (int g = G0; g < G1; ++g)
+#pragma unroll
+    for (int j = 0; j < half; ++j) {
+      u64& a = x[g * 2 * half + j];
+      u64& b = x[g * 2 * half + j + half];
+      if (LAST)
+        inv_butterfly_last<A>(a, b, il.n1, il.n1p, il.n1w, il.n1wp, m, k);
+      else
+        inv_butterfly<A, BOUND>(a, b, wl[g - G0].x, wl[g - G0].y, m, k);
+    }
+}
+
+template <int COUNT>
+__device__ __forceinline__ void load_twiddle_run(ulonglong2* w, const ulonglong2* __restrict__ tw,
+                                                 u32 first) {
+#pragma unroll
+  for (int i = 0; i < COUNT; ++i) w[i] = tw[first + i];
+}
+
+// The 5-stage subtrees of the strided pass, twiddles streamed (see fwd_level).
+template <class A>
+__device__ __forceinline__ void fwd_subtree5_streamed(u64* x, const ulonglong2* __restrict__ tw,
+                                                      u32 node, const ModConst& m) {
+  ulonglong2 w0, w1[2], w2[4], w3[8], w4a[8], w4b[8];
+  load_twiddle_run<1>(&w0, tw, node);
+  load_twiddle_run<2>(w1, tw, node << 1);
+  load_twiddle_run<4>(w2, tw, node << 2);
+  load_twiddle_run<8>(w3, tw, node << 3);
+  fwd_level<5, 0, 0, 1, A>(x, &w0, m);
+  fwd_level<5, 1, 0, 2, A>(x, w1, m);
+  fwd_level<5, 2, 0, 4, A>(x, w2, m);
+  load_twiddle_run<8>(w4a, tw, node << 4);
+  fwd_level<5, 3, 0, 8, A>(x, w3, m);
+  load_twiddle_run<8>(w4b, tw, (node << 4) + 8);
+  fwd_level<5, 4, 0, 8, A>(x, w4a, m);
+  fwd_level<5, 4, 8, 16, A>(x, w4b, m);
+}
+
+template <class A, bool LAST>
+__device__ __forceinline__ void inv_subtree5_streamed(u64* x, const ulonglong2* __restrict__ tw,
+                                                      u32 node, const ModConst& m,
+                                                      const InvLast& il) {
+  // Lazy: the first stage bounds its sums (a lazy run is at most 4 stages deep),
+  // the remaining four run at depths 0..3.
+  constexpr bool kB = A::kLazy;
+  ulonglong2 w0, w1[2], w2[4], w3[8], w4a[8], w4b[8];
+  load_twiddle_run<8>(w4a, tw, node << 4);
+  load_twiddle_run<8>(w4b, tw, (node << 4) + 8);
+  inv_level<5, 4, 0, 8, A, kB, false>(x, w4a, m, il, 0);
+  load_twiddle_run<8>(w3, tw, node << 3);
+  inv_level<5, 4, 8, 16, A, kB, false>(x, w4b, m, il, 0);
+  load_twiddle_run<4>(w2, tw, node << 2);
+  load_twiddle_run<2>(w1, tw, node << 1);
+  load_twiddle_run<1>(&w0, tw, node);
+  inv_level<5, 3, 0, 8, A, false, false>(x, w3, m, il, 0);
+  inv_level<5, 2, 0, 4, A, false, false>(x, w2, m, il, 1);
+  inv_level<5, 1, 0, 2, A, false, false>(x, w1, m, il, 2);
+  inv_level<5, 0, 0, 1, A, false, LAST>(x, &w0, m, il, 3);
+  if (A::kLazy && !LAST) InvLadder<5, 0, A>::run(x, m);
 }
 
 // ---------------------------------------------------------------------------
@@ -179,63 +275,85 @@ __device__ __forceinline__ void inv_subtree(u64* x, const ulonglong2* wv, const 
 // S = N >> (a0 + R); element e of the item is at b*N + (h*2^R + e)*S + c.
 // Lanes map to consecutive columns: every access is a coalesced 512-byte wave
 // access and the twiddles are wave-uniform (scalar loads).
-template <bool FWD, int R, class A>
-__global__ void __launch_bounds__(256)
+// Occupancy floor (workgroups of 4 waves per CU = waves per SIMD): the data alone
+// is 2 * 2^R VGPRs, so 4 waves/SIMD (<= 128 VGPRs) is the most a 5-stage subtree
+// can have; shallower ones get 6.
+template <int R>
+constexpr int strided_min_waves() { return R >= 5 ? 4 : 6; }
+
+// LAST (inverse only): the pass contains the root stage of the transform (a0 == 0).
+template <bool FWD, int R, class A, bool LAST>
+__global__ void __launch_bounds__(256, (strided_min_waves<R>()))
 strided_pass(u64* __restrict__ out, const u64* __restrict__ in,
              const ulonglong2* __restrict__ tw, ModConst m, u32 log_n, u32 a0, u32 flags,
              u64 items, InvLast il) {
   constexpr int E = 1 << R;
   const u32 finish = flags & kFinishMask;
-  const u64 wi = (u64)blockIdx.x * 256 + threadIdx.x;
-  if (wi >= items) return;
+  // items is a multiple of 64 (>= 64 columns per subtree): waves are whole, and a
+  // wave covers 64 adjacent columns of ONE subtree, so everything but the lane's
+  // column offset is wave-uniform, in particular the twiddles (scalar loads into
+  // SGPRs).
+  // XCD-aware block order: the dispatcher deals consecutive workgroups round-robin
+  // to the 8 XCDs; remapped, each XCD walks one contiguous eighth of the work, so
+  // the rows it has open in HBM are few and long (measured: 0.79 -> 0.71 ms at full
+  // occupancy; without it the pass only reaches 0.70 ms when occupancy is throttled
+  // to 2 waves per SIMD).
+  u32 bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  if ((u64)bid * 256 + threadIdx.x >= items) return;
+  const u32 lane = threadIdx.x & 63;
+  const u64 wi = __builtin_amdgcn_readfirstlane(bid * 4 + (threadIdx.x >> 6));  // wave index
   const u32 log_s = log_n - a0 - R;
-  const u64 b = wi >> (log_n - R);
-  const u32 rem = (u32)(wi & ((1ull << (log_n - R)) - 1));
+  const u32 log_wpp = log_n - R - 6;  // log2(waves per polynomial)
+  const u64 b = wi >> log_wpp;
+  const u32 rem = ((u32)wi & ((1u << log_wpp) - 1)) << 6;  // first work item of the wave
   const u32 h = rem >> log_s;
-  const u32 c = rem & ((1u << log_s) - 1);
-  const u64 base = (b << log_n) + ((u64)h << (log_s + R)) + c;
-  u32 node = (1u << a0) + h;
-  // all lanes of a wave share h when a wave spans <= S columns
-  if (log_s >= 6) node = __builtin_amdgcn_readfirstlane(node);
+  const u32 c0 = rem & ((1u << log_s) - 1);
+  const u64 base = (b << log_n) + ((u64)h << (log_s + R)) + c0;
+  const u64 vbase = base + lane;  // (SGPR base + 32-bit lane offset measured 3% slower here)
+  const u32 node = (1u << a0) + h;
   ulonglong2 wv[E];
-  load_twiddles<R>(wv, tw, node);
+  if constexpr (R < 5) load_twiddles<R>(wv, tw, node);
 
   u64 x[E];
 #pragma unroll
-  for (int e = 0; e < E; ++e) x[e] = in[base + ((u64)e << log_s)];
+  for (int e = 0; e < E; ++e) x[e] = in[vbase + ((u64)e << log_s)];
   if (flags & kFirstPass) {
 #pragma unroll
     for (int e = 0; e < E; ++e) x[e] = to_internal<A>(x[e]);
   }
 
   if (FWD) {
-    fwd_subtree<R, A>(x, wv, m);
+    if constexpr (R < 5)
+      fwd_subtree<R, A>(x, wv, m);
+    else
+      fwd_subtree5_streamed<A>(x, tw, node, m);
     if (finish) {
 #pragma unroll
       for (int e = 0; e < E; ++e) x[e] = fwd_finish<A>(x[e], m, finish == 2);
     }
   } else {
-    if (a0 == 0) {
-      inv_subtree<R, A, true>(x, wv, m, il);
-    } else {
-      inv_subtree<R, A, false>(x, wv, m, il);
-    }
+    if constexpr (R < 5)
+      inv_subtree<R, A, LAST>(x, wv, m, il);
+    else
+      inv_subtree5_streamed<A, LAST>(x, tw, node, m, il);
     if (finish) {
 #pragma unroll
       for (int e = 0; e < E; ++e) x[e] = inv_finish<A>(x[e], m, finish == 2);
     }
   }
 #pragma unroll
-  for (int e = 0; e < E; ++e) out[base + ((u64)e << log_s)] = x[e];
+  for (int e = 0; e < E; ++e) out[vbase + ((u64)e << log_s)] = x[e];
 }
 
 // ---------------------------------------------------------------------------
 // tile_pass: S stages on a 4096-element tile staged through LDS
 // ---------------------------------------------------------------------------
-// Tile size is a template parameter TL (log2 elements): 10 -> 1024 elements
-// (8 KiB of LDS, 128 threads = 2 waves, 16 workgroups per CU) for N <= 2^16, 12 ->
-// 4096 elements (32 KiB, 512 threads, 4 workgroups per CU) for larger N.  Either
-// way a thread holds 8 elements, a round is 3 stages, and 32 waves fit a CU.
+// Tile size is a template parameter TL (log2 elements): 10 -> 1024 elements (8 KiB
+// of LDS, 128 threads = 2 waves, 16 workgroups per CU) for N <= 2^10, 11 -> 2048
+// elements for the 11-stage bottom pass of N = 2^13..2^16, 12 -> 4096 elements
+// (32 KiB, 512 threads, 4 workgroups per CU) otherwise.  Either way a thread holds
+// 8 elements, a round is 3 stages, and 32 waves fit a CU.
 #ifndef HEXL_AMD_RE
 #define HEXL_AMD_RE 3
 #endif
@@ -310,12 +428,6 @@ template <int CB>
 __device__ __forceinline__ u64 tile_uniform_offset(const TileGeom& g, u32 dp) {
   if (CB == 0) return g.base + dp;
   return g.base + ((u64)(dp >> CB) << g.log_row);
-}
-__device__ __forceinline__ u64 load_global(const u64* uniform_base, u32 byte_off) {
-  return *reinterpret_cast<const u64*>(reinterpret_cast<const char*>(uniform_base) + byte_off);
-}
-__device__ __forceinline__ void store_global(u64* uniform_base, u32 byte_off, u64 v) {
-  *reinterpret_cast<u64*>(reinterpret_cast<char*>(uniform_base) + byte_off) = v;
 }
 
 // Twiddles of round j for every sub-run this thread owns in that round.
@@ -554,7 +666,8 @@ __device__ __forceinline__ void store_elem(u64* __restrict__ out, u32 tid, int i
 template <int S, int CB>
 constexpr int min_waves() { return (S >= 10 || CB > 0) ? 8 : 6; }
 
-template <bool FWD, int S, int CB, int TL, bool GUARD, class A>
+// LAST (inverse only): the pass contains the root stage of the transform.
+template <bool FWD, int S, int CB, int TL, bool GUARD, class A, bool LAST>
 __global__ void __launch_bounds__(1 << (TL - kRE), (min_waves<S, CB>()))
 tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* __restrict__ tw,
           ModConst m, u32 log_n, u32 flags, u64 total, InvLast il) {
@@ -564,7 +677,9 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
   const bool first = (flags & kFirstPass) != 0;
   __shared__ u64 lds[1 << TL];
   const u32 tid = threadIdx.x;
-  const TileGeom g = make_geom<S, CB, TL>(blockIdx.x, log_n);
+  // (The XCD-aware block order of strided_pass was measured here too: 2-7 % slower.)
+  const u32 bid = blockIdx.x;
+  const TileGeom g = make_geom<S, CB, TL>(bid, log_n);
   u64 x[kE];
   HX_STAMP(0);
 
@@ -614,10 +729,7 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
     {
       if constexpr (!RD::pre_inv(0)) round_twiddles<S, CB, TL, 0>(w0, tw, tid, g);
       lds_load_round<S, CB, TL, 0>(x, lds, tid);
-      if (g.a0 == 0)
-        round_compute<S, CB, 0, A, false, true>(x, w0, m, il);
-      else
-        round_compute<S, CB, 0, A, false, false>(x, w0, m, il);
+      round_compute<S, CB, 0, A, false, LAST>(x, w0, m, il);
 #pragma unroll
       for (int i = 0; i < kE; ++i) {
         u64 v = x[i];
@@ -638,11 +750,16 @@ static hipError_t launch_strided(int R, u64* out, const u64* in, const ulonglong
                                  const InvLast& il, hipStream_t st) {
   const u64 items = batch << (log_n - R);
   const unsigned grid = (unsigned)((items + 255) / 256);
+  if (log_n < a0 + (u32)R + 6) return hipErrorInvalidValue;  // needs >= 64 columns per subtree
   ScopedKernelTimer timer(FWD ? "ntt_fwd_strided_pass" : "ntt_inv_strided_pass", st);
-#define HX_LAUNCH_S(RR)                                                                  \
-  case RR:                                                                               \
-    hipLaunchKernelGGL((strided_pass<FWD, RR, A>), dim3(grid), dim3(256), 0, st, out, in, \
-                       tw, m, log_n, a0, finish, items, il);                             \
+#define HX_LAUNCH_S(RR)                                                                   \
+  case RR:                                                                                \
+    if (!FWD && a0 == 0)                                                                  \
+      hipLaunchKernelGGL((strided_pass<FWD, RR, A, !FWD>), dim3(grid), dim3(256), 0, st, \
+                         out, in, tw, m, log_n, a0, finish, items, il);                   \
+    else                                                                                  \
+      hipLaunchKernelGGL((strided_pass<FWD, RR, A, false>), dim3(grid), dim3(256), 0, st, \
+                         out, in, tw, m, log_n, a0, finish, items, il);                   \
     break;
   switch (R) {
     HX_LAUNCH_S(1)
@@ -666,20 +783,24 @@ static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2
   const unsigned grid = (unsigned)((total + (1u << TL) - 1) >> TL);
   const bool guard = (total & ((1u << TL) - 1)) != 0;  // the batch ends inside the last tile
   ScopedKernelTimer timer(FWD ? "ntt_fwd_tile_pass_bottom" : "ntt_inv_tile_pass_bottom", st);
+#define HX_LAUNCH_B2(T, G, LST)                                                           \
+  hipLaunchKernelGGL((tile_pass<FWD, T, 0, TL, G, A, LST>), dim3(grid), dim3(1 << (TL - kRE)), \
+                     0, st, out, in, tw, m, log_n, finish, total, il)
 #define HX_LAUNCH_B(T)                                                                    \
   case T:                                                                                 \
-    if constexpr (T <= TL && (TL <= 10 || T >= 9))                                        \
-    {                                                                                     \
-      if (guard)                                                                          \
-        hipLaunchKernelGGL((tile_pass<FWD, T, 0, TL, true, A>), dim3(grid),               \
-                           dim3(1 << (TL - kRE)), 0, st, out, in, tw, m, log_n, finish,   \
-                           total, il);                                 \
-      else                                                                                \
-        hipLaunchKernelGGL((tile_pass<FWD, T, 0, TL, false, A>), dim3(grid),              \
-                           dim3(1 << (TL - kRE)), 0, st, out, in, tw, m, log_n, finish,   \
-                           total, il);                                 \
-    }                                                                                     \
-    else                                                                                  \
+    if constexpr (T <= TL && (TL <= 10 || T >= 9) && (TL != 11 || T == 11)) {             \
+      if (!FWD && (u32)T == log_n) {                                                      \
+        if (guard)                                                                        \
+          HX_LAUNCH_B2(T, true, !FWD);                                                    \
+        else                                                                              \
+          HX_LAUNCH_B2(T, false, !FWD);                                                   \
+      } else {                                                                            \
+        if (guard)                                                                        \
+          HX_LAUNCH_B2(T, true, false);                                                   \
+        else                                                                              \
+          HX_LAUNCH_B2(T, false, false);                                                  \
+      }                                                                                   \
+    } else                                                                                \
       return hipErrorInvalidValue;                                                        \
     break;
   switch (S) {
@@ -699,6 +820,7 @@ static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2
       return hipErrorInvalidValue;
   }
 #undef HX_LAUNCH_B
+#undef HX_LAUNCH_B2
   return hipGetLastError();
 }
 
@@ -714,7 +836,7 @@ static hipError_t launch_top(int S, u64* out, const u64* in, const ulonglong2* t
 #define HX_LAUNCH_T(T)                                                                      \
   case T:                                                                                   \
     if constexpr (T <= TL - 4 && (TL == 10 || T >= 7))                                      \
-      hipLaunchKernelGGL((tile_pass<FWD, T, TL - T, TL, false, A>), dim3(grid),             \
+      hipLaunchKernelGGL((tile_pass<FWD, T, TL - T, TL, false, A, !FWD>), dim3(grid),       \
                          dim3(1 << (TL - kRE)), 0, st, out, in, tw, m, log_n, finish, total, \
                          il);                                                               \
     else                                                                                    \
@@ -747,10 +869,9 @@ struct Plan {
   int bottom;
 };
 
-// Default for N >= 2^13: register-only strided pass(es) + a 12-stage bottom
-// tile_pass.  HEXL_AMD_PLAN=tiled selects two LDS-tiled kernels instead (6 + 10
-// stages on 1024-element tiles for N = 2^16); measured within 2% of each other
-// on MI355X, see DESIGN.md.
+// Default for N >= 2^13: register-only strided pass(es) + an 11- or 12-stage
+// bottom tile_pass.  HEXL_AMD_PLAN=tiled selects two LDS-tiled kernels instead
+// (6 + 10 stages on 1024-element tiles for N = 2^16); slower, see DESIGN.md.
 static bool plan_strided_requested() {
   static const bool v = [] {
     const char* e = getenv("HEXL_AMD_PLAN");
@@ -767,15 +888,17 @@ static Plan make_plan(int L) {
     return p;
   }
   if (plan_strided_requested() && L >= 13) {
-    p.tl = 12;
-    p.bottom = 12;
-    // experiment knob: HEXL_AMD_BOTTOM=9..12 stages for the bottom tile_pass
+    // 11 bottom stages on 2048-element tiles up to N = 2^16 (strided pass of <= 5
+    // stages: both kernels then carry a comparable share of the arithmetic), 12 on
+    // 4096-element tiles above.  HEXL_AMD_BOTTOM=11|12 overrides (A/B runs).
+    p.bottom = L <= 16 ? 11 : 12;
     static const int bottom_override = [] {
       const char* e = getenv("HEXL_AMD_BOTTOM");
       return e ? atoi(e) : 0;
     }();
-    if (bottom_override >= 9 && bottom_override <= 12 && L - bottom_override >= 1)
+    if ((bottom_override == 11 || bottom_override == 12) && L - bottom_override >= 1)
       p.bottom = bottom_override;
+    p.tl = p.bottom;
     int top = L - p.bottom;
     if (top <= 5) {
       p.strided[p.n_strided++] = top;
@@ -813,6 +936,7 @@ static hipError_t launch_bottom_tl(int tl, int S, u64* out, const u64* in, const
                                    const ModConst& m, u32 log_n, u32 finish, u64 batch,
                                    const InvLast& il, hipStream_t st) {
   if (tl == 10) return launch_bottom<FWD, 10, A>(S, out, in, tw, m, log_n, finish, batch, il, st);
+  if (tl == 11) return launch_bottom<FWD, 11, A>(S, out, in, tw, m, log_n, finish, batch, il, st);
   return launch_bottom<FWD, 12, A>(S, out, in, tw, m, log_n, finish, batch, il, st);
 }
 

@@ -1,0 +1,30 @@
+#!/bin/bash
+# tools/collect_profiles.sh -- run ON THE GPU BOX (gpurun): collects the rocprofv3
+# evidence behind bench.py's roofline block into gpurun_out/prof/ .
+#   1. kernel trace + stats of the default bench command
+#   2. PMC passes (each counter set in its own run, --pmc only, as the gfx950 guide
+#      prescribes): FETCH_SIZE, WRITE_SIZE, SQ issue counters, LDS counters
+#   3. the same FETCH/WRITE passes over tools/ubench's copy kernels (known traffic)
+#      to calibrate the counters
+# Summarise afterwards with tools/summarize_profiles.py (runs anywhere).
+set -u
+REPO=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$REPO/gpurun_out/prof
+rm -rf "$OUT"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- \
+  python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_under_trace.json 2> $OUT/trace.log
+run_pmc() {  # name, counters..., then -- command
+  local name=$1; shift
+  local ctr=()
+  while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
+  rocprofv3 --pmc "${ctr[@]}" --output-format csv -d $OUT/$name -o p -- "$@" > /dev/null 2> $OUT/$name.log
+}
+run_pmc fetch FETCH_SIZE -- $BENCH
+run_pmc write WRITE_SIZE -- $BENCH
+run_pmc sq SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY -- $BENCH
+run_pmc lds SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -- $BENCH
+run_pmc cal_fetch FETCH_SIZE -- $REPO/tools/ubench
+run_pmc cal_write WRITE_SIZE -- $REPO/tools/ubench
+ls -R $OUT | head -50

@@ -1,0 +1,104 @@
+"""Turn gpurun_out/prof/ (tools/collect_profiles.sh) into the committed summaries:
+
+    profiles/r1_kernel_stats.csv   rocprofv3 --stats per-kernel table
+    profiles/r1_pmc_summary.md     counters per dispatch, HBM traffic vs algorithmic
+    profiles/r1_hbm_traffic.json   HBM bytes per launch, read by bench.py
+
+HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE counts
+streaming reads at half their size (calibrated below on copy kernels of known
+traffic, as MI355X_MICROARCH.md prescribes), WRITE_SIZE is exact.
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof")
+DST = os.path.join(ROOT, "profiles")
+N, BATCH = 65536, 4096
+ALG = 16.0 * N * BATCH
+
+
+def counters(name):
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(SRC, name, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+
+
+def short(k):
+    k = k.replace("hexl_amd::", "")
+    return k.split("(")[0]
+
+
+def family(k):
+    fwd = "<true" in k
+    if "strided_pass" in k:
+        return "ntt_fwd_strided_pass" if fwd else "ntt_inv_strided_pass"
+    if "tile_pass" in k:
+        return "ntt_fwd_tile_pass_bottom" if fwd else "ntt_inv_tile_pass_bottom"
+    return None
+
+
+def main():
+    stats = glob.glob(os.path.join(SRC, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], os.path.join(DST, "r1_kernel_stats.csv"))
+    fetch, write = counters("fetch"), counters("write")
+    calf, calw = counters("cal_fetch"), counters("cal_write")
+    sq, lds = counters("sq"), counters("lds")
+    out = ["# Round-1 PMC summary (rocprofv3 --pmc, separate passes; averages per dispatch)", "",
+           "Collected by `tools/collect_profiles.sh`, summarised by `tools/summarize_profiles.py`.",
+           "Command: `rocprofv3 --pmc <counters> -- python bench.py --steps 3 --warmup 1 "
+           "--no-cpu-baseline` (N=65536, 55-bit q, batch 4096; plan = strided_pass<4> + "
+           "tile_pass<12 stages>).", "",
+           "## HBM traffic calibration (tools/ubench copy kernels: exactly 2 GiB read + 2 GiB "
+           "written per launch)", "",
+           "| kernel | counter | avg per dispatch (KB) | true KB | factor |", "|---|---|---|---|---|"]
+    for cal, cname in ((calf, "FETCH_SIZE"), (calw, "WRITE_SIZE")):
+        for k, d in cal.items():
+            if "copy" in k and cname in d:
+                out.append(f"| {short(k)} | {cname} | {d[cname]:.1f} | 2097152 | "
+                           f"{2097152 / d[cname]:.3f} |")
+    out += ["", "HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.", "",
+            "## NTT kernels", "",
+            "| kernel | FETCH_SIZE (KB) | WRITE_SIZE (KB) | HBM bytes/launch (corrected) | "
+            "algorithmic bytes/launch | ratio |", "|---|---|---|---|---|---|"]
+    traffic, fam = {}, {}
+    for k in fetch:
+        if family(k) is None or k not in write:
+            continue
+        f, w = fetch[k]["FETCH_SIZE"], write[k]["WRITE_SIZE"]
+        hbm = (2 * f + w) * 1024
+        traffic[short(k)] = hbm
+        fam[family(k)] = hbm
+        out.append(f"| {short(k)} | {f:.0f} | {w:.0f} | {hbm:.4g} | {ALG:.4g} | {hbm / ALG:.4f} |")
+    out += ["", "## SQ / LDS counters", "", "| kernel | counter | avg per dispatch |", "|---|---|---|"]
+    for table in (sq, lds):
+        for k, d in table.items():
+            if family(k) is None:
+                continue
+            for c in sorted(d):
+                out.append(f"| {short(k)} | {c} | {d[c]:.4g} |")
+    out += ["", "Derived (per dispatch): VALU instructions per wave = SQ_INSTS_VALU / SQ_WAVES; "
+            "average shader clock = GRBM_GUI_ACTIVE / kernel duration.", ""]
+    for k, d in sq.items():
+        if family(k) and d.get("SQ_WAVES"):
+            out.append(f"- {short(k)}: {d['SQ_INSTS_VALU'] / d['SQ_WAVES']:.0f} VALU instructions "
+                       f"per wave, {d['SQ_WAVES']:.0f} waves")
+    open(os.path.join(DST, "r1_pmc_summary.md"), "w").write("\n".join(out) + "\n")
+    json.dump({"source": "profiles/r1_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+               "separate passes, FETCH_SIZE x2 gfx950 correction)",
+               "hbm_bytes_per_launch": traffic, "by_bench_kernel_family": fam,
+               "workload": f"N={N}, q=18014398510661633, batch={BATCH} (bench.py default), one launch"},
+              open(os.path.join(DST, "r1_hbm_traffic.json"), "w"), indent=1)
+    print("\n".join(out[-12:]))
+
+
+if __name__ == "__main__":
+    sys.exit(main())

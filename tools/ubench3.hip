@@ -1,7 +1,9 @@
 // ubench3.hip -- ALU-only cost of the register subtrees (no memory, no LDS):
-// cycles per wave-butterfly for the forward / inverse subtree of depth R under
-// the Strict and Lazy arithmetic policies at 4 and 8 waves per SIMD.  This is
-// the instruction-issue roofline of the NTT kernels.
+// wall-clock nanoseconds of SIMD time per wave-butterfly for the forward /
+// inverse subtree of depth R under the Strict and Lazy arithmetic policies at
+// 1..8 waves per SIMD.  This is the instruction-issue roofline of the NTT
+// kernels.  (s_memtime ticks are printed too, but the counter does not run at
+// the shader clock: only the wall-clock figure is a rate.)
 // Build: hipcc --offload-arch=gfx950 -O3 -Ihexl_amd/csrc tools/ubench3.hip -o tools/ubench3
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -21,7 +23,7 @@ using namespace hexl_amd;
     }                                                                           \
   } while (0)
 
-constexpr int TRIPS = 64;
+constexpr int TRIPS = 256;
 
 template <int R, class A, bool FWD>
 __global__ void __launch_bounds__(256) k(u64* out, const ulonglong2* tw, ModConst m, u64* cyc) {
@@ -69,15 +71,25 @@ static void run(const char* name, const ulonglong2* tw, ModConst m) {
     CK(hipMalloc(&cyc, (size_t)blocks * 8));
     k<R, A, FWD><<<blocks, 256>>>(out, tw, m, cyc);
     CK(hipDeviceSynchronize());
-    k<R, A, FWD><<<blocks, 256>>>(out, tw, m, cyc);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    for (int rep = 0; rep < 4; ++rep) k<R, A, FWD><<<blocks, 256>>>(out, tw, m, cyc);
+    CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= 4;
     std::vector<u64> h(blocks);
     CK(hipMemcpy(h.data(), cyc, blocks * 8, hipMemcpyDeviceToHost));
     double avg = 0;
     for (auto v : h) avg += v;
     avg /= blocks;
     const double bfly = (double)TRIPS * R * (1 << (R - 1));
-    printf("  w%d: %6.1f cyc/bfly/wave (%5.1f per SIMD)", wps, avg / bfly, avg / bfly / wps);
+    // waves per SIMD = wps, 1024 SIMDs: SIMD-ns per wave-butterfly
+    const double ns = ms * 1e6 / (bfly * wps);
+    printf("  w%d: %5.1f ns/bfly/SIMD (%5.1f ticks/wave)", wps, ns, avg / bfly);
     CK(hipFree(out));
     CK(hipFree(cyc));
   }
@@ -86,7 +98,7 @@ static void run(const char* name, const ulonglong2* tw, ModConst m) {
 
 int main() {
   const u64 q = 18014398510661633ull;
-  ModConst m{q, 2 * q, 0 - q, (u64)((((unsigned __int128)1) << 64) / q)};
+  const ModConst m = make_mod_const(q);
   std::vector<ulonglong2> h(64 * 16);
   for (size_t i = 0; i < h.size(); ++i) {
     u64 W = (0x9E3779B97F4A7C15ull * (i + 1)) % q;

@@ -55,8 +55,8 @@ def main():
     out = ["# Round-1 PMC summary (rocprofv3 --pmc, separate passes; averages per dispatch)", "",
            "Collected by `tools/collect_profiles.sh`, summarised by `tools/summarize_profiles.py`.",
            "Command: `rocprofv3 --pmc <counters> -- python bench.py --steps 3 --warmup 1 "
-           "--no-cpu-baseline` (N=65536, 55-bit q, batch 4096; plan = strided_pass<4> + "
-           "tile_pass<12 stages>).", "",
+           "--no-cpu-baseline` (N=65536, 55-bit q, batch 4096; default plan = strided_pass<5 "
+           "stages> + tile_pass<11 stages on 2048-element tiles>).", "",
            "## HBM traffic calibration (tools/ubench copy kernels: exactly 2 GiB read + 2 GiB "
            "written per launch)", "",
            "| kernel | counter | avg per dispatch (KB) | true KB | factor |", "|---|---|---|---|---|"]

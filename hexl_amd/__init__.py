@@ -28,7 +28,8 @@ _LIB_PATH = os.environ.get("HEXL_AMD_LIB") or os.path.join(_HERE, "lib", "libhex
 
 __all__ = [
     "NTT", "EltwiseAddMod", "EltwiseSubMod", "EltwiseMultMod", "EltwiseFMAMod",
-    "EltwiseReduceMod", "EltwiseReduceFMAMod", "HexlAmdError", "lib", "LIB_PATH",
+    "EltwiseReduceMod", "EltwiseReduceFMAMod", "EltwiseCmpAdd", "EltwiseCmpSubMod", "CMPINT",
+    "HexlAmdError", "lib", "LIB_PATH",
     "MinimalPrimitiveRoot", "GeneratePrimes", "IsPrime", "InverseMod", "MultiplyMod",
     "PowMod", "IsPrimitiveRoot", "ReverseBits", "MultiplyFactor", "fill_splitmix",
     "from_numpy", "to_numpy",
@@ -79,6 +80,9 @@ def _load():
     sig("hexl_amd_eltwise_reduce_mod", ci, p64, p64, u64, u64, u64, u64, vp)
     sig("hexl_amd_eltwise_reduce_fma_mod", ci, p64, p64, u64, p64, u64, u64, u64, vp)
     sig("hexl_amd_eltwise_host", ci, ci, p64, p64, p64, u64, u64, u64, u64, u64)
+    sig("hexl_amd_eltwise_cmp_add", ci, p64, p64, u64, ci, u64, u64, vp)
+    sig("hexl_amd_eltwise_cmp_sub_mod", ci, p64, p64, u64, u64, ci, u64, u64, vp)
+    sig("hexl_amd_eltwise_cmp_host", ci, p64, p64, u64, u64, ci, u64, u64)
     sig("hexl_amd_multiply_factor", u64, u64, u64, u64)
     sig("hexl_amd_inverse_mod", u64, u64, u64)
     sig("hexl_amd_multiply_mod", u64, u64, u64, u64)
@@ -111,6 +115,7 @@ C_ABI_SYMBOLS = [
     "hexl_amd_eltwise_add_mod", "hexl_amd_eltwise_add_mod_scalar", "hexl_amd_eltwise_sub_mod",
     "hexl_amd_eltwise_sub_mod_scalar", "hexl_amd_eltwise_mult_mod", "hexl_amd_eltwise_fma_mod",
     "hexl_amd_eltwise_reduce_mod", "hexl_amd_eltwise_reduce_fma_mod", "hexl_amd_eltwise_host",
+    "hexl_amd_eltwise_cmp_add", "hexl_amd_eltwise_cmp_sub_mod", "hexl_amd_eltwise_cmp_host",
     "hexl_amd_multiply_factor", "hexl_amd_inverse_mod", "hexl_amd_multiply_mod",
     "hexl_amd_pow_mod", "hexl_amd_is_primitive_root", "hexl_amd_generate_primitive_root",
     "hexl_amd_minimal_primitive_root", "hexl_amd_reverse_bits", "hexl_amd_is_prime",
@@ -356,6 +361,23 @@ def EltwiseFMAMod(result, arg1, arg2, arg3, n, modulus, input_mod_factor):
 def EltwiseReduceMod(result, operand, n, modulus, input_mod_factor, output_mod_factor):
     _check(lib.hexl_amd_eltwise_reduce_mod(_ptr(result), _ptr(operand), n, modulus,
                                            input_mod_factor, output_mod_factor, _stream()))
+
+
+class CMPINT:
+    """hexl/include/hexl/util/util.hpp:16-25."""
+    EQ, LT, LE, FALSE, NE, NLT, NLE, TRUE = range(8)
+
+
+def EltwiseCmpAdd(result, operand1, n, cmp, bound, diff):
+    """hexl/include/hexl/eltwise/eltwise-cmp-add.hpp:24-25."""
+    _check(lib.hexl_amd_eltwise_cmp_add(_ptr(result), _ptr(operand1), n, int(cmp), bound, diff,
+                                        _stream()))
+
+
+def EltwiseCmpSubMod(result, operand1, n, modulus, cmp, bound, diff):
+    """hexl/include/hexl/eltwise/eltwise-cmp-sub-mod.hpp:26-28."""
+    _check(lib.hexl_amd_eltwise_cmp_sub_mod(_ptr(result), _ptr(operand1), n, modulus, int(cmp),
+                                            bound, diff, _stream()))
 
 
 def EltwiseReduceFMAMod(result, arg1, arg2, arg3, n, modulus, input_mod_factor):

@@ -382,7 +382,8 @@ static int check_elt(EltOp op, const EltArgs& g) {
   if ((op == ELT_ADD || op == ELT_SUB || op == ELT_MULT) && !g.b)
     return fail(HEXL_AMD_ERR_INVALID_ARG, "operand2 == nullptr");
   if (g.n == 0) return fail(HEXL_AMD_ERR_INVALID_ARG, "n == 0");
-  if (g.q <= 1) return fail(HEXL_AMD_ERR_INVALID_ARG, "modulus must be > 1");
+  if (op != ELT_CMP_ADD && g.q <= 1)
+    return fail(HEXL_AMD_ERR_INVALID_ARG, "modulus must be > 1");
   switch (op) {
     case ELT_ADD:
     case ELT_SUB:
@@ -412,6 +413,13 @@ static int check_elt(EltOp op, const EltArgs& g) {
       break;
     case ELT_REDUCE_FMA:
       if (g.q >= (1ull << 61)) return fail(HEXL_AMD_ERR_INVALID_ARG, "modulus must be < 2^61");
+      break;
+    case ELT_CMP_ADD:
+    case ELT_CMP_SUB_MOD:
+      if (g.cmp < 0 || g.cmp > 7) return fail(HEXL_AMD_ERR_INVALID_ARG, "cmp must be a CMPINT (0..7)");
+      if (g.scalar == 0) return fail(HEXL_AMD_ERR_INVALID_ARG, "diff == 0");
+      if (op == ELT_CMP_SUB_MOD && g.scalar >= g.q)
+        return fail(HEXL_AMD_ERR_INVALID_ARG, "diff must be < modulus");
       break;
   }
   return HEXL_AMD_OK;
@@ -461,12 +469,46 @@ int hexl_amd_eltwise_reduce_fma_mod(uint64_t* result, const uint64_t* arg1, uint
   return elt_run(ELT_FMA, EltArgs{result, arg1, arg3, arg2, n, q, in_mf, 1}, stream);
 }
 
+static EltArgs cmp_args(uint64_t* result, const uint64_t* a, uint64_t n, uint64_t q, int cmp,
+                        uint64_t bound, uint64_t diff) {
+  EltArgs g{result, a, nullptr, diff, n, q, 1, 1};
+  g.cmp = cmp;
+  g.bound = bound;
+  return g;
+}
+int hexl_amd_eltwise_cmp_add(uint64_t* result, const uint64_t* operand1, uint64_t n, int cmp,
+                             uint64_t bound, uint64_t diff, void* stream) {
+  return elt_run(ELT_CMP_ADD, cmp_args(result, operand1, n, 0, cmp, bound, diff), stream);
+}
+int hexl_amd_eltwise_cmp_sub_mod(uint64_t* result, const uint64_t* operand1, uint64_t n,
+                                 uint64_t q, int cmp, uint64_t bound, uint64_t diff,
+                                 void* stream) {
+  return elt_run(ELT_CMP_SUB_MOD, cmp_args(result, operand1, n, q, cmp, bound, diff), stream);
+}
+
+static int eltwise_host_run(EltOp op, EltArgs g, uint64_t* result, const uint64_t* operand1,
+                            const uint64_t* operand2);
+
+int hexl_amd_eltwise_cmp_host(uint64_t* result, const uint64_t* operand1, uint64_t n,
+                              uint64_t q, int cmp, uint64_t bound, uint64_t diff) {
+  const EltOp op = q == 0 ? ELT_CMP_ADD : ELT_CMP_SUB_MOD;
+  return eltwise_host_run(op, cmp_args(result, operand1, n, q, cmp, bound, diff), result,
+                          operand1, nullptr);
+}
+
 int hexl_amd_eltwise_host(int op, uint64_t* result, const uint64_t* operand1,
                           const uint64_t* operand2, uint64_t scalar, uint64_t n, uint64_t q,
                           uint64_t in_mf, uint64_t out_mf) {
   if (op < 0 || op > 6) return fail(HEXL_AMD_ERR_INVALID_ARG, "unknown eltwise op %d", op);
-  EltArgs g{result, operand1, operand2, scalar, n, q, in_mf, out_mf};
-  if (int rc = check_elt((EltOp)op, g)) return rc;
+  return eltwise_host_run((EltOp)op, EltArgs{result, operand1, operand2, scalar, n, q, in_mf, out_mf},
+                          result, operand1, operand2);
+}
+
+// host buffers: stage to the device, run the kernel, copy the result back
+static int eltwise_host_run(EltOp op, EltArgs g, uint64_t* result, const uint64_t* operand1,
+                            const uint64_t* operand2) {
+  if (int rc = check_elt(op, g)) return rc;
+  const uint64_t n = g.n;
   int device = 0;
   HX_HIP(hipGetDevice(&device));
   const size_t bytes = (size_t)n * sizeof(u64);
@@ -480,7 +522,7 @@ int hexl_amd_eltwise_host(int op, uint64_t* result, const uint64_t* operand1,
   g.result = da;
   g.a = da;
   g.b = db;
-  hipError_t e = eltwise_launch((EltOp)op, g, st);
+  hipError_t e = eltwise_launch(op, g, st);
   if (e != hipSuccess) return hip_fail(e, "eltwise launch");
   HX_HIP(hipMemcpyAsync(result, da, bytes, hipMemcpyDeviceToHost, st));
   HX_HIP(hipStreamSynchronize(st));

@@ -8,6 +8,8 @@
 //   EltwiseMultMod    hexl/eltwise/eltwise-mult-mod-internal.hpp:34-100
 //   EltwiseFMAMod     hexl/eltwise/eltwise-fma-mod-internal.hpp:12-39
 //   EltwiseReduceMod  hexl/eltwise/eltwise-reduce-mod.cpp:16-123
+//   EltwiseCmpAdd     hexl/eltwise/eltwise-cmp-add.cpp:16-106
+//   EltwiseCmpSubMod  hexl/eltwise/eltwise-cmp-sub-mod.cpp:18-66
 // Algorithmic bytes per element: 24 (two inputs + one output) or 16.
 #include <hip/hip_runtime.h>
 
@@ -115,6 +117,47 @@ struct ReduceFmaOp {
   __device__ __forceinline__ u64 operator()(u64 a, u64 c) const {
     u64 r = csub(mul_lazy(full(a), s, sp, q), q);
     if (HAS_C) r = csub(r + full(c), q);
+    return r;
+  }
+};
+
+// CMPINT (hexl/include/hexl/util/util.hpp:16-25) and Compare
+// (hexl/util/util-internal.hpp:16-41).  `cmp` is uniform: the switch is scalar.
+__device__ __forceinline__ bool compare_cmpint(int cmp, u64 lhs, u64 rhs) {
+  switch (cmp) {
+    case 0: return lhs == rhs;
+    case 1: return lhs < rhs;
+    case 2: return lhs <= rhs;
+    case 3: return false;
+    case 4: return lhs != rhs;
+    case 5: return lhs >= rhs;
+    case 6: return lhs > rhs;
+    default: return true;
+  }
+}
+// eltwise-cmp-add.cpp:32-106: plain 64-bit addition where the comparison holds
+struct CmpAddOp {
+  u64 bound, diff;
+  int cmp;
+  __device__ __forceinline__ u64 operator()(u64 a, u64) const {
+    return compare_cmpint(cmp, a, bound) ? a + diff : a;
+  }
+};
+// eltwise-cmp-sub-mod.cpp:47-66: the comparison sees the unreduced word; the
+// word is then reduced with a true `% modulus` (any modulus > 1, any 64-bit
+// input: single-word Barrett with floor(2^64/m) is off by at most one) and diff
+// subtracted as SubUIntMod does (number-theory.cpp:68-73, same wrapping
+// expression).
+struct CmpSubModOp {
+  u64 m, barrett, bound, diff;
+  int cmp;
+  __device__ __forceinline__ u64 operator()(u64 a, u64) const {
+    u64 r = a - __umul64hi(a, barrett) * m;
+    r = r >= m ? r - m : r;
+    if (compare_cmpint(cmp, a, bound)) {
+      const u64 d = (r + m) - diff;
+      r = d >= m ? d - m : d;
+    }
     return r;
   }
 };
@@ -227,6 +270,11 @@ hipError_t eltwise_launch(EltOp op, const EltArgs& g, hipStream_t st) {
         return run<ReduceFmaOp<true>, true>(g, g.b, ReduceFmaOp<true>{q, s, sp, bar}, st);
       return run<ReduceFmaOp<false>, false>(g, nullptr, ReduceFmaOp<false>{q, s, sp, bar}, st);
     }
+    case ELT_CMP_ADD:
+      return run<CmpAddOp, false>(g, nullptr, CmpAddOp{g.bound, g.scalar, g.cmp}, st);
+    case ELT_CMP_SUB_MOD:
+      return run<CmpSubModOp, false>(
+          g, nullptr, CmpSubModOp{q, host_floor_2_64_over(1, q), g.bound, g.scalar, g.cmp}, st);
   }
   return hipErrorInvalidValue;
 }

@@ -268,5 +268,25 @@ void EltwiseReduceMod(uint64_t* result, const uint64_t* operand, uint64_t n, uin
                                 output_mod_factor));
 }
 
+void EltwiseCmpAdd(uint64_t* result, const uint64_t* operand1, uint64_t n, CMPINT cmp,
+                   uint64_t bound, uint64_t diff) {
+  if (on_device(result, operand1, nullptr))
+    check(hexl_amd_eltwise_cmp_add(result, operand1, n, static_cast<int>(cmp), bound, diff,
+                                   nullptr));
+  else
+    check(hexl_amd_eltwise_cmp_host(result, operand1, n, 0, static_cast<int>(cmp), bound, diff));
+}
+
+void EltwiseCmpSubMod(uint64_t* result, const uint64_t* operand1, uint64_t n, uint64_t modulus,
+                      CMPINT cmp, uint64_t bound, uint64_t diff) {
+  if (modulus <= 1) throw std::runtime_error("EltwiseCmpSubMod: modulus must be > 1");
+  if (on_device(result, operand1, nullptr))
+    check(hexl_amd_eltwise_cmp_sub_mod(result, operand1, n, modulus, static_cast<int>(cmp), bound,
+                                       diff, nullptr));
+  else
+    check(hexl_amd_eltwise_cmp_host(result, operand1, n, modulus, static_cast<int>(cmp), bound,
+                                    diff));
+}
+
 }  // namespace hexl
 }  // namespace intel

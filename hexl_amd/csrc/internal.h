@@ -73,7 +73,9 @@ enum EltOp {
   ELT_MULT = 4,
   ELT_FMA = 5,
   ELT_REDUCE = 6,
-  ELT_REDUCE_FMA = 7
+  ELT_REDUCE_FMA = 7,
+  ELT_CMP_ADD = 8,
+  ELT_CMP_SUB_MOD = 9
 };
 
 struct EltArgs {
@@ -85,6 +87,8 @@ struct EltArgs {
   u64 q;
   u64 in_mf;
   u64 out_mf;
+  int cmp = 0;    // CMPINT of the cmp_* ops (their `diff` travels in `scalar`)
+  u64 bound = 0;
 };
 
 hipError_t eltwise_launch(EltOp op, const EltArgs& args, hipStream_t st);

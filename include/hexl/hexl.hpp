@@ -4,6 +4,8 @@
 #pragma once
 
 #include "hexl/eltwise/eltwise-add-mod.hpp"
+#include "hexl/eltwise/eltwise-cmp-add.hpp"
+#include "hexl/eltwise/eltwise-cmp-sub-mod.hpp"
 #include "hexl/eltwise/eltwise-fma-mod.hpp"
 #include "hexl/eltwise/eltwise-mult-mod.hpp"
 #include "hexl/eltwise/eltwise-reduce-mod.hpp"

@@ -188,6 +188,25 @@ int hexl_amd_eltwise_reduce_fma_mod(uint64_t* result, const uint64_t* arg1,
                                     uint64_t n, uint64_t modulus,
                                     uint64_t input_mod_factor, void* stream);
 
+/* EltwiseCmpAdd: result[i] = cmp(operand1[i], bound) ? operand1[i] + diff :
+ * operand1[i], plain 64-bit addition
+ * (hexl/include/hexl/eltwise/eltwise-cmp-add.hpp:24-25;
+ * hexl/eltwise/eltwise-cmp-add.cpp:16-106).  `cmp` is the reference's CMPINT
+ * value (hexl/include/hexl/util/util.hpp:16-25): 0 EQ, 1 LT, 2 LE, 3 FALSE,
+ * 4 NE, 5 NLT, 6 NLE, 7 TRUE.  n != 0, diff != 0. */
+int hexl_amd_eltwise_cmp_add(uint64_t* result, const uint64_t* operand1,
+                             uint64_t n, int cmp, uint64_t bound,
+                             uint64_t diff, void* stream);
+
+/* EltwiseCmpSubMod: result[i] = cmp(operand1[i], bound) ?
+ * (operand1[i] mod modulus - diff) mod modulus : operand1[i] mod modulus
+ * (hexl/include/hexl/eltwise/eltwise-cmp-sub-mod.hpp:26-28;
+ * hexl/eltwise/eltwise-cmp-sub-mod.cpp:18-66).  Any modulus > 1 (not
+ * necessarily prime), arbitrary 64-bit operands, 0 < diff < modulus. */
+int hexl_amd_eltwise_cmp_sub_mod(uint64_t* result, const uint64_t* operand1,
+                                 uint64_t n, uint64_t modulus, int cmp,
+                                 uint64_t bound, uint64_t diff, void* stream);
+
 /* Host-pointer forms for the intel::hexl::Eltwise* shim (synchronous).
  * `op`: 0 add, 1 add_scalar, 2 sub, 3 sub_scalar, 4 mult, 5 fma, 6 reduce.
  * Unused operands are NULL / 0. */
@@ -196,6 +215,12 @@ int hexl_amd_eltwise_host(int op, uint64_t* result, const uint64_t* operand1,
                           uint64_t n, uint64_t modulus,
                           uint64_t input_mod_factor,
                           uint64_t output_mod_factor);
+
+/* Host-pointer forms of the two comparison ops (synchronous).  `modulus` == 0
+ * selects EltwiseCmpAdd, anything else EltwiseCmpSubMod. */
+int hexl_amd_eltwise_cmp_host(uint64_t* result, const uint64_t* operand1,
+                              uint64_t n, uint64_t modulus, int cmp,
+                              uint64_t bound, uint64_t diff);
 
 /* ---------------------------------------------------------------------------
  * Host-side scalar number theory the plan builder uses; exported because it

@@ -528,6 +528,51 @@ void ho_eltwise_reduce_mod(uint64_t* result, const uint64_t* operand,
   }
 }
 
+/* hexl/include/hexl/util/util.hpp:16-25 enum class CMPINT and
+ * hexl/util/util-internal.hpp:16-41 Compare(): EQ 0, LT 1, LE 2, FALSE 3, NE 4,
+ * NLT 5, NLE 6, TRUE 7 (anything else: true, :39-40). */
+static int compare_cmpint(int cmp, uint64_t lhs, uint64_t rhs) {
+  switch (cmp) {
+    case 0: return lhs == rhs;
+    case 1: return lhs < rhs;
+    case 2: return lhs <= rhs;
+    case 3: return 0;
+    case 4: return lhs != rhs;
+    case 5: return lhs >= rhs;
+    case 6: return lhs > rhs;
+    case 7: return 1;
+  }
+  return 1;
+}
+
+/* hexl/eltwise/eltwise-cmp-add.cpp:32-106 EltwiseCmpAddNative:
+ * result[i] = cmp(operand1[i], bound) ? operand1[i] + diff : operand1[i]
+ * (plain 64-bit addition, no modulus). */
+void ho_eltwise_cmp_add(uint64_t* result, const uint64_t* operand1, uint64_t n,
+                        int cmp, uint64_t bound, uint64_t diff) {
+  for (uint64_t i = 0; i < n; ++i) {
+    uint64_t op = operand1[i];
+    result[i] = compare_cmpint(cmp, op, bound) ? op + diff : op;
+  }
+}
+
+/* hexl/eltwise/eltwise-cmp-sub-mod.cpp:47-66 EltwiseCmpSubModNative: the
+ * comparison sees the unreduced word, the word is then reduced with a true
+ * `% modulus` (:60) and diff is subtracted mod modulus where the comparison
+ * held (SubUIntMod, number-theory.cpp:68-73).  modulus > 1 (any value, not
+ * necessarily prime), 0 < diff < modulus. */
+void ho_eltwise_cmp_sub_mod(uint64_t* result, const uint64_t* operand1,
+                            uint64_t n, uint64_t modulus, int cmp,
+                            uint64_t bound, uint64_t diff) {
+  for (uint64_t i = 0; i < n; ++i) {
+    uint64_t op = operand1[i];
+    int op_cmp = compare_cmpint(cmp, op, bound);
+    op %= modulus;
+    if (op_cmp) op = ho_sub_uint_mod(op, diff, modulus);
+    result[i] = op;
+  }
+}
+
 /* ------------------------------------------------------------------------ */
 /* Convenience used by tests / bench: a complete plan in one allocation.     */
 /* ------------------------------------------------------------------------ */

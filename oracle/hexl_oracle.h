@@ -66,6 +66,11 @@ void ho_eltwise_mult_mod(uint64_t* result, const uint64_t* a,
 void ho_eltwise_fma_mod(uint64_t* result, const uint64_t* arg1, uint64_t arg2,
                         const uint64_t* arg3, uint64_t n, uint64_t q,
                         uint64_t in_mf);
+void ho_eltwise_cmp_add(uint64_t* result, const uint64_t* operand1, uint64_t n,
+                        int cmp, uint64_t bound, uint64_t diff);
+void ho_eltwise_cmp_sub_mod(uint64_t* result, const uint64_t* operand1,
+                            uint64_t n, uint64_t modulus, int cmp,
+                            uint64_t bound, uint64_t diff);
 void ho_eltwise_reduce_mod(uint64_t* result, const uint64_t* operand,
                            uint64_t n, uint64_t q, uint64_t in_mf,
                            uint64_t out_mf);

@@ -65,6 +65,8 @@ def _load():
     sig("ho_eltwise_mult_mod", None, p64, p64, p64, u64, u64, u64)
     sig("ho_eltwise_fma_mod", None, p64, p64, u64, p64, u64, u64, u64)
     sig("ho_eltwise_reduce_mod", None, p64, p64, u64, u64, u64, u64)
+    sig("ho_eltwise_cmp_add", None, p64, p64, u64, C.c_int, u64, u64)
+    sig("ho_eltwise_cmp_sub_mod", None, p64, p64, u64, u64, C.c_int, u64, u64)
     sig("ho_ntt_create", C.c_void_p, u64, u64, u64)
     sig("ho_ntt_destroy", None, C.c_void_p)
     sig("ho_ntt_forward_batch", None, C.c_void_p, p64, p64, u64, u64, u64)
@@ -223,6 +225,25 @@ def eltwise_fma_mod(a, s, c, q, in_mf=1):
         c = _arr(c)
         cp = _p(c)
     lib.ho_eltwise_fma_mod(_p(out), _p(a), int(s), cp, a.size, q, in_mf)
+    return out
+
+
+# CMPINT (hexl/include/hexl/util/util.hpp:16-25)
+CMPINT = {"EQ": 0, "LT": 1, "LE": 2, "FALSE": 3, "NE": 4, "NLT": 5, "NLE": 6, "TRUE": 7}
+
+
+def eltwise_cmp_add(a, cmp, bound, diff):
+    a = _arr(a)
+    out = np.empty_like(a)
+    lib.ho_eltwise_cmp_add(_p(out), _p(a), a.size, int(cmp), int(bound), int(diff))
+    return out
+
+
+def eltwise_cmp_sub_mod(a, modulus, cmp, bound, diff):
+    a = _arr(a)
+    out = np.empty_like(a)
+    lib.ho_eltwise_cmp_sub_mod(_p(out), _p(a), a.size, int(modulus), int(cmp), int(bound),
+                               int(diff))
     return out
 
 

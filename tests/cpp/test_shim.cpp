@@ -231,7 +231,24 @@ static void test_eltwise() {
     EltwiseSubMod(r.data(), a.data(), 3, 8, 10);
     EXPECT((r == V{8, 9, 0, 1, 2, 3, 4, 5}));
   }
+  {  // ExampleEltwiseCmpAdd / ExampleEltwiseCmpSubMod (example/example.cpp:56-85) and
+     // TEST_P(EltwiseCmpAddTest / EltwiseCmpSubModTest, Native) NE rows, in place
+    V op1{1, 2, 3, 4, 5, 6, 7, 8};
+    EltwiseCmpAdd(op1.data(), op1.data(), op1.size(), CMPINT::NLE, 3, 5);
+    EXPECT((op1 == V{1, 2, 3, 9, 10, 11, 12, 13}));
+    V op2{1, 2, 3, 4, 5, 6, 7};
+    EltwiseCmpSubMod(op2.data(), op2.data(), op2.size(), 10, CMPINT::NLE, 4, 5);
+    EXPECT((op2 == V{1, 2, 3, 4, 0, 1, 2}));
+    V op3{1, 2, 3, 4, 5, 6, 7}, r(7);
+    EltwiseCmpAdd(r.data(), op3.data(), 7, CMPINT::NE, 4, 5);
+    EXPECT((r == V{6, 7, 8, 4, 10, 11, 12}));
+    EltwiseCmpSubMod(r.data(), op3.data(), 7, 10, CMPINT::NE, 4, 5);
+    EXPECT((r == V{6, 7, 8, 4, 0, 1, 2}));
+    EXPECT(Not(CMPINT::LT) == CMPINT::NLT && Not(CMPINT::TRUE) == CMPINT::FALSE);
+  }
   V z(4);
+  EXPECT_THROW(EltwiseCmpAdd(z.data(), z.data(), 4, CMPINT::EQ, 1, 0));
+  EXPECT_THROW(EltwiseCmpSubMod(z.data(), z.data(), 4, 10, CMPINT::EQ, 1, 0));
   EXPECT_THROW(EltwiseMultMod(z.data(), z.data(), z.data(), 4, 769, 3));
   EXPECT_THROW(EltwiseFMAMod(z.data(), z.data(), 1, nullptr, 4, 1ULL << 61, 1));
 }

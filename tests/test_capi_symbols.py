@@ -51,6 +51,10 @@ def test_shim_library_exports_reference_api():
                    "unsigned long, unsigned long)",
                    "intel::hexl::EltwiseSubMod(", "intel::hexl::EltwiseMultMod(",
                    "intel::hexl::EltwiseFMAMod(", "intel::hexl::EltwiseReduceMod(",
+                   "intel::hexl::EltwiseCmpAdd(unsigned long*, unsigned long const*, unsigned long, "
+                   "intel::hexl::CMPINT, unsigned long, unsigned long)",
+                   "intel::hexl::EltwiseCmpSubMod(unsigned long*, unsigned long const*, unsigned "
+                   "long, unsigned long, intel::hexl::CMPINT, unsigned long, unsigned long)",
                    "intel::hexl::MinimalPrimitiveRoot(", "intel::hexl::GeneratePrimes(",
                    "intel::hexl::IsPrime(", "intel::hexl::InverseMod(", "intel::hexl::PowMod(",
                    "intel::hexl::ReverseBits(", "intel::hexl::mallocStrategy"):

@@ -485,3 +485,74 @@ def test_eltwise_argument_errors(hx):
         hx.EltwiseReduceMod(x, x, 8, 769, 3, 1)
     with pytest.raises(hx.HexlAmdError):
         hx.EltwiseAddMod(x, x, x, 0, 769)
+
+
+# ---------------------------------------------------------------- EltwiseCmpAdd / EltwiseCmpSubMod
+@pytest.mark.parametrize("case", KAT["eltwise_cmp_add"]["cases"], ids=lambda c: c["cmp"])
+def test_cmp_add_kat(hx, ho, case):
+    """TEST_P(EltwiseCmpAddTest, Native), test/test-eltwise-cmp-add.cpp:45-78 (in place)."""
+    da = dev(hx, case["a"])
+    hx.EltwiseCmpAdd(da, da, len(case["a"]), ho.CMPINT[case["cmp"]], case["bound"], case["diff"])
+    assert host(hx, da).tolist() == case["out"]
+
+
+@pytest.mark.parametrize("case", KAT["eltwise_cmp_sub_mod"]["cases"],
+                         ids=lambda c: f"{c['cmp']}_{c['q']}")
+def test_cmp_sub_mod_kat(hx, ho, case):
+    """TEST_P(EltwiseCmpSubModTest, Native), test/test-eltwise-cmp-sub-mod.cpp:49-88."""
+    da = dev(hx, case["a"])
+    hx.EltwiseCmpSubMod(da, da, len(case["a"]), case["q"], ho.CMPINT[case["cmp"]], case["bound"],
+                        case["diff"])
+    assert host(hx, da).tolist() == case["out"]
+
+
+@pytest.mark.parametrize("cmp", range(8))
+def test_cmp_ops_random_vs_oracle(hx, ho, cmp):
+    """The reference's randomized cross-checks (test/test-eltwise-cmp-add-avx512.cpp:22-52,
+    test-eltwise-cmp-sub-mod-avx512.cpp:54-89): lengths 1025 / 172, moduli 100 and 48..51-bit
+    primes; plus arbitrary 64-bit words, composite and > 2^62 moduli, misaligned and
+    out-of-place buffers."""
+    import torch
+    rng = np.random.default_rng(100 + cmp)
+    for trial in range(6):
+        m = 100
+        a = rng.integers(0, m, 1025, dtype=np.uint64)
+        bound, diff = int(rng.integers(0, m)), int(rng.integers(1, m))
+        da = dev(hx, a)
+        out = torch.zeros_like(da)
+        hx.EltwiseCmpAdd(out, da, a.size, cmp, bound, diff)
+        assert np.array_equal(host(hx, out), ho.eltwise_cmp_add(a, cmp, bound, diff))
+    for bits in (48, 49, 50, 51):
+        m = ho.generate_primes(1, bits, True, 1024)[0]
+        a = rng.integers(0, m, 172, dtype=np.uint64)
+        bound, diff = int(rng.integers(0, m)), int(rng.integers(1, m - 1))
+        da = dev(hx, a)
+        hx.EltwiseCmpSubMod(da, da, a.size, m, cmp, bound, diff)
+        assert np.array_equal(host(hx, da), ho.eltwise_cmp_sub_mod(a, m, cmp, bound, diff))
+    for m in (2, 10, 4294967296, 1152921504606748673, (1 << 62) + 135, (1 << 63) + 29):
+        a = rng.integers(0, 1 << 64, 1031, dtype=np.uint64)
+        a[:4] = [0, m - 1, m, (1 << 64) - 1]
+        bound = int(a[9])
+        diff = 1 if m == 2 else int(rng.integers(1, m - 1, dtype=np.uint64))
+        buf = dev(hx, np.concatenate([U([0]), a]))  # operand starts 8 bytes off 16-byte alignment
+        src = buf[1:]
+        out = torch.zeros(a.size + 1, dtype=src.dtype, device=src.device)[1:]
+        hx.EltwiseCmpSubMod(out, src, a.size, m, cmp, bound, diff)
+        assert np.array_equal(host(hx, out), ho.eltwise_cmp_sub_mod(a, m, cmp, bound, diff))
+        hx.EltwiseCmpAdd(out, src, a.size, cmp, bound, diff)
+        assert np.array_equal(host(hx, out), ho.eltwise_cmp_add(a, cmp, bound, diff))
+
+
+def test_cmp_ops_reject_bad_arguments(hx):
+    """HEXL_CHECKs of eltwise-cmp-add.cpp:18-21 / eltwise-cmp-sub-mod.cpp:21-25,52-57."""
+    da = dev(hx, [1, 2, 3, 4])
+    with pytest.raises(hx.HexlAmdError):
+        hx.EltwiseCmpAdd(da, da, 0, 0, 1, 1)            # n == 0
+    with pytest.raises(hx.HexlAmdError):
+        hx.EltwiseCmpAdd(da, da, 4, 0, 1, 0)            # diff == 0
+    with pytest.raises(hx.HexlAmdError):
+        hx.EltwiseCmpSubMod(da, da, 4, 1, 0, 1, 1)      # modulus <= 1
+    with pytest.raises(hx.HexlAmdError):
+        hx.EltwiseCmpSubMod(da, da, 4, 10, 0, 1, 10)    # diff >= modulus
+    with pytest.raises(hx.HexlAmdError):
+        hx.EltwiseCmpSubMod(da, da, 4, 10, 8, 1, 1)     # not a CMPINT

@@ -302,3 +302,40 @@ def test_nt_generate_primes():
                 assert (1 << bit_size) <= p <= (1 << (bit_size + 1))
     for c in KAT["generate_primes_survey_probe"]["cases"]:
         assert ho.generate_primes(*c["args"]) == c["out"]
+
+
+# ---------------------------------------------------------------- EltwiseCmpAdd / EltwiseCmpSubMod
+@pytest.mark.parametrize("case", KAT["eltwise_cmp_add"]["cases"], ids=lambda c: c["cmp"])
+def test_cmp_add_kat(case):
+    got = ho.eltwise_cmp_add(case["a"], ho.CMPINT[case["cmp"]], case["bound"], case["diff"])
+    assert got.tolist() == case["out"]
+
+
+@pytest.mark.parametrize("case", KAT["eltwise_cmp_sub_mod"]["cases"],
+                         ids=lambda c: f"{c['cmp']}_{c['q']}")
+def test_cmp_sub_mod_kat(case):
+    got = ho.eltwise_cmp_sub_mod(case["a"], case["q"], ho.CMPINT[case["cmp"]], case["bound"],
+                                 case["diff"])
+    assert got.tolist() == case["out"]
+
+
+def test_cmp_ops_against_python_ints():
+    """Independent model in Python integers over arbitrary 64-bit words, composite and
+    prime moduli (hexl/eltwise/eltwise-cmp-sub-mod.cpp:58-64, eltwise-cmp-add.cpp:40-103)."""
+    rng = np.random.default_rng(5)
+    py_cmp = [lambda a, b: a == b, lambda a, b: a < b, lambda a, b: a <= b, lambda a, b: False,
+              lambda a, b: a != b, lambda a, b: a >= b, lambda a, b: a > b, lambda a, b: True]
+    for m in (2, 10, 769, 4294967296, 1152921504606748673, (1 << 62) + 135):
+        a = rng.integers(0, 1 << 64, 257, dtype=np.uint64)
+        a[:4] = [0, m - 1, m, (1 << 64) - 1]
+        bound = int(a[7])
+        diff = 1 + int(rng.integers(0, m - 1, dtype=np.uint64)) if m > 2 else 1
+        for cmp in range(8):
+            got = ho.eltwise_cmp_sub_mod(a, m, cmp, bound, diff).tolist()
+            want = [((int(x) % m) - diff) % m if py_cmp[cmp](int(x), bound) else int(x) % m
+                    for x in a]
+            assert got == want
+            got = ho.eltwise_cmp_add(a, cmp, bound, diff).tolist()
+            want = [(int(x) + diff) % (1 << 64) if py_cmp[cmp](int(x), bound) else int(x)
+                    for x in a]
+            assert got == want

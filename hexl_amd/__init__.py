@@ -28,7 +28,7 @@ _LIB_PATH = os.environ.get("HEXL_AMD_LIB") or os.path.join(_HERE, "lib", "libhex
 
 __all__ = [
     "NTT", "EltwiseAddMod", "EltwiseSubMod", "EltwiseMultMod", "EltwiseFMAMod",
-    "EltwiseReduceMod", "EltwiseReduceFMAMod", "EltwiseCmpAdd", "EltwiseCmpSubMod", "CMPINT",
+    "EltwiseReduceMod", "EltwiseReduceFMAMod", "EltwiseCmpAdd", "EltwiseCmpSubMod", "CMPINT", "DyadicMultiply",
     "HexlAmdError", "lib", "LIB_PATH",
     "MinimalPrimitiveRoot", "GeneratePrimes", "IsPrime", "InverseMod", "MultiplyMod",
     "PowMod", "IsPrimitiveRoot", "ReverseBits", "MultiplyFactor", "fill_splitmix",
@@ -80,6 +80,8 @@ def _load():
     sig("hexl_amd_eltwise_reduce_mod", ci, p64, p64, u64, u64, u64, u64, vp)
     sig("hexl_amd_eltwise_reduce_fma_mod", ci, p64, p64, u64, p64, u64, u64, u64, vp)
     sig("hexl_amd_eltwise_host", ci, ci, p64, p64, p64, u64, u64, u64, u64, u64)
+    sig("hexl_amd_dyadic_multiply", ci, p64, p64, p64, u64, C.POINTER(u64), u64, vp)
+    sig("hexl_amd_dyadic_multiply_host", ci, p64, p64, p64, u64, C.POINTER(u64), u64)
     sig("hexl_amd_eltwise_cmp_add", ci, p64, p64, u64, ci, u64, u64, vp)
     sig("hexl_amd_eltwise_cmp_sub_mod", ci, p64, p64, u64, u64, ci, u64, u64, vp)
     sig("hexl_amd_eltwise_cmp_host", ci, p64, p64, u64, u64, ci, u64, u64)
@@ -116,6 +118,7 @@ C_ABI_SYMBOLS = [
     "hexl_amd_eltwise_sub_mod_scalar", "hexl_amd_eltwise_mult_mod", "hexl_amd_eltwise_fma_mod",
     "hexl_amd_eltwise_reduce_mod", "hexl_amd_eltwise_reduce_fma_mod", "hexl_amd_eltwise_host",
     "hexl_amd_eltwise_cmp_add", "hexl_amd_eltwise_cmp_sub_mod", "hexl_amd_eltwise_cmp_host",
+    "hexl_amd_dyadic_multiply", "hexl_amd_dyadic_multiply_host",
     "hexl_amd_multiply_factor", "hexl_amd_inverse_mod", "hexl_amd_multiply_mod",
     "hexl_amd_pow_mod", "hexl_amd_is_primitive_root", "hexl_amd_generate_primitive_root",
     "hexl_amd_minimal_primitive_root", "hexl_amd_reverse_bits", "hexl_amd_is_prime",
@@ -361,6 +364,14 @@ def EltwiseFMAMod(result, arg1, arg2, arg3, n, modulus, input_mod_factor):
 def EltwiseReduceMod(result, operand, n, modulus, input_mod_factor, output_mod_factor):
     _check(lib.hexl_amd_eltwise_reduce_mod(_ptr(result), _ptr(operand), n, modulus,
                                            input_mod_factor, output_mod_factor, _stream()))
+
+
+def DyadicMultiply(result, operand1, operand2, n, moduli):
+    """hexl/include/hexl/experimental/seal/dyadic-multiply.hpp:26-28; `moduli` is a host
+    sequence of integers."""
+    arr = (C.c_uint64 * len(moduli))(*[int(m) for m in moduli])
+    _check(lib.hexl_amd_dyadic_multiply(_ptr(result), _ptr(operand1), _ptr(operand2), n, arr,
+                                        len(moduli), _stream()))
 
 
 class CMPINT:

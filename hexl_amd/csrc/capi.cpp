@@ -529,6 +529,59 @@ static int eltwise_host_run(EltOp op, EltArgs g, uint64_t* result, const uint64_
   return HEXL_AMD_OK;
 }
 
+// ------------------------------------------------------------------ DyadicMultiply
+
+static int check_dyadic(const uint64_t* result, const uint64_t* a, const uint64_t* b, uint64_t n,
+                        const uint64_t* moduli, uint64_t num_moduli) {
+  if (!result) return fail(HEXL_AMD_ERR_INVALID_ARG, "result == nullptr");
+  if (!a) return fail(HEXL_AMD_ERR_INVALID_ARG, "operand1 == nullptr");
+  if (!b) return fail(HEXL_AMD_ERR_INVALID_ARG, "operand2 == nullptr");
+  if (!moduli) return fail(HEXL_AMD_ERR_INVALID_ARG, "moduli == nullptr");
+  if (n == 0) return fail(HEXL_AMD_ERR_INVALID_ARG, "n == 0");
+  for (uint64_t i = 0; i < num_moduli; ++i)
+    if (moduli[i] <= 1 || moduli[i] >= (1ull << 62))
+      return fail(HEXL_AMD_ERR_INVALID_ARG, "moduli[%llu] must be in (1, 2^62)",
+                  (unsigned long long)i);
+  return HEXL_AMD_OK;
+}
+
+int hexl_amd_dyadic_multiply(uint64_t* result, const uint64_t* operand1, const uint64_t* operand2,
+                             uint64_t n, const uint64_t* moduli, uint64_t num_moduli,
+                             void* stream) {
+  if (int rc = check_dyadic(result, operand1, operand2, n, moduli, num_moduli)) return rc;
+  if (num_moduli == 0) return HEXL_AMD_OK;
+  hipError_t e = dyadic_multiply_launch(result, operand1, operand2, n, moduli, num_moduli,
+                                        (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "dyadic multiply launch");
+  return HEXL_AMD_OK;
+}
+
+int hexl_amd_dyadic_multiply_host(uint64_t* result, const uint64_t* operand1,
+                                  const uint64_t* operand2, uint64_t n, const uint64_t* moduli,
+                                  uint64_t num_moduli) {
+  if (int rc = check_dyadic(result, operand1, operand2, n, moduli, num_moduli)) return rc;
+  if (num_moduli == 0) return HEXL_AMD_OK;
+  int device = 0;
+  HX_HIP(hipGetDevice(&device));
+  const size_t poly = (size_t)n * num_moduli * sizeof(u64);
+  // layout of the staging buffer: x (2 polys) | y (2 polys) | result (3 polys)
+  if (int rc = g_staging.ensure(device, 7 * poly)) return rc;
+  u64* dx = (u64*)g_staging.buf;
+  u64* dy = dx + 2 * n * num_moduli;
+  u64* dr = dy + 2 * n * num_moduli;
+  hipStream_t st = g_staging.stream;
+  HX_HIP(hipMemcpyAsync(dx, operand1, 2 * poly, hipMemcpyHostToDevice, st));
+  HX_HIP(hipMemcpyAsync(dy, operand2, 2 * poly, hipMemcpyHostToDevice, st));
+  // coefficients the reference leaves untouched (n > 512 not a multiple of 512) keep
+  // whatever the caller's result buffer holds
+  HX_HIP(hipMemcpyAsync(dr, result, 3 * poly, hipMemcpyHostToDevice, st));
+  hipError_t e = dyadic_multiply_launch(dr, dx, dy, n, moduli, num_moduli, st);
+  if (e != hipSuccess) return hip_fail(e, "dyadic multiply launch");
+  HX_HIP(hipMemcpyAsync(result, dr, 3 * poly, hipMemcpyDeviceToHost, st));
+  HX_HIP(hipStreamSynchronize(st));
+  return HEXL_AMD_OK;
+}
+
 // ------------------------------------------------------------------ number theory
 
 uint64_t hexl_amd_multiply_factor(uint64_t operand, uint64_t bit_shift, uint64_t modulus) {

@@ -268,6 +268,14 @@ void EltwiseReduceMod(uint64_t* result, const uint64_t* operand, uint64_t n, uin
                                 output_mod_factor));
 }
 
+void DyadicMultiply(uint64_t* result, const uint64_t* operand1, const uint64_t* operand2,
+                    uint64_t n, const uint64_t* moduli, uint64_t num_moduli) {
+  if (on_device(result, operand1, operand2))
+    check(hexl_amd_dyadic_multiply(result, operand1, operand2, n, moduli, num_moduli, nullptr));
+  else
+    check(hexl_amd_dyadic_multiply_host(result, operand1, operand2, n, moduli, num_moduli));
+}
+
 void EltwiseCmpAdd(uint64_t* result, const uint64_t* operand1, uint64_t n, CMPINT cmp,
                    uint64_t bound, uint64_t diff) {
   if (on_device(result, operand1, nullptr))

@@ -92,6 +92,8 @@ struct EltArgs {
 };
 
 hipError_t eltwise_launch(EltOp op, const EltArgs& args, hipStream_t st);
+hipError_t dyadic_multiply_launch(u64* result, const u64* op1, const u64* op2, u64 n,
+                                  const u64* moduli_host, u64 num_moduli, hipStream_t st);
 hipError_t fill_splitmix_launch(u64* data, u64 n, u64 batch, u64 seed0, u64 bound,
                                 hipStream_t st);
 

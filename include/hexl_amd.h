@@ -216,6 +216,21 @@ int hexl_amd_eltwise_host(int op, uint64_t* result, const uint64_t* operand1,
                           uint64_t input_mod_factor,
                           uint64_t output_mod_factor);
 
+/* DyadicMultiply (hexl/include/hexl/experimental/seal/dyadic-multiply.hpp:26-28;
+ * hexl/experimental/seal/dyadic-multiply-internal.cpp:17-74): ciphertext
+ * product (x0, x1) * (y0, y1) -> (x0 y0, x0 y1 + x1 y0, x1 y1) in RNS form.
+ * operand1 / operand2: 2 polynomials of n * num_moduli words (device), result:
+ * 3 polynomials (may alias an operand); `moduli` is a HOST array of num_moduli
+ * words, each 1 < q < 2^62, operands < q.  One fused kernel. */
+int hexl_amd_dyadic_multiply(uint64_t* result, const uint64_t* operand1,
+                             const uint64_t* operand2, uint64_t n,
+                             const uint64_t* moduli, uint64_t num_moduli,
+                             void* stream);
+/* Same with host buffers (synchronous). */
+int hexl_amd_dyadic_multiply_host(uint64_t* result, const uint64_t* operand1,
+                                  const uint64_t* operand2, uint64_t n,
+                                  const uint64_t* moduli, uint64_t num_moduli);
+
 /* Host-pointer forms of the two comparison ops (synchronous).  `modulus` == 0
  * selects EltwiseCmpAdd, anything else EltwiseCmpSubMod. */
 int hexl_amd_eltwise_cmp_host(uint64_t* result, const uint64_t* operand1,

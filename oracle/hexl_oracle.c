@@ -573,6 +573,39 @@ void ho_eltwise_cmp_sub_mod(uint64_t* result, const uint64_t* operand1,
   }
 }
 
+/* hexl/experimental/seal/dyadic-multiply-internal.cpp:17-74 DyadicMultiply:
+ * (x0, x1) * (y0, y1) -> (x0*y0, x0*y1 + x1*y0, x1*y1) per RNS modulus, each
+ * polynomial n * num_moduli words.  Same call order as the reference (result
+ * may alias operand1/operand2: poly 2 is written first, poly 0 last) and the
+ * same tiling: tiles of min(n, 512) coefficients, n / tile whole tiles (:33-34;
+ * a remainder, only possible when n > 512 is not a multiple of 512, is left
+ * untouched exactly as there). */
+void ho_dyadic_multiply(uint64_t* result, const uint64_t* operand1,
+                        const uint64_t* operand2, uint64_t n,
+                        const uint64_t* moduli, uint64_t num_moduli) {
+  uint64_t poly_size = n * num_moduli;
+  uint64_t tile_size = n < 512 ? n : 512;
+  uint64_t num_tiles = n / tile_size;
+  uint64_t* temp = (uint64_t*)malloc(tile_size * sizeof(uint64_t));
+  for (uint64_t i = 0; i < num_moduli; ++i) {
+    for (uint64_t tile = 0; tile < num_tiles; ++tile) {
+      uint64_t p0 = i * n + tile_size * tile;
+      uint64_t p1 = p0 + poly_size;
+      uint64_t p2 = p0 + 2 * poly_size;
+      ho_eltwise_mult_mod(result + p2, operand1 + p1, operand2 + p1, tile_size,
+                          moduli[i], 1);
+      ho_eltwise_mult_mod(temp, operand1 + p1, operand2 + p0, tile_size,
+                          moduli[i], 1);
+      ho_eltwise_mult_mod(result + p1, operand1 + p0, operand2 + p1, tile_size,
+                          moduli[i], 1);
+      ho_eltwise_add_mod(result + p1, temp, result + p1, tile_size, moduli[i]);
+      ho_eltwise_mult_mod(result + p0, operand1 + p0, operand2 + p0, tile_size,
+                          moduli[i], 1);
+    }
+  }
+  free(temp);
+}
+
 /* ------------------------------------------------------------------------ */
 /* Convenience used by tests / bench: a complete plan in one allocation.     */
 /* ------------------------------------------------------------------------ */

@@ -71,6 +71,9 @@ void ho_eltwise_cmp_add(uint64_t* result, const uint64_t* operand1, uint64_t n,
 void ho_eltwise_cmp_sub_mod(uint64_t* result, const uint64_t* operand1,
                             uint64_t n, uint64_t modulus, int cmp,
                             uint64_t bound, uint64_t diff);
+void ho_dyadic_multiply(uint64_t* result, const uint64_t* operand1,
+                        const uint64_t* operand2, uint64_t n,
+                        const uint64_t* moduli, uint64_t num_moduli);
 void ho_eltwise_reduce_mod(uint64_t* result, const uint64_t* operand,
                            uint64_t n, uint64_t q, uint64_t in_mf,
                            uint64_t out_mf);

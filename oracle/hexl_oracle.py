@@ -65,6 +65,7 @@ def _load():
     sig("ho_eltwise_mult_mod", None, p64, p64, p64, u64, u64, u64)
     sig("ho_eltwise_fma_mod", None, p64, p64, u64, p64, u64, u64, u64)
     sig("ho_eltwise_reduce_mod", None, p64, p64, u64, u64, u64, u64)
+    sig("ho_dyadic_multiply", None, p64, p64, p64, u64, p64, u64)
     sig("ho_eltwise_cmp_add", None, p64, p64, u64, C.c_int, u64, u64)
     sig("ho_eltwise_cmp_sub_mod", None, p64, p64, u64, u64, C.c_int, u64, u64)
     sig("ho_ntt_create", C.c_void_p, u64, u64, u64)
@@ -245,6 +246,17 @@ def eltwise_cmp_sub_mod(a, modulus, cmp, bound, diff):
     lib.ho_eltwise_cmp_sub_mod(_p(out), _p(a), a.size, int(modulus), int(cmp), int(bound),
                                int(diff))
     return out
+
+
+def dyadic_multiply(op1, op2, n, moduli, result=None):
+    """DyadicMultiply; op1/op2 hold 2 polynomials of n * len(moduli) words, the result 3.
+    `result` (an array of 3 * n * len(moduli) words) may be op1 / op2 themselves to
+    exercise the in-place forms of the reference's tests."""
+    op1, op2, moduli = _arr(op1), _arr(op2), _arr(moduli)
+    if result is None:
+        result = np.zeros(3 * n * moduli.size, dtype=np.uint64)
+    lib.ho_dyadic_multiply(_p(result), _p(op1), _p(op2), n, _p(moduli), moduli.size)
+    return result
 
 
 def eltwise_reduce_mod(a, q, in_mf, out_mf):

@@ -246,6 +246,16 @@ static void test_eltwise() {
     EXPECT((r == V{6, 7, 8, 4, 0, 1, 2}));
     EXPECT(Not(CMPINT::LT) == CMPINT::NLT && Not(CMPINT::TRUE) == CMPINT::FALSE);
   }
+  {  // TEST(DyadicMultiply, small_two_mod / small_one_mod_inplace)
+    V moduli{10, 20};
+    V x{1, 2, 3, 11, 12, 13, 4, 5, 6, 14, 15, 16}, y{2, 4, 6, 12, 14, 16, 8, 1, 3, 18, 11, 13};
+    V out(18, 0);
+    DyadicMultiply(out.data(), x.data(), y.data(), 3, moduli.data(), 2);
+    EXPECT((out == V{2, 8, 8, 12, 8, 8, 6, 2, 5, 6, 2, 5, 2, 5, 8, 12, 5, 8}));
+    V one{10}, a{1, 2, 3, 4, 5, 6, 0, 0, 0}, b{2, 4, 6, 8, 1, 3};
+    DyadicMultiply(a.data(), a.data(), b.data(), 3, one.data(), 1);
+    EXPECT((a == V{2, 8, 8, 6, 2, 5, 2, 5, 8}));
+  }
   V z(4);
   EXPECT_THROW(EltwiseCmpAdd(z.data(), z.data(), 4, CMPINT::EQ, 1, 0));
   EXPECT_THROW(EltwiseCmpSubMod(z.data(), z.data(), 4, 10, CMPINT::EQ, 1, 0));

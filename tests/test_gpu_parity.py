@@ -556,3 +556,53 @@ def test_cmp_ops_reject_bad_arguments(hx):
         hx.EltwiseCmpSubMod(da, da, 4, 10, 0, 1, 10)    # diff >= modulus
     with pytest.raises(hx.HexlAmdError):
         hx.EltwiseCmpSubMod(da, da, 4, 10, 8, 1, 1)     # not a CMPINT
+
+
+# ---------------------------------------------------------------- DyadicMultiply
+@pytest.mark.parametrize("case", KAT["dyadic_multiply"]["cases"], ids=lambda c: c["name"])
+def test_dyadic_multiply_kat(hx, case):
+    """test/experimental/seal/test-dyadic-multiply.cpp:16-180 incl. the in-place forms."""
+    import torch
+    op1 = U(case["op1"])
+    if case["inplace"]:
+        op1 = np.concatenate([op1, np.zeros(op1.size // 2, dtype=np.uint64)])
+    d1 = dev(hx, op1)
+    d2 = d1 if case["same_op"] else dev(hx, case["op2"])
+    out = d1 if case["inplace"] else torch.zeros(len(case["out"]), dtype=d1.dtype, device=d1.device)
+    hx.DyadicMultiply(out, d1, d2, case["n"], case["moduli"])
+    assert host(hx, out).tolist() == case["out"]
+
+
+@pytest.mark.parametrize("n,num_moduli", [(4, 1), (512, 3), (4096, 4), (600, 2), (8192, 40)])
+def test_dyadic_multiply_random_vs_oracle(hx, ho, n, num_moduli):
+    """Sizes around the reference's 512-coefficient tiling (whole tiles only), more moduli
+    than one launch carries (40 > 32), RNS primes up to 61 bits."""
+    import torch
+    rng = np.random.default_rng(n + num_moduli)
+    pool = [int(q) for bits in (30, 45, 54, 61) for q in ho.generate_primes(10, bits, True, 8192)]
+    moduli = pool[:num_moduli]
+    x = np.concatenate([rng.integers(0, q, n, dtype=np.uint64) for q in moduli] * 2)
+    y = np.concatenate([rng.integers(0, q, n, dtype=np.uint64) for q in moduli] * 2)
+    x[0] = moduli[0] - 1
+    y[0] = moduli[0] - 1
+    want = ho.dyadic_multiply(x, y, n, moduli, result=np.full(3 * x.size // 2, 5, dtype=np.uint64))
+    out = dev(hx, np.full(3 * x.size // 2, 5, dtype=np.uint64))
+    hx.DyadicMultiply(out, dev(hx, x), dev(hx, y), n, moduli)
+    assert np.array_equal(host(hx, out), want)
+    # in place over operand1 (extended by the third polynomial)
+    ext = np.concatenate([x, np.full(x.size // 2, 5, dtype=np.uint64)])
+    buf = dev(hx, ext)
+    hx.DyadicMultiply(buf, buf, dev(hx, y), n, moduli)
+    want_inplace = ext.copy()
+    ho.dyadic_multiply(want_inplace, y, n, moduli, result=want_inplace)
+    assert np.array_equal(host(hx, buf), want_inplace)
+
+
+def test_dyadic_multiply_rejects_bad_arguments(hx):
+    d = dev(hx, [1, 2, 3, 4, 5, 6, 0, 0, 0])
+    with pytest.raises(hx.HexlAmdError):
+        hx.DyadicMultiply(d, d, d, 0, [10])
+    with pytest.raises(hx.HexlAmdError):
+        hx.DyadicMultiply(d, d, d, 3, [1])
+    with pytest.raises(hx.HexlAmdError):
+        hx.DyadicMultiply(d, d, d, 3, [1 << 62])

@@ -339,3 +339,44 @@ def test_cmp_ops_against_python_ints():
             want = [(int(x) + diff) % (1 << 64) if py_cmp[cmp](int(x), bound) else int(x)
                     for x in a]
             assert got == want
+
+
+# ---------------------------------------------------------------- DyadicMultiply
+def _dyadic_buffers(case):
+    op1 = np.asarray(case["op1"], dtype=np.uint64)
+    op2 = op1 if case["same_op"] else np.asarray(case["op2"], dtype=np.uint64)
+    if case["inplace"]:  # result aliases operand1, which is extended by the output polynomial
+        op1 = np.concatenate([op1, np.zeros(op1.size // 2, dtype=np.uint64)])
+        if case["same_op"]:
+            op2 = op1
+    return op1, op2
+
+
+@pytest.mark.parametrize("case", KAT["dyadic_multiply"]["cases"], ids=lambda c: c["name"])
+def test_dyadic_multiply_kat(case):
+    op1, op2 = _dyadic_buffers(case)
+    out = ho.dyadic_multiply(op1, op2, case["n"], case["moduli"],
+                             result=op1 if case["inplace"] else None)
+    assert out.tolist() == case["out"]
+
+
+def test_dyadic_multiply_against_python_ints():
+    """Definition check with RNS primes and the reference's tiling (n = 2048 is four tiles
+    of 512; n = 600 leaves 88 coefficients per modulus untouched,
+    dyadic-multiply-internal.cpp:33-34)."""
+    rng = np.random.default_rng(9)
+    for n in (4, 512, 2048, 600):
+        moduli = [int(q) for q in ho.generate_primes(3, 40, True, 1024)] + [10]
+        k = len(moduli)
+        x = np.concatenate([rng.integers(0, q, n, dtype=np.uint64) for q in moduli] * 2)
+        y = np.concatenate([rng.integers(0, q, n, dtype=np.uint64) for q in moduli] * 2)
+        res = np.full(3 * n * k, 7, dtype=np.uint64)
+        ho.dyadic_multiply(x, y, n, moduli, result=res)
+        n_proc = (n // min(n, 512)) * min(n, 512)
+        for i, q in enumerate(moduli):
+            for e in (0, 1, n_proc - 1, n - 1):
+                x0, x1 = int(x[i * n + e]), int(x[n * k + i * n + e])
+                y0, y1 = int(y[i * n + e]), int(y[n * k + i * n + e])
+                want = ([x0 * y0 % q, (x0 * y1 + x1 * y0) % q, x1 * y1 % q] if e < n_proc
+                        else [7, 7, 7])
+                assert [int(res[p * n * k + i * n + e]) for p in range(3)] == want

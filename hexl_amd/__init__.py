@@ -28,7 +28,7 @@ _LIB_PATH = os.environ.get("HEXL_AMD_LIB") or os.path.join(_HERE, "lib", "libhex
 
 __all__ = [
     "NTT", "EltwiseAddMod", "EltwiseSubMod", "EltwiseMultMod", "EltwiseFMAMod",
-    "EltwiseReduceMod", "EltwiseReduceFMAMod", "EltwiseCmpAdd", "EltwiseCmpSubMod", "CMPINT", "DyadicMultiply",
+    "EltwiseReduceMod", "EltwiseReduceFMAMod", "EltwiseCmpAdd", "EltwiseCmpSubMod", "CMPINT", "DyadicMultiply", "KeySwitch",
     "HexlAmdError", "lib", "LIB_PATH",
     "MinimalPrimitiveRoot", "GeneratePrimes", "IsPrime", "InverseMod", "MultiplyMod",
     "PowMod", "IsPrimitiveRoot", "ReverseBits", "MultiplyFactor", "fill_splitmix",
@@ -82,6 +82,10 @@ def _load():
     sig("hexl_amd_eltwise_host", ci, ci, p64, p64, p64, u64, u64, u64, u64, u64)
     sig("hexl_amd_dyadic_multiply", ci, p64, p64, p64, u64, C.POINTER(u64), u64, vp)
     sig("hexl_amd_dyadic_multiply_host", ci, p64, p64, p64, u64, C.POINTER(u64), u64)
+    sig("hexl_amd_key_switch", ci, p64, p64, u64, u64, u64, u64, u64, C.POINTER(u64),
+        C.POINTER(vp), C.POINTER(u64), vp)
+    sig("hexl_amd_key_switch_host", ci, p64, p64, u64, u64, u64, u64, u64, C.POINTER(u64),
+        C.POINTER(vp), C.POINTER(u64))
     sig("hexl_amd_eltwise_cmp_add", ci, p64, p64, u64, ci, u64, u64, vp)
     sig("hexl_amd_eltwise_cmp_sub_mod", ci, p64, p64, u64, u64, ci, u64, u64, vp)
     sig("hexl_amd_eltwise_cmp_host", ci, p64, p64, u64, u64, ci, u64, u64)
@@ -119,6 +123,7 @@ C_ABI_SYMBOLS = [
     "hexl_amd_eltwise_reduce_mod", "hexl_amd_eltwise_reduce_fma_mod", "hexl_amd_eltwise_host",
     "hexl_amd_eltwise_cmp_add", "hexl_amd_eltwise_cmp_sub_mod", "hexl_amd_eltwise_cmp_host",
     "hexl_amd_dyadic_multiply", "hexl_amd_dyadic_multiply_host",
+    "hexl_amd_key_switch", "hexl_amd_key_switch_host",
     "hexl_amd_multiply_factor", "hexl_amd_inverse_mod", "hexl_amd_multiply_mod",
     "hexl_amd_pow_mod", "hexl_amd_is_primitive_root", "hexl_amd_generate_primitive_root",
     "hexl_amd_minimal_primitive_root", "hexl_amd_reverse_bits", "hexl_amd_is_prime",
@@ -372,6 +377,18 @@ def DyadicMultiply(result, operand1, operand2, n, moduli):
     arr = (C.c_uint64 * len(moduli))(*[int(m) for m in moduli])
     _check(lib.hexl_amd_dyadic_multiply(_ptr(result), _ptr(operand1), _ptr(operand2), n, arr,
                                         len(moduli), _stream()))
+
+
+def KeySwitch(result, t_target_iter, n, decomp_modulus_size, key_modulus_size, rns_modulus_size,
+              key_component_count, moduli, k_switch_keys, modswitch_factors):
+    """hexl/include/hexl/experimental/seal/key-switch.hpp:40-46.  result, t_target_iter and the
+    entries of k_switch_keys are device tensors; moduli / modswitch_factors host sequences."""
+    mod = (C.c_uint64 * len(moduli))(*[int(m) for m in moduli])
+    msf = (C.c_uint64 * len(modswitch_factors))(*[int(m) for m in modswitch_factors])
+    keys = (C.c_void_p * len(k_switch_keys))(*[_ptr(k).value for k in k_switch_keys])
+    _check(lib.hexl_amd_key_switch(_ptr(result), _ptr(t_target_iter), n, decomp_modulus_size,
+                                   key_modulus_size, rns_modulus_size, key_component_count, mod,
+                                   keys, msf, _stream()))
 
 
 class CMPINT:

@@ -7,7 +7,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <tuple>
 #include <new>
 #include <string>
 #include <vector>
@@ -578,6 +580,211 @@ int hexl_amd_dyadic_multiply_host(uint64_t* result, const uint64_t* operand1,
   hipError_t e = dyadic_multiply_launch(dr, dx, dy, n, moduli, num_moduli, st);
   if (e != hipSuccess) return hip_fail(e, "dyadic multiply launch");
   HX_HIP(hipMemcpyAsync(result, dr, 3 * poly, hipMemcpyDeviceToHost, st));
+  HX_HIP(hipStreamSynchronize(st));
+  return HEXL_AMD_OK;
+}
+
+// ------------------------------------------------------------------ KeySwitch
+
+namespace {
+
+// Plans by (n, q, device), the counterpart of the reference's GetNTT cache
+// (hexl/include/hexl/experimental/seal/ntt-cache.hpp:27-53).  Entries live for
+// the life of the process.
+const hexl_amd_ntt* cached_plan(u64 n, u64 q, int device) {
+  static std::mutex mu;
+  static std::map<std::tuple<u64, u64, int>, hexl_amd_ntt*> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_tuple(n, q, device);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  hexl_amd_ntt* p = nullptr;
+  if (hexl_amd_ntt_create(&p, n, q, 0, device) != HEXL_AMD_OK) return nullptr;
+  cache.emplace(key, p);
+  return p;
+}
+
+thread_local Staging g_workspace;  // device scratch of the composite operations
+
+u64 floor_2_64_over(u64 q) { return (u64)((((unsigned __int128)1) << 64) / q); }
+
+}  // namespace
+
+static int check_key_switch(const uint64_t* result, const uint64_t* t_target, uint64_t n,
+                            uint64_t D, uint64_t K, uint64_t R, uint64_t C,
+                            const uint64_t* moduli, const uint64_t* const* keys,
+                            const uint64_t* msf) {
+  if (!result) return fail(HEXL_AMD_ERR_INVALID_ARG, "result == nullptr");
+  if (!t_target) return fail(HEXL_AMD_ERR_INVALID_ARG, "t_target_iter_ptr == nullptr");
+  if (!moduli) return fail(HEXL_AMD_ERR_INVALID_ARG, "moduli == nullptr");
+  if (!keys) return fail(HEXL_AMD_ERR_INVALID_ARG, "k_switch_keys == nullptr");
+  if (!msf) return fail(HEXL_AMD_ERR_INVALID_ARG, "modswitch_factors == nullptr");
+  if (n == 0 || D == 0 || C == 0)
+    return fail(HEXL_AMD_ERR_INVALID_ARG, "n, decomp_modulus_size, key_component_count must be > 0");
+  if (D > (uint64_t)kKsMaxDecomp)
+    return fail(HEXL_AMD_ERR_INVALID_ARG, "decomp_modulus_size > %d is not supported", kKsMaxDecomp);
+  if (C > 65535) return fail(HEXL_AMD_ERR_INVALID_ARG, "key_component_count too large");
+  // the algorithm indexes moduli[0..D-1] and moduli[K-1], and RNS index D uses key K-1
+  if (K < D + 1 || R != D + 1)
+    return fail(HEXL_AMD_ERR_INVALID_ARG,
+                "need key_modulus_size > decomp_modulus_size and rns_modulus_size == "
+                "decomp_modulus_size + 1");
+  for (uint64_t j = 0; j < D; ++j)
+    if (!keys[j]) return fail(HEXL_AMD_ERR_INVALID_ARG, "k_switch_keys[%llu] == nullptr",
+                              (unsigned long long)j);
+  for (uint64_t i = 0; i < K; ++i)
+    if (i < D || i == K - 1)
+      if (!hexl_amd_ntt_check_arguments(n, moduli[i]) || moduli[i] >= (1ull << 61))
+        return fail(HEXL_AMD_ERR_INVALID_ARG,
+                    "moduli[%llu] is not an NTT-friendly prime below 2^61 for degree %llu",
+                    (unsigned long long)i, (unsigned long long)n);
+  return HEXL_AMD_OK;
+}
+
+// Device buffers throughout.  `keys`: host array of D device pointers.
+static int key_switch_device(u64* result, const u64* t_target_iter, u64 n, u64 D, u64 K, u64 R,
+                             u64 C, const u64* moduli, const u64* const* keys, const u64* msf,
+                             hipStream_t st) {
+  int device = 0;
+  HX_HIP(hipGetDevice(&device));
+  std::vector<const hexl_amd_ntt*> plan(K, nullptr);
+  for (u64 i = 0; i < K; ++i)
+    if (i < D || i == K - 1) {
+      plan[i] = cached_plan(n, moduli[i], device);
+      if (!plan[i]) return HEXL_AMD_ERR_HIP;  // message set by hexl_amd_ntt_create
+    }
+  // workspace: t_target (D n) | ntt_buf (D n) | t_poly_prod (C R n)
+  const size_t words = (size_t)n * (2 * D + C * R);
+  if (int rc = g_workspace.ensure(device, words * sizeof(u64))) return rc;
+  u64* t_target = (u64*)g_workspace.buf;
+  u64* ntt_buf = t_target + D * n;
+  u64* prod = ntt_buf + D * n;
+  hipError_t e;
+
+  // key-switch-internal.cpp:38-56: coefficient form of the target per decomposition modulus
+  HX_HIP(hipMemcpyAsync(t_target, t_target_iter, D * n * sizeof(u64), hipMemcpyDeviceToDevice, st));
+  for (u64 j = 0; j < D; ++j) {
+    e = ntt_inverse_launch(plan[j]->t, t_target + j * n, t_target + j * n, 1, 1, st);
+    if (e != hipSuccess) return hip_fail(e, "KeySwitch inverse NTT");
+  }
+
+  // :61-131 per RNS index: operands to the key modulus, lazy forward NTT, MAC, reduce
+  for (u64 i = 0; i < R; ++i) {
+    const u64 key_index = (i == D) ? K - 1 : i;
+    const u64 q = moduli[key_index];
+    KsGather g{};
+    KsMac m{};
+    g.q = q;
+    g.barrett = floor_2_64_over(q);
+    u32 slots = 0;
+    for (u64 j = 0; j < D; ++j) {
+      m.keys[j] = keys[j];
+      if (j == i) continue;
+      g.jmap[slots] = (u32)j;
+      if (moduli[j] > q) g.reduce_mask |= 1u << slots;
+      m.slot[j] = slots++;
+    }
+    e = ks_gather_launch(ntt_buf, t_target, n, slots, g, st);
+    if (e != hipSuccess) return hip_fail(e, "KeySwitch gather");
+    if (slots) {
+      e = ntt_forward_launch(plan[key_index]->t, ntt_buf, ntt_buf, slots, 4, st);
+      if (e != hipSuccess) return hip_fail(e, "KeySwitch forward NTT");
+    }
+    m.decomp = (u32)D;
+    m.self = (u32)i;  // == D for the extra RNS index: no operand from t_target_iter
+    m.key_component_stride = K * n;
+    m.key_index_offset = key_index * n;
+    m.prod_component_stride = R * n;
+    m.prod_offset = i * n;
+    m.q = q;
+    m.barrett = g.barrett;
+    m.two64_mod_q = (u64)((((unsigned __int128)1) << 64) % q);
+    const u32 ceil_log = 64 - __builtin_clzll(q);
+    m.shift = ceil_log - 2;
+    m.mu = (u64)((((unsigned __int128)(1ull << (ceil_log + 62 - 64))) << 64) / q);
+    e = ks_mac_launch(prod, t_target_iter, ntt_buf, n, (u32)C, m, st);
+    if (e != hipSuccess) return hip_fail(e, "KeySwitch multiply-accumulate");
+  }
+
+  // :134-197 per key component: modulus switching from the special prime
+  const u64 qk = moduli[K - 1];
+  KsRound rd{};
+  KsFinish fin{};
+  rd.qk = qk;
+  rd.barrett_k = floor_2_64_over(qk);
+  rd.qk_half = qk >> 1;
+  for (u64 i = 0; i < D; ++i) {
+    const u64 qi = moduli[i];
+    const u64 bf = floor_2_64_over(qi);
+    u64 h = rd.qk_half - (u64)(((unsigned __int128)rd.qk_half * bf) >> 64) * qi;  // BarrettReduce64
+    if (h >= qi) h -= qi;
+    rd.mod[i] = KsRoundMod{qi, bf, qi - h, qk > qi ? 1u : 0u};
+    u64 s = msf[i];  // FMAMod reduces its scalar from [0, 8q) (eltwise-fma-mod.cpp:60-64)
+    if (s >= 4 * qi) s -= 4 * qi;
+    if (s >= 2 * qi) s -= 2 * qi;
+    if (s >= qi) s -= qi;
+    fin.mod[i] = KsFinishMod{qi, s, (u64)((((unsigned __int128)s) << 64) / qi)};
+  }
+  for (u64 kc = 0; kc < C; ++kc) {
+    u64* pk = prod + kc * n * R;
+    u64* t_last = pk + D * n;
+    e = ntt_inverse_launch(plan[K - 1]->t, t_last, t_last, 1, 2, st);
+    if (e != hipSuccess) return hip_fail(e, "KeySwitch inverse NTT (last)");
+    e = ks_round_launch(ntt_buf, t_last, n, (u32)D, rd, st);
+    if (e != hipSuccess) return hip_fail(e, "KeySwitch rounding");
+    for (u64 i = 0; i < D; ++i) {
+      e = ntt_forward_launch(plan[i]->t, ntt_buf + i * n, ntt_buf + i * n, 1, 4, st);
+      if (e != hipSuccess) return hip_fail(e, "KeySwitch forward NTT (switch)");
+    }
+    e = ks_finish_launch(result + n * D * kc, pk, ntt_buf, n, (u32)D, fin, st);
+    if (e != hipSuccess) return hip_fail(e, "KeySwitch finish");
+  }
+  return HEXL_AMD_OK;
+}
+
+int hexl_amd_key_switch(uint64_t* result, const uint64_t* t_target_iter_ptr, uint64_t n,
+                        uint64_t decomp_modulus_size, uint64_t key_modulus_size,
+                        uint64_t rns_modulus_size, uint64_t key_component_count,
+                        const uint64_t* moduli, const uint64_t* const* k_switch_keys,
+                        const uint64_t* modswitch_factors, void* stream) {
+  if (int rc = check_key_switch(result, t_target_iter_ptr, n, decomp_modulus_size,
+                                key_modulus_size, rns_modulus_size, key_component_count, moduli,
+                                k_switch_keys, modswitch_factors))
+    return rc;
+  return key_switch_device(result, t_target_iter_ptr, n, decomp_modulus_size, key_modulus_size,
+                           rns_modulus_size, key_component_count, moduli, k_switch_keys,
+                           modswitch_factors, (hipStream_t)stream);
+}
+
+int hexl_amd_key_switch_host(uint64_t* result, const uint64_t* t_target_iter_ptr, uint64_t n,
+                             uint64_t D, uint64_t K, uint64_t R, uint64_t C,
+                             const uint64_t* moduli, const uint64_t* const* k_switch_keys,
+                             const uint64_t* modswitch_factors) {
+  if (int rc = check_key_switch(result, t_target_iter_ptr, n, D, K, R, C, moduli, k_switch_keys,
+                                modswitch_factors))
+    return rc;
+  int device = 0;
+  HX_HIP(hipGetDevice(&device));
+  // staging: result (C D n) | target (D n) | D key blocks of C K n words
+  const size_t res_words = (size_t)C * D * n, key_words = (size_t)C * K * n;
+  if (int rc = g_staging.ensure(device, (res_words + D * n + D * key_words) * sizeof(u64)))
+    return rc;
+  u64* d_res = (u64*)g_staging.buf;
+  u64* d_tgt = d_res + res_words;
+  u64* d_keys = d_tgt + D * n;
+  hipStream_t st = g_staging.stream;
+  HX_HIP(hipMemcpyAsync(d_res, result, res_words * sizeof(u64), hipMemcpyHostToDevice, st));
+  HX_HIP(hipMemcpyAsync(d_tgt, t_target_iter_ptr, D * n * sizeof(u64), hipMemcpyHostToDevice, st));
+  std::vector<const u64*> kp(D);
+  for (u64 j = 0; j < D; ++j) {
+    HX_HIP(hipMemcpyAsync(d_keys + j * key_words, k_switch_keys[j], key_words * sizeof(u64),
+                          hipMemcpyHostToDevice, st));
+    kp[j] = d_keys + j * key_words;
+  }
+  if (int rc = key_switch_device(d_res, d_tgt, n, D, K, R, C, moduli, kp.data(),
+                                 modswitch_factors, st))
+    return rc;
+  HX_HIP(hipMemcpyAsync(result, d_res, res_words * sizeof(u64), hipMemcpyDeviceToHost, st));
   HX_HIP(hipStreamSynchronize(st));
   return HEXL_AMD_OK;
 }

@@ -276,6 +276,25 @@ void DyadicMultiply(uint64_t* result, const uint64_t* operand1, const uint64_t* 
     check(hexl_amd_dyadic_multiply_host(result, operand1, operand2, n, moduli, num_moduli));
 }
 
+void KeySwitch(uint64_t* result, const uint64_t* t_target_iter_ptr, uint64_t n,
+               uint64_t decomp_modulus_size, uint64_t key_modulus_size,
+               uint64_t rns_modulus_size, uint64_t key_component_count, const uint64_t* moduli,
+               const uint64_t** k_switch_keys, const uint64_t* modswitch_factors,
+               const uint64_t* root_of_unity_powers_ptr) {
+  if (root_of_unity_powers_ptr != nullptr)  // key-switch-internal.cpp:31-34
+    throw std::invalid_argument("Parameter root_of_unity_powers_ptr is not supported yet.");
+  const bool dev = on_device(result, t_target_iter_ptr,
+                             k_switch_keys ? k_switch_keys[0] : nullptr);
+  if (dev)
+    check(hexl_amd_key_switch(result, t_target_iter_ptr, n, decomp_modulus_size, key_modulus_size,
+                              rns_modulus_size, key_component_count, moduli, k_switch_keys,
+                              modswitch_factors, nullptr));
+  else
+    check(hexl_amd_key_switch_host(result, t_target_iter_ptr, n, decomp_modulus_size,
+                                   key_modulus_size, rns_modulus_size, key_component_count,
+                                   moduli, k_switch_keys, modswitch_factors));
+}
+
 void EltwiseCmpAdd(uint64_t* result, const uint64_t* operand1, uint64_t n, CMPINT cmp,
                    uint64_t bound, uint64_t diff) {
   if (on_device(result, operand1, nullptr))

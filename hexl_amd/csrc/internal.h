@@ -94,6 +94,46 @@ struct EltArgs {
 hipError_t eltwise_launch(EltOp op, const EltArgs& args, hipStream_t st);
 hipError_t dyadic_multiply_launch(u64* result, const u64* op1, const u64* op2, u64 n,
                                   const u64* moduli_host, u64 num_moduli, hipStream_t st);
+// ---- KeySwitch stages (keyswitch_kernels.hip); argument blocks travel as kernel
+// arguments, so the number of decomposition moduli per call is bounded.
+constexpr int kKsMaxDecomp = 32;
+struct KsGather {
+  u64 q, barrett;          // key modulus of this RNS index, floor(2^64 / q)
+  u32 jmap[kKsMaxDecomp];  // slot -> decomposition modulus
+  u32 reduce_mask;         // bit s: moduli[jmap[s]] > q, reduce
+};
+struct KsMac {
+  const u64* keys[kKsMaxDecomp];
+  u32 slot[kKsMaxDecomp];  // decomposition modulus -> slot of ntt_buf (unused for `self`)
+  u32 decomp, self;        // self == decomp: no operand is taken from t_target_iter
+  u64 key_component_stride, key_index_offset;
+  u64 prod_component_stride, prod_offset;
+  u64 q, barrett, two64_mod_q, mu;  // mu, shift: generalised Barrett of MultOp
+  u32 shift;
+};
+struct KsRoundMod {
+  u64 q, barrett, fix;
+  u32 reduce;
+};
+struct KsRound {
+  u64 qk, barrett_k, qk_half;
+  KsRoundMod mod[kKsMaxDecomp];
+};
+struct KsFinishMod {
+  u64 q, s, sp;
+};
+struct KsFinish {
+  KsFinishMod mod[kKsMaxDecomp];
+};
+hipError_t ks_gather_launch(u64* out, const u64* t_target, u64 n, u32 slots, const KsGather& g,
+                            hipStream_t st);
+hipError_t ks_mac_launch(u64* prod, const u64* t_target_iter, const u64* ntt_buf, u64 n,
+                         u32 components, const KsMac& m, hipStream_t st);
+hipError_t ks_round_launch(u64* tbuf, const u64* t_last, u64 n, u32 decomp, const KsRound& r,
+                           hipStream_t st);
+hipError_t ks_finish_launch(u64* result, const u64* prod, const u64* tbuf, u64 n, u32 decomp,
+                            const KsFinish& f, hipStream_t st);
+
 hipError_t fill_splitmix_launch(u64* data, u64 n, u64 batch, u64 seed0, u64 bound,
                                 hipStream_t st);
 

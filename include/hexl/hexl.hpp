@@ -11,6 +11,7 @@
 #include "hexl/eltwise/eltwise-reduce-mod.hpp"
 #include "hexl/eltwise/eltwise-sub-mod.hpp"
 #include "hexl/experimental/seal/dyadic-multiply.hpp"
+#include "hexl/experimental/seal/key-switch.hpp"
 #include "hexl/ntt/ntt.hpp"
 #include "hexl/number-theory/number-theory.hpp"
 #include "hexl/util/aligned-allocator.hpp"

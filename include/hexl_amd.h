@@ -231,6 +231,30 @@ int hexl_amd_dyadic_multiply_host(uint64_t* result, const uint64_t* operand1,
                                   const uint64_t* operand2, uint64_t n,
                                   const uint64_t* moduli, uint64_t num_moduli);
 
+/* KeySwitch (hexl/include/hexl/experimental/seal/key-switch.hpp:40-46;
+ * hexl/experimental/seal/key-switch-internal.cpp:25-201, CKKS path).  All data
+ * pointers are device memory: result (key_component_count x decomp_modulus_size
+ * x n words, accumulated into), t_target_iter_ptr (decomp_modulus_size x n,
+ * NTT form), k_switch_keys[j] (key_component_count x key_modulus_size x n).
+ * `moduli`, `modswitch_factors` and the array `k_switch_keys` itself are HOST
+ * arrays.  Plans for (n, moduli[i]) are created on first use and cached, as the
+ * reference's GetNTT does (ntt-cache.hpp:27-53).  Requires rns_modulus_size ==
+ * decomp_modulus_size + 1 <= key_modulus_size, decomp_modulus_size <= 32,
+ * NTT-friendly primes below 2^61. */
+int hexl_amd_key_switch(uint64_t* result, const uint64_t* t_target_iter_ptr,
+                        uint64_t n, uint64_t decomp_modulus_size,
+                        uint64_t key_modulus_size, uint64_t rns_modulus_size,
+                        uint64_t key_component_count, const uint64_t* moduli,
+                        const uint64_t* const* k_switch_keys,
+                        const uint64_t* modswitch_factors, void* stream);
+/* Same with host buffers everywhere (synchronous). */
+int hexl_amd_key_switch_host(uint64_t* result, const uint64_t* t_target_iter_ptr,
+                             uint64_t n, uint64_t decomp_modulus_size,
+                             uint64_t key_modulus_size, uint64_t rns_modulus_size,
+                             uint64_t key_component_count, const uint64_t* moduli,
+                             const uint64_t* const* k_switch_keys,
+                             const uint64_t* modswitch_factors);
+
 /* Host-pointer forms of the two comparison ops (synchronous).  `modulus` == 0
  * selects EltwiseCmpAdd, anything else EltwiseCmpSubMod. */
 int hexl_amd_eltwise_cmp_host(uint64_t* result, const uint64_t* operand1,

@@ -658,6 +658,102 @@ void ho_ntt_inverse_batch(const ho_ntt* p, uint64_t* result,
     ho_ntt_inverse(p, result + b * p->n, operand + b * p->n, in_mf, out_mf);
 }
 
+/* hexl/experimental/seal/key-switch-internal.cpp:25-201 KeySwitch (CKKS path,
+ * root_of_unity_powers_ptr == nullptr).  Restated step by step with the same
+ * intermediate ranges; GetNTT(n, q) (ntt-cache.hpp:27-53) becomes a plan per
+ * modulus built up front.
+ *   n = coeff_count; t_target_iter: decomp x n words (NTT form);
+ *   k_switch_keys[j]: key_component_count x key_modulus_size x n words;
+ *   result: key_component_count x decomp x n words, accumulated into. */
+void ho_key_switch(uint64_t* result, const uint64_t* t_target_iter, uint64_t n,
+                   uint64_t decomp_modulus_size, uint64_t key_modulus_size,
+                   uint64_t rns_modulus_size, uint64_t key_component_count,
+                   const uint64_t* moduli, const uint64_t* const* k_switch_keys,
+                   const uint64_t* modswitch_factors) {
+  const uint64_t D = decomp_modulus_size, K = key_modulus_size,
+                 R = rns_modulus_size, C = key_component_count;
+  ho_ntt** plans = (ho_ntt**)calloc(K, sizeof(ho_ntt*));
+  for (uint64_t i = 0; i < K; ++i) plans[i] = ho_ntt_create(n, moduli[i], 0);
+
+  /* :38-56 copy of the target, back to coefficient form per decomposition
+   * modulus: ComputeInverse(2, 1) */
+  uint64_t* t_target = (uint64_t*)malloc(D * n * sizeof(uint64_t));
+  memcpy(t_target, t_target_iter, D * n * sizeof(uint64_t));
+  uint64_t* t_ntt = (uint64_t*)calloc(n, sizeof(uint64_t));
+  for (uint64_t j = 0; j < D; ++j)
+    ho_ntt_inverse(plans[j], t_target + j * n, t_target + j * n, 2, 1);
+
+  uint64_t* t_poly_prod = (uint64_t*)calloc(C * n * R, sizeof(uint64_t));
+  unsigned __int128* acc =
+      (unsigned __int128*)malloc(C * n * sizeof(unsigned __int128));
+
+  for (uint64_t i = 0; i < R; ++i) { /* :61-131 */
+    uint64_t key_index = (i == D ? K - 1 : i);
+    uint64_t qk = moduli[key_index];
+    for (uint64_t x = 0; x < C * n; ++x) acc[x] = 0;
+    for (uint64_t j = 0; j < D; ++j) {
+      const uint64_t* t_operand;
+      if (i == j) {
+        t_operand = t_target_iter + j * n; /* :72-73 already in NTT form */
+      } else {
+        if (moduli[j] <= qk) { /* :77-80 */
+          memcpy(t_ntt, t_target + j * n, n * sizeof(uint64_t));
+        } else { /* :82-86 ReduceMod(in = modulus, out = 1) */
+          ho_eltwise_reduce_mod(t_ntt, t_target + j * n, n, qk, qk, 1);
+        }
+        ho_ntt_forward(plans[key_index], t_ntt, t_ntt, 4, 4); /* :89 lazy */
+        t_operand = t_ntt;
+      }
+      /* :94-115 128-bit multiply-accumulate, no reduction */
+      for (uint64_t k = 0; k < C; ++k)
+        for (uint64_t l = 0; l < n; ++l)
+          acc[k * n + l] += (unsigned __int128)t_operand[l] *
+                            k_switch_keys[j][n * key_index + k * K * n + l];
+    }
+    /* :122-130 BarrettReduce128 == exact remainder (util/gcc.hpp:20-28) */
+    for (uint64_t k = 0; k < C; ++k)
+      for (uint64_t l = 0; l < n; ++l)
+        t_poly_prod[i * n + n * R * k + l] = (uint64_t)(acc[k * n + l] % qk);
+  }
+
+  for (uint64_t kc = 0; kc < C; ++kc) { /* :134-197 */
+    uint64_t* prod = t_poly_prod + kc * n * R;
+    uint64_t* t_last = prod + D * n;
+    uint64_t qk = moduli[K - 1];
+    uint64_t qk_half = qk >> 1;
+    ho_ntt_inverse(plans[K - 1], t_last, t_last, 2, 2); /* :140-141 */
+    uint64_t bf_k = ho_multiply_factor(1, 64, qk);
+    for (uint64_t l = 0; l < n; ++l) /* :146-151 */
+      t_last[l] = barrett_reduce64(t_last[l] + qk_half, qk, bf_k, 1);
+    for (uint64_t i = 0; i < D; ++i) {
+      uint64_t qi = moduli[i];
+      if (qk > qi) { /* :159-167 */
+        ho_eltwise_reduce_mod(t_ntt, t_last, n, qi, qi, 1);
+      } else {
+        memcpy(t_ntt, t_last, n * sizeof(uint64_t));
+      }
+      uint64_t bf_i = ho_multiply_factor(1, 64, qi);
+      uint64_t fix = qi - barrett_reduce64(qk_half, qi, bf_i, 1); /* :170-175 */
+      for (uint64_t l = 0; l < n; ++l) t_ntt[l] += fix;
+      ho_ntt_forward(plans[i], t_ntt, t_ntt, 4, 4); /* :178 */
+      uint64_t qi_lazy = qi << 2;                   /* :180 */
+      uint64_t* t_ith = prod + i * n;
+      for (uint64_t l = 0; l < n; ++l) /* :183-186 */
+        t_ith[l] = t_ith[l] + qi_lazy - t_ntt[l];
+      ho_eltwise_fma_mod(t_ith, t_ith, modswitch_factors[i], NULL, n, qi,
+                         8); /* :189-190 */
+      uint64_t* data = result + n * (D * kc + i);
+      ho_eltwise_add_mod(data, data, t_ith, n, qi); /* :195-196 */
+    }
+  }
+  free(acc);
+  free(t_poly_prod);
+  free(t_ntt);
+  free(t_target);
+  for (uint64_t i = 0; i < K; ++i) ho_ntt_destroy(plans[i]);
+  free(plans);
+}
+
 /* splitmix64 stream shared by tests, bench and the device-side generator:
  * coefficient i of polynomial `seed` = next() mod bound. */
 void ho_fill_splitmix(uint64_t* out, uint64_t n, uint64_t seed,

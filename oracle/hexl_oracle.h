@@ -99,6 +99,11 @@ void ho_ntt_inverse_batch(const ho_ntt* p, uint64_t* result,
                           const uint64_t* operand, uint64_t batch,
                           uint64_t in_mf, uint64_t out_mf);
 
+void ho_key_switch(uint64_t* result, const uint64_t* t_target_iter, uint64_t n,
+                   uint64_t decomp_modulus_size, uint64_t key_modulus_size,
+                   uint64_t rns_modulus_size, uint64_t key_component_count,
+                   const uint64_t* moduli, const uint64_t* const* k_switch_keys,
+                   const uint64_t* modswitch_factors);
 void ho_fill_splitmix(uint64_t* out, uint64_t n, uint64_t seed,
                       uint64_t bound);
 

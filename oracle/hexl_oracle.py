@@ -72,6 +72,7 @@ def _load():
     sig("ho_ntt_destroy", None, C.c_void_p)
     sig("ho_ntt_forward_batch", None, C.c_void_p, p64, p64, u64, u64, u64)
     sig("ho_ntt_inverse_batch", None, C.c_void_p, p64, p64, u64, u64, u64)
+    sig("ho_key_switch", None, p64, p64, u64, u64, u64, u64, u64, p64, C.POINTER(p64), p64)
     sig("ho_fill_splitmix", None, p64, u64, u64, u64)
     return lib
 
@@ -256,6 +257,19 @@ def dyadic_multiply(op1, op2, n, moduli, result=None):
     if result is None:
         result = np.zeros(3 * n * moduli.size, dtype=np.uint64)
     lib.ho_dyadic_multiply(_p(result), _p(op1), _p(op2), n, _p(moduli), moduli.size)
+    return result
+
+
+def key_switch(result, t_target, n, decomp, key_mod, rns_mod, key_comp, moduli, keys,
+               modswitch_factors):
+    """KeySwitch; `result` (key_comp * decomp * n words) is accumulated into and returned;
+    `keys` is a list of `decomp` arrays of key_comp * key_mod * n words."""
+    result, t_target = _arr(result).copy(), _arr(t_target)
+    moduli, msf = _arr(moduli), _arr(modswitch_factors)
+    keys = [_arr(k) for k in keys]
+    kp = (p64 * len(keys))(*[C.cast(_p(k), p64) for k in keys])
+    lib.ho_key_switch(_p(result), _p(t_target), n, decomp, key_mod, rns_mod, key_comp,
+                      _p(moduli), kp, _p(msf))
     return result
 
 

@@ -300,7 +300,41 @@ static void test_number_theory() {  // test/test-number-theory.cpp
   EXPECT(Not(CMPINT::LT) == CMPINT::NLT && Not(CMPINT::TRUE) == CMPINT::FALSE);
 }
 
-int main() {
+// TEST(KeySwitch, small) through host buffers; data from tests/golden/hexl_kat.json
+// (written next to this file by tests/test_cpp_shim.py as key_switch_kat.txt:
+// n D K R C, moduli, modswitch factors, keys, input, target, expected).
+static void test_key_switch(const char* path) {
+  FILE* f = fopen(path, "r");
+  if (!f) {
+    printf("key_switch KAT file missing, skipped\n");
+    return;
+  }
+  unsigned long long n, D, K, R, C;
+  EXPECT(fscanf(f, "%llu %llu %llu %llu %llu", &n, &D, &K, &R, &C) == 5);
+  auto read = [&](size_t count) {
+    V v(count);
+    for (auto& x : v) {
+      unsigned long long t;
+      EXPECT(fscanf(f, "%llu", &t) == 1);
+      x = t;
+    }
+    return v;
+  };
+  V moduli = read(K), msf = read(D);
+  std::vector<V> keys;
+  for (unsigned long long j = 0; j < D; ++j) keys.push_back(read(C * K * n));
+  V input = read(C * D * n), target = read(D * n), expected = read(C * D * n);
+  fclose(f);
+  std::vector<const uint64_t*> kp;
+  for (auto& k : keys) kp.push_back(k.data());
+  KeySwitch(input.data(), target.data(), n, D, K, R, C, moduli.data(), kp.data(), msf.data());
+  EXPECT(input == expected);
+  EXPECT_THROW(KeySwitch(input.data(), target.data(), n, D, K, R, C, moduli.data(), kp.data(),
+                         msf.data(), moduli.data()));
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1) test_key_switch(argv[1]);
   test_number_theory();
   test_ntt_api();
   test_ntt_powers_and_roots();

@@ -51,6 +51,7 @@ def test_shim_library_exports_reference_api():
                    "unsigned long, unsigned long)",
                    "intel::hexl::EltwiseSubMod(", "intel::hexl::EltwiseMultMod(",
                    "intel::hexl::EltwiseFMAMod(", "intel::hexl::EltwiseReduceMod(",
+                   "intel::hexl::DyadicMultiply(", "intel::hexl::KeySwitch(",
                    "intel::hexl::EltwiseCmpAdd(unsigned long*, unsigned long const*, unsigned long, "
                    "intel::hexl::CMPINT, unsigned long, unsigned long)",
                    "intel::hexl::EltwiseCmpSubMod(unsigned long*, unsigned long const*, unsigned "

@@ -25,10 +25,27 @@ def test_cpp_api_compiles_against_headers():
     assert os.path.exists(EXE)
 
 
+def write_key_switch_kat(path):
+    """The KeySwitch known answer (tests/golden/hexl_kat.json) as plain numbers for the C++ test."""
+    import json
+    case = json.load(open(os.path.join(ROOT, "tests", "golden", "hexl_kat.json")))[
+        "key_switch"]["cases"][0]
+    n, D, C = case["n"], case["decomp_modulus_size"], case["key_component_count"]
+    words = [n, D, case["key_modulus_size"], case["rns_modulus_size"], C]
+    words += case["moduli"] + case["modswitch_factors"]
+    for k in case["keys"]:
+        words += k
+    words += case["input"][:C * D * n] + case["t_target"] + case["out"][:C * D * n]
+    with open(path, "w") as f:
+        f.write("\n".join(str(w) for w in words) + "\n")
+
+
 @pytest.mark.gpu
-def test_cpp_shim_kats_on_gpu():
+def test_cpp_shim_kats_on_gpu(tmp_path):
     build_exe()
+    kat = str(tmp_path / "key_switch_kat.txt")
+    write_key_switch_kat(kat)
     env = dict(os.environ, LD_LIBRARY_PATH=LIB + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
-    r = subprocess.run([EXE], capture_output=True, text=True, env=env, timeout=600)
+    r = subprocess.run([EXE, kat], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all C++ shim checks passed" in r.stdout

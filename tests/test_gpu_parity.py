@@ -606,3 +606,57 @@ def test_dyadic_multiply_rejects_bad_arguments(hx):
         hx.DyadicMultiply(d, d, d, 3, [1])
     with pytest.raises(hx.HexlAmdError):
         hx.DyadicMultiply(d, d, d, 3, [1 << 62])
+
+
+# ---------------------------------------------------------------- KeySwitch
+def _run_key_switch(hx, result, target, n, D, K, R, C, moduli, keys, msf):
+    d_res = dev(hx, result)
+    hx.KeySwitch(d_res, dev(hx, target), n, D, K, R, C, moduli, [dev(hx, k) for k in keys], msf)
+    return host(hx, d_res)
+
+
+@pytest.mark.parametrize("case", KAT["key_switch"]["cases"])
+def test_key_switch_kat(hx, case):
+    """TEST(KeySwitch, small), test/experimental/seal/test-key-switch.cpp:16-190."""
+    n, D, C = case["n"], case["decomp_modulus_size"], case["key_component_count"]
+    inp = U(case["input"])
+    got = _run_key_switch(hx, inp[:C * D * n], case["t_target"], n, D, case["key_modulus_size"],
+                          case["rns_modulus_size"], C, case["moduli"], case["keys"],
+                          case["modswitch_factors"])
+    assert got.tolist() == case["out"][:C * D * n]
+    assert case["input"][C * D * n:] == case["out"][C * D * n:]  # the tail is never written
+
+
+@pytest.mark.parametrize("n,D,K,C,bits", [(1024, 1, 2, 2, 40), (4096, 3, 4, 2, 50),
+                                          (8192, 4, 6, 3, 60), (2048, 2, 3, 2, 30)])
+def test_key_switch_random_vs_oracle(hx, ho, n, D, K, C, bits):
+    """Random RNS bases (mixed sizes so that both the reduce and the copy branches of
+    key-switch-internal.cpp:77-86 / :159-167 are taken), more key moduli than used."""
+    rng = np.random.default_rng(n + D)
+    primes = [int(q) for q in ho.generate_primes(K, bits, True, n)]
+    if D >= 2:  # one smaller and one larger decomposition modulus than the special prime
+        primes[0] = int(ho.generate_primes(1, bits - 5, True, n)[0])
+        primes[1] = int(ho.generate_primes(1, min(bits + 1, 60), False, n)[0])
+    moduli = primes
+    R = D + 1
+    target = np.concatenate([rng.integers(0, moduli[j], n, dtype=np.uint64) for j in range(D)])
+    keys = []
+    for j in range(D):
+        keys.append(np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                                    for _ in range(C) for i in range(K)]))
+    msf = [int(rng.integers(1, moduli[i], dtype=np.uint64)) for i in range(D)]
+    result = np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                             for _ in range(C) for i in range(D)])
+    want = ho.key_switch(result, target, n, D, K, R, C, moduli, keys, msf)
+    got = _run_key_switch(hx, result, target, n, D, K, R, C, moduli, keys, msf)
+    assert np.array_equal(got, want)
+
+
+def test_key_switch_rejects_bad_arguments(hx, ho):
+    n = 16
+    q = [int(x) for x in ho.generate_primes(3, 40, True, n)]
+    d = dev(hx, np.zeros(4 * n, dtype=np.uint64))
+    with pytest.raises(hx.HexlAmdError):   # rns_modulus_size != decomp + 1
+        hx.KeySwitch(d, d, n, 2, 3, 2, 2, q, [d, d], [1, 1])
+    with pytest.raises(hx.HexlAmdError):   # composite modulus
+        hx.KeySwitch(d, d, n, 2, 3, 3, 2, [q[0], 1000, q[2]], [d, d], [1, 1])

@@ -380,3 +380,19 @@ def test_dyadic_multiply_against_python_ints():
                 want = ([x0 * y0 % q, (x0 * y1 + x1 * y0) % q, x1 * y1 % q] if e < n_proc
                         else [7, 7, 7])
                 assert [int(res[p * n * k + i * n + e]) for p in range(3)] == want
+
+
+# ---------------------------------------------------------------- KeySwitch
+def _key_switch_args(case):
+    return (case["n"], case["decomp_modulus_size"], case["key_modulus_size"],
+            case["rns_modulus_size"], case["key_component_count"], case["moduli"], case["keys"],
+            case["modswitch_factors"])
+
+
+@pytest.mark.parametrize("case", KAT["key_switch"]["cases"])
+def test_key_switch_kat(case):
+    """TEST(KeySwitch, small), test/experimental/seal/test-key-switch.cpp:16-190: pins the
+    oracle's inverse/forward NTTs with lazy outputs, ReduceMod, the 128-bit accumulation and
+    FMAMod(8) in one composite known answer."""
+    got = ho.key_switch(case["input"], case["t_target"], *_key_switch_args(case))
+    assert got.tolist() == case["out"]

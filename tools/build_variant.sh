@@ -10,7 +10,7 @@ ROOT=${SRC_ROOT:-$ROOT}
 OUT=$(cd "$(dirname "$0")" && pwd)
 NAME=$1; shift
 T=$(mktemp -d)
-for f in ntt_kernels.hip eltwise_kernels.hip; do
+for f in ntt_kernels.hip eltwise_kernels.hip keyswitch_kernels.hip; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" \
     -Wno-unused-command-line-argument -I$ROOT/include -I$ROOT/hexl_amd/csrc \
     -c $ROOT/hexl_amd/csrc/$f -o $T/$f.o &

@@ -740,6 +740,13 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
   }
 }
 
+// (Round-1 experiment, removed: `tile_stream`, a persistent variant of the bottom pass
+// with two LDS tile buffers per workgroup, the next tile prefetched by
+// `global_load ... lds` DMA (no VGPRs, permutation applied on the global side) and the
+// wait for it placed in front of the stores.  Bit-exact, but 1.17-1.21 ms against
+// 1.07 ms: two buffers cap occupancy at 5 waves/SIMD, and what a wave no longer waits
+// for HBM it waits for the VALU and the extra barrier instead.  See DESIGN.md.)
+
 // ---------------------------------------------------------------------------
 // Host-side planning and launch
 // ---------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 """Developer diagnostic: where does a block_pass workgroup spend its life?
 
 Loads tools/libhexl_amd_phaseprof.so (the product sources built with
--DHEXL_AMD_PHASE_PROFILE, see tools/build_phaseprof.sh), runs the forward NTT at
+`tools/build_variant.sh phaseprof -DHEXL_AMD_PHASE_PROFILE`), runs the forward NTT at
 the headline shape and prints, per phase, the mean / p50 / p90 number of shader
 cycles a wave spends between consecutive stamps.
 """
@@ -25,7 +25,8 @@ Q = 18014398510661633
 plan = vp()
 assert lib.hexl_amd_ntt_create(C.byref(plan), N, Q, 0, 0) == 0, lib.hexl_amd_last_error()
 data = torch.randint(0, Q, (BATCH, N), dtype=torch.int64, device="cuda")
-blocks = BATCH * N // 4096
+TILE = int(os.environ.get("PHASE_TILE", "2048"))  # elements per workgroup of the tile pass
+blocks = BATCH * N // TILE
 stamps = torch.zeros((blocks, 8, 16), dtype=torch.int64, device="cuda")
 for it in range(3):
     stamps.zero_()
@@ -36,6 +37,7 @@ for it in range(3):
     torch.cuda.synchronize()
     lib.hexl_amd_debug_set_phase_buf(None)
 s = stamps.cpu().numpy().astype(np.int64)
+s = s[:, :TILE // 512, :]  # waves a workgroup really has
 names = {1: "global loads landed", 2: "round 0 compute", 3: "LDS store + block barrier",
          4: "round 1 (load, compute, store, wave sync)", 5: "round 2", 6: "round 3",
          8: "copy-out: LDS read, finish, issue stores", 9: "stores acknowledged"}

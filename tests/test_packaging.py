@@ -1,0 +1,67 @@
+"""Packaging parity: the install tree answers find_package(HEXL 1.2.5)
+and pkg-config like the reference's (hexl/CMakeLists.txt:114-215)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def prefix(tmp_path_factory):
+    from hexl_amd.install import install
+    return install(str(tmp_path_factory.mktemp("prefix")))
+
+
+def test_install_tree_layout(prefix):
+    for rel in ("include/hexl/hexl.hpp", "include/hexl/ntt/ntt.hpp", "include/hexl_amd.h",
+                "lib/libhexl.so", "lib/libhexl_amd.so", "lib/cmake/hexl-1.2.5/HEXLConfig.cmake",
+                "lib/cmake/hexl-1.2.5/HEXLConfigVersion.cmake",
+                "lib/cmake/hexl-1.2.5/HEXLTargets.cmake", "lib/pkgconfig/hexl.pc"):
+        assert os.path.exists(os.path.join(prefix, rel)), rel
+    pc = open(os.path.join(prefix, "lib", "pkgconfig", "hexl.pc")).read()
+    assert "Version: 1.2.5" in pc and "-lhexl" in pc
+
+
+def _configure_and_build(prefix, tmp_path, version="1.2.5"):
+    src = tmp_path / "src"
+    shutil.copytree(os.path.join(ROOT, "tests", "cpp", "consumer"), src)
+    if version != "1.2.5":
+        p = src / "CMakeLists.txt"
+        p.write_text(p.read_text().replace("HEXL 1.2.5", "HEXL " + version))
+    build = tmp_path / "build"
+    r = subprocess.run(["cmake", "-S", str(src), "-B", str(build),
+                        "-DCMAKE_PREFIX_PATH=" + prefix, "-DCMAKE_BUILD_TYPE=Release"],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        return r, None
+    r = subprocess.run(["cmake", "--build", str(build)], capture_output=True, text=True)
+    return r, build / "consumer"
+
+
+def test_find_package_consumer_builds(prefix, tmp_path):
+    if shutil.which("cmake") is None:
+        pytest.skip("cmake not available")
+    r, exe = _configure_and_build(prefix, tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert os.path.exists(exe)
+
+
+def test_find_package_is_exact_version(prefix, tmp_path):
+    """COMPATIBILITY ExactVersion (hexl/CMakeLists.txt:180-183): 1.2.4 must not resolve."""
+    if shutil.which("cmake") is None:
+        pytest.skip("cmake not available")
+    r, _ = _configure_and_build(prefix, tmp_path, version="1.2.4")
+    assert r.returncode != 0
+
+
+@pytest.mark.gpu
+def test_find_package_consumer_runs_on_gpu(prefix, tmp_path):
+    if shutil.which("cmake") is None:
+        pytest.skip("cmake not available")
+    r, exe = _configure_and_build(prefix, tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "consumer OK" in out.stdout, out.stdout + out.stderr

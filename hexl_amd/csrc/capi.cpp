@@ -194,7 +194,7 @@ int hexl_amd_ntt_create(hexl_amd_ntt** out, uint64_t degree, uint64_t modulus,
   }
   // Device tables: heap-ordered (value, Shoup factor) pairs; the factor has 63
   // fractional bits under the Lazy arithmetic policy, 64 otherwise.
-  const u64 shoup_bits = q < kLazyModulusBound ? 63 : 64;
+  const u64 shoup_bits = q < kSmallModulusBound ? 32 : q < kLazyModulusBound ? 63 : 64;
   std::vector<ulonglong2> hf(n), hi(n);
   for (u64 i = 0; i < n; ++i) {
     hf[i].x = R[i];

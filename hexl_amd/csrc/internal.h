@@ -19,6 +19,9 @@ struct InvLast {
 // Moduli below this bound use the Lazy arithmetic policy (modarith.h); their
 // device tables carry 63-bit Shoup factors.
 constexpr u64 kLazyModulusBound = 1ull << 56;
+// Moduli below this bound use the Small policy (32-bit arithmetic); their device
+// tables carry 32-bit Shoup factors.
+constexpr u64 kSmallModulusBound = 1ull << 30;
 
 // Device-resident state of one NTT plan.
 struct NttTables {

@@ -142,10 +142,29 @@ HX_HD u64 mul_add_lazy2(u64 acc, u64 D, u64 W, u64 W63, u64 neg_two_q) {
 
 struct Strict {  // any q < 2^62; tables hold floor(W * 2^64 / q); plain values
   static constexpr bool kLazy = false;
+  static constexpr bool kSmall = false;
 };
 struct Lazy {  // q < 2^56; tables hold floor(W * 2^63 / q); doubled values
   static constexpr bool kLazy = true;
+  static constexpr bool kSmall = false;
 };
+// q < 2^30 (the reference's 32-bit path, hexl/ntt/ntt-internal.cpp:218-226,
+// :279-287): every value of the Strict invariants is below 4q < 2^32, so the
+// arithmetic runs on the low words only -- Shoup factor floor(W * 2^32 / q), three
+// 32-bit multiplies per butterfly instead of nine, conditional subtraction as one
+// v_sub + v_min_u32.  Storage stays 64-bit (the API's), high words zero.
+struct Small {
+  static constexpr bool kLazy = false;
+  static constexpr bool kSmall = true;
+};
+
+// x*W - floor(x*Wp / 2^32)*q in [0, 2q) for any 32-bit x; W < q < 2^30, Wp = floor(W 2^32 / q)
+HX_HD u32 mul_small(u32 x, u32 W, u32 Wp, u32 q) { return x * W - mul_hi32(x, Wp) * q; }
+// x - m if x >= m else x, as min(x, x - m) on unsigned words
+HX_HD u32 csub32(u32 x, u32 m) {
+  const u32 t = x - m;
+  return t < x ? t : x;
+}
 
 // Value as held inside a transform <-> value in the caller's buffer.
 template <class A>
@@ -160,6 +179,11 @@ HX_HD void fwd_butterfly(u64& x, u64& y, u64 W, u64 Wp, const ModConst& m) {
     const u64 xs = mul_add_lazy2<false>(x, y, W, Wp, m.neg_two_q);
     y = (x << 1) + m.six_q - xs;
     x = xs;
+  } else if (A::kSmall) {
+    const u32 tx = csub32((u32)x, (u32)m.two_q);
+    const u32 T = mul_small((u32)y, (u32)W, (u32)Wp, (u32)m.q);
+    x = tx + T;
+    y = tx + (u32)m.two_q - T;
   } else {
     const u64 tx = csub(x, m.two_q);
     const u64 T = mul_lazy(y, W, Wp, m.q);
@@ -182,6 +206,7 @@ HX_HD u64 fwd_finish(u64 x, const ModConst& m, bool canonical) {
     if (canonical) r2 = csub_neg(r2, m.neg_two_q);
     return r2 >> 1;
   }
+  if (A::kSmall) return canonical ? csub32(csub32((u32)x, (u32)m.two_q), (u32)m.q) : x;
   return canonical ? csub(csub(x, m.two_q), m.q) : x;
 }
 
@@ -197,6 +222,10 @@ HX_HD void inv_butterfly(u64& x, u64& y, u64 W, u64 Wp, const ModConst& m, int k
     const u64 d = x + (m.two_q << (k + 2)) - y;
     x = BOUND ? csub_neg(s, m.neg_two_q << 2) : s;
     y = mul_add_lazy2<false>(0, d, W, Wp, m.neg_two_q);
+  } else if (A::kSmall) {
+    const u32 d = (u32)x + (u32)m.two_q - (u32)y;
+    x = csub32((u32)s, (u32)m.two_q);
+    y = mul_small(d, (u32)W, (u32)Wp, (u32)m.q);
   } else {
     const u64 d = x + m.two_q - y;
     x = csub(s, m.two_q);
@@ -216,6 +245,10 @@ HX_HD void inv_butterfly_last(u64& x, u64& y, u64 n1, u64 n1p, u64 n1w, u64 n1wp
     const u64 d = x + (m.two_q << (k + 2)) - y;
     x = mul_add_lazy2<true>(0, s, n1, n1p, m.neg_two_q);
     y = mul_add_lazy2<true>(0, d, n1w, n1wp, m.neg_two_q);
+  } else if (A::kSmall) {
+    const u32 d = (u32)x + (u32)m.two_q - (u32)y;
+    x = mul_small((u32)s, (u32)n1, (u32)n1p, (u32)m.q);
+    y = mul_small(d, (u32)n1w, (u32)n1wp, (u32)m.q);
   } else {
     const u64 d = x + m.two_q - y;
     x = mul_lazy(s, n1, n1p, m.q);
@@ -230,6 +263,7 @@ HX_HD u64 inv_finish(u64 v, const ModConst& m, bool canonical) {
     if (canonical) v = csub_neg(v, m.neg_two_q);
     return v >> 1;
   }
+  if (A::kSmall) return canonical ? csub32((u32)v, (u32)m.q) : v;
   return canonical ? csub(v, m.q) : v;
 }
 

@@ -1013,6 +1013,8 @@ static hipError_t transform_impl(const NttTables& t, u64* result, const u64* ope
 hipError_t ntt_forward_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
                               u64 out_mf, hipStream_t st) {
   if (batch == 0) return hipSuccess;
+  if (t.mod.q < kSmallModulusBound)
+    return transform_impl<true, Small>(t, result, operand, batch, out_mf, st);
   if (t.mod.q < kLazyModulusBound)
     return transform_impl<true, Lazy>(t, result, operand, batch, out_mf, st);
   return transform_impl<true, Strict>(t, result, operand, batch, out_mf, st);
@@ -1021,6 +1023,8 @@ hipError_t ntt_forward_launch(const NttTables& t, u64* result, const u64* operan
 hipError_t ntt_inverse_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
                               u64 out_mf, hipStream_t st) {
   if (batch == 0) return hipSuccess;
+  if (t.mod.q < kSmallModulusBound)
+    return transform_impl<false, Small>(t, result, operand, batch, out_mf, st);
   if (t.mod.q < kLazyModulusBound)
     return transform_impl<false, Lazy>(t, result, operand, batch, out_mf, st);
   return transform_impl<false, Strict>(t, result, operand, batch, out_mf, st);

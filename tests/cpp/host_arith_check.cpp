@@ -47,7 +47,7 @@ template <class A>
 static void check(u64 n, u64 q, const std::vector<int>& inv_runs, u64 in_mf_f, u64 in_mf_i) {
   int L = 0;
   while ((1ull << L) < n) ++L;
-  const u64 shoup = A::kLazy ? 63 : 64;
+  const u64 shoup = A::kSmall ? 32 : A::kLazy ? 63 : 64;
   std::vector<u64> R(n), Rp(n), Ri_stage(n), Rip_stage(n);
   ho_ntt_tables(n, q, ho_minimal_primitive_root(2 * n, q), R.data(), Rp.data(), Ri_stage.data(),
                 Rip_stage.data());
@@ -232,6 +232,18 @@ int main() {
         check<Lazy>(c.n, primes[pi], runs, 1, 1);
         check<Strict>(c.n, primes[pi], runs, 4, 2);
       }
+  }
+  // Small policy: q < 2^30, up to the bound (GeneratePrimes(., 29, false, .) walks down from 2^30)
+  {
+    const Case small_cases[] = {{16, 10}, {1024, 20}, {4096, 28}, {65536, 29}};
+    for (const Case& c : small_cases) {
+      size_t got = ho_generate_primes(primes, 2, c.bits, 1, c.n);
+      got += ho_generate_primes(primes + got, 2, c.bits, 0, c.n);
+      for (size_t pi = 0; pi < got; ++pi) {
+        check<Small>(c.n, primes[pi], run_sets[0], 4, 2);
+        check<Small>(c.n, primes[pi], run_sets[1], 1, 1);
+      }
+    }
   }
   // the largest primes below 2^56 (GeneratePrimes(., 55, false, .) walks downwards)
   {

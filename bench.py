@@ -107,13 +107,21 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # Dry-run hooks for a 1-GPU box (tests of the multi-rank code path): BENCH_ONE_DEVICE=1
+    # puts every rank on cuda:0, BENCH_BACKEND=gloo replaces RCCL for the barrier / max.
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if os.environ.get("BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     def barrier():
         if dist is not None:
@@ -151,7 +159,7 @@ def main():
     # fwd followed by inv is the identity: the data must be back where it started
     assert torch.equal(check, data[:2]), "round trip mismatch inside the timed region"
 
-    elapsed = max_over_ranks(elapsed, dist, device="cuda")
+    elapsed = max_over_ranks(elapsed, dist, device="cuda" if backend == "nccl" else "cpu")
 
     ntts = 2 * batch * args.steps * world
     value = ntts / elapsed

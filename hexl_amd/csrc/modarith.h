@@ -63,6 +63,13 @@ HX_HD u64 csub_neg(u64 x, u64 neg_m) {
   return (int32_t)(u32)(t >> 32) < 0 ? x : t;
 }
 
+// The same for any 64-bit x, m > 0: t = x + (-m) wraps above x exactly when x < m;
+// one v_lshl_add_u64, one 64-bit compare, two v_cndmask.  neg_m = 2^64 - m.
+HX_HD u64 csub_wrap(u64 x, u64 neg_m) {
+  const u64 t = x + neg_m;
+  return t <= x ? t : x;
+}
+
 // Shoup / Harvey lazy product: x*W - floor(x*Wp / 2^64)*q  in [0, 2q) for ANY
 // 64-bit x, W < q, Wp = floor(W * 2^64 / q).
 HX_HD u64 mul_lazy(u64 x, u64 W, u64 Wp, u64 q) {
@@ -74,8 +81,9 @@ HX_HD u64 mul_lazy(u64 x, u64 W, u64 Wp, u64 q) {
 struct ModConst {
   u64 q;
   u64 two_q;
-  // Lazy policy only:
+  u64 neg_q;  // 2^64 - q (Strict policy)
   u64 neg_two_q;  // 2^64 - 2q
+  // Lazy policy only:
   u64 six_q;
   u32 fin_mul;    // floor(2^(31 + fin_shift) / q)
   u32 fin_shift;  // floor(log2 q)
@@ -85,6 +93,7 @@ inline ModConst make_mod_const(u64 q) {  // host only
   ModConst m;
   m.q = q;
   m.two_q = q << 1;
+  m.neg_q = 0 - q;
   m.neg_two_q = 0 - (q << 1);
   m.six_q = 6 * q;  // only meaningful (and only read) for q < 2^56
   u32 b = 0;
@@ -140,6 +149,40 @@ HX_HD u64 mul_add_lazy2(u64 acc, u64 D, u64 W, u64 W63, u64 neg_two_q) {
   return ((u64)hi << 32) | (u32)lo;
 }
 
+// Strict-policy product for ANY 64-bit y: acc + (y*W - floor(y*Wp / 2^64)*q) mod 2^64,
+// the exact Harvey lazy product in [0, 2q) (number-theory.hpp:127-141) written as
+// a v_mad_u64_u32 chain.  The middle column a1*b0 + a0*b1 + hi(a0*b0) can exceed
+// 64 bits here, so it is summed in two steps whose carries are explicit:
+//   S1 = a1*b0 + hi(a0*b0)  (< 2^64),  (carry, T1) = a0*b1 + S1  (65 bits),
+//   Q  = a1*b1 + (carry * 2^32 + hi32(T1)).
+// 10 multiplies and ~8 other instructions instead of the ~30 of __umul64hi plus
+// two 64-bit low products.
+HX_HD u64 mul_add_strict(u64 acc, u64 y, u64 W, u64 Wp, u64 neg_q) {
+  const u32 a0 = (u32)y, a1 = (u32)(y >> 32);
+  const u32 b0 = (u32)Wp, b1 = (u32)(Wp >> 32);
+  u64 S1 = (u64)a1 * b0 + mul_hi32(a0, b0);
+  HX_OPAQUE(S1);
+  u64 T1;
+  const bool carry = __builtin_add_overflow((u64)a0 * b1, S1, &T1);  // mad with carry-out
+  const u64 Q = (u64)a1 * b1 + ((T1 >> 32) | ((u64)carry << 32));
+  const u32 w0 = (u32)W, w1 = (u32)(W >> 32);
+  const u32 q0 = (u32)Q, q1 = (u32)(Q >> 32);
+  const u32 n0 = (u32)neg_q, n1 = (u32)(neg_q >> 32);
+  u64 lo = (u64)a0 * w0 + acc;
+  lo = (u64)q0 * n0 + lo;
+  u64 c = (u64)a0 * w1;
+  HX_OPAQUE(c);
+  c = (u64)a1 * w0 + c;
+  HX_OPAQUE(c);
+  c = (u64)q0 * n1 + c;
+  HX_OPAQUE(c);
+  c = (u64)q1 * n0 + c;
+  HX_OPAQUE(c);
+  u32 hi = (u32)(lo >> 32) + (u32)c;
+  HX_OPAQUE(hi);
+  return ((u64)hi << 32) | (u32)lo;
+}
+
 struct Strict {  // any q < 2^62; tables hold floor(W * 2^64 / q); plain values
   static constexpr bool kLazy = false;
   static constexpr bool kSmall = false;
@@ -185,10 +228,10 @@ HX_HD void fwd_butterfly(u64& x, u64& y, u64 W, u64 Wp, const ModConst& m) {
     x = tx + T;
     y = tx + (u32)m.two_q - T;
   } else {
-    const u64 tx = csub(x, m.two_q);
-    const u64 T = mul_lazy(y, W, Wp, m.q);
-    x = tx + T;
-    y = tx + m.two_q - T;
+    const u64 tx = csub_wrap(x, m.neg_two_q);
+    const u64 xs = mul_add_strict(tx, y, W, Wp, m.neg_q);
+    y = (tx << 1) + m.two_q - xs;  // = tx + 2q - T (mod 2^64; the true value is < 4q)
+    x = xs;
   }
 }
 
@@ -228,8 +271,8 @@ HX_HD void inv_butterfly(u64& x, u64& y, u64 W, u64 Wp, const ModConst& m, int k
     y = mul_small(d, (u32)W, (u32)Wp, (u32)m.q);
   } else {
     const u64 d = x + m.two_q - y;
-    x = csub(s, m.two_q);
-    y = mul_lazy(d, W, Wp, m.q);
+    x = csub_wrap(s, m.neg_two_q);
+    y = mul_add_strict(0, d, W, Wp, m.neg_q);
   }
 }
 
@@ -251,8 +294,8 @@ HX_HD void inv_butterfly_last(u64& x, u64& y, u64 n1, u64 n1p, u64 n1w, u64 n1wp
     y = mul_small(d, (u32)n1w, (u32)n1wp, (u32)m.q);
   } else {
     const u64 d = x + m.two_q - y;
-    x = mul_lazy(s, n1, n1p, m.q);
-    y = mul_lazy(d, n1w, n1wp, m.q);
+    x = mul_add_strict(0, s, n1, n1p, m.neg_q);
+    y = mul_add_strict(0, d, n1w, n1wp, m.neg_q);
   }
 }
 

@@ -8,7 +8,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hexl_amd as hx  # noqa: E402
 
-N, B = 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+N = int(os.environ.get("NTT_N", "65536"))
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 q = int(os.environ.get("NTT_Q", "18014398510661633"))
 ntt = hx.NTT(N, q)
 x = torch.empty((B, N), dtype=torch.int64, device="cuda")

@@ -165,19 +165,25 @@ struct CmpSubModOp {
   }
 };
 
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+
 template <class Op, bool HAS_B>
 __global__ void __launch_bounds__(256)
 eltwise_vec2(u64* __restrict__ res, const u64* __restrict__ a, const u64* __restrict__ b,
              u64 npairs, Op op) {
-  const ulonglong2* a2 = reinterpret_cast<const ulonglong2*>(a);
-  const ulonglong2* b2 = reinterpret_cast<const ulonglong2*>(b);
-  ulonglong2* r2 = reinterpret_cast<ulonglong2*>(res);
+  const u64x2* a2 = reinterpret_cast<const u64x2*>(a);
+  const u64x2* b2 = reinterpret_cast<const u64x2*>(b);
+  u64x2* r2 = reinterpret_cast<u64x2*>(res);
   const u64 stride = (u64)gridDim.x * 256;
   for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < npairs; i += stride) {
-    const ulonglong2 va = a2[i];
-    ulonglong2 vb = make_ulonglong2(0, 0);
-    if (HAS_B) vb = b2[i];
-    r2[i] = make_ulonglong2(op(va.x, vb.x), op(va.y, vb.y));
+    // nontemporal 16-byte accesses: the vectors are streamed once
+    const u64x2 va = __builtin_nontemporal_load(a2 + i);
+    u64x2 vb = {0, 0};
+    if (HAS_B) vb = __builtin_nontemporal_load(b2 + i);
+    u64x2 vr;
+    vr.x = op(va.x, vb.x);
+    vr.y = op(va.y, vb.y);
+    __builtin_nontemporal_store(vr, r2 + i);
   }
 }
 

@@ -756,7 +756,9 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
 // `global_load ... lds` DMA (no VGPRs, permutation applied on the global side) and the
 // wait for it placed in front of the stores.  Bit-exact, but 1.17-1.21 ms against
 // 1.07 ms: two buffers cap occupancy at 5 waves/SIMD, and what a wave no longer waits
-// for HBM it waits for the VALU and the extra barrier instead.  See DESIGN.md.)
+// for HBM it waits for the VALU and the extra barrier instead.  A second persistent
+// variant prefetching the next tile into 16 spare VGPRs (6 waves/SIMD) measured
+// 1.25 ms against 1.04 ms.  See DESIGN.md.)
 
 // ---------------------------------------------------------------------------
 // Host-side planning and launch

@@ -358,7 +358,7 @@ strided_pass(u64* __restrict__ out, const u64* __restrict__ in,
 }
 
 // ---------------------------------------------------------------------------
-// tile_pass: S stages on a 4096-element tile staged through LDS
+// tile_pass: S stages on a 2^TL-element tile staged through LDS
 // ---------------------------------------------------------------------------
 // Tile size is a template parameter TL (log2 elements): 10 -> 1024 elements (8 KiB
 // of LDS, 128 threads = 2 waves, 16 workgroups per CU) for N <= 2^10, 11 -> 2048
@@ -441,12 +441,10 @@ __device__ __forceinline__ u64 tile_uniform_offset(const TileGeom& g, u32 dp) {
   return g.base + ((u64)(dp >> CB) << g.log_row);
 }
 
-// Twiddles of round j for every sub-run this thread owns in that round.
-// Wave-uniform twiddles (gap >= 64) are fetched up front with scalar loads (no
-// VGPR cost).  Per-lane twiddles are fetched up front too unless HOIST is false:
-// the persistent kernel leaves them to the compiler's per-stage loads because the
-// registers are needed for the next tile's prefetch.
-template <int S, int CB, int TL, int j, bool HOIST = true>
+// Twiddles of round j for every sub-run this thread owns in that round, all
+// requested before the round's first butterfly.  Wave-uniform twiddles (gap >= 64)
+// come through scalar loads (no VGPR cost), the others through per-lane loads.
+template <int S, int CB, int TL, int j>
 __device__ __forceinline__ void round_twiddles(ulonglong2* wv, const ulonglong2* __restrict__ tw,
                                                u32 tid, const TileGeom& g) {
   using RD = Rounds<S, CB>;
@@ -660,11 +658,10 @@ __device__ __forceinline__ void store_elem(u64* __restrict__ out, u32 tid, int i
 #endif
 }
 
-// One workgroup per tile.  (A persistent variant -- each workgroup looping over
-// tiles with the next tile's loads prefetched into dead registers -- was built
-// and measured in round 1: it was 14 % SLOWER, because the four workgroups of a
-// CU then march in lockstep and the phase diversity that overlaps one
-// workgroup's memory waits with another's arithmetic is lost.  See DESIGN.md.)
+// One workgroup per tile; the hardware refills a CU's slots as workgroups retire.
+// (Three persistent variants were built and measured in round 1 -- register
+// prefetch at 8 and at 6 waves per SIMD, LDS-direct DMA prefetch -- all slower, see
+// the note after the kernel and DESIGN.md.)
 //
 // FWD:  global --(round 0)--> LDS --(rounds 1..)--> LDS --> coalesced store
 // INV:  coalesced load --> LDS --(rounds NR-1..1)--> LDS --(round 0)--> global

@@ -136,3 +136,19 @@ def test_no_product_file_touches_the_oracle():
                 if f.endswith((".py", ".h", ".hpp", ".cpp", ".hip")):
                     text = open(os.path.join(d, f), errors="ignore").read()
                     assert "hexl_oracle" not in text and "oracle/" not in text, os.path.join(d, f)
+
+
+def test_c_abi_header_is_plain_c(tmp_path):
+    """include/hexl_amd.h is a C header: C99, pedantic, no C++ or HIP types, and links against
+    the library from a C translation unit."""
+    import subprocess
+    src = tmp_path / "c_abi_check.c"
+    src.write_text('#include "hexl_amd.h"\n'
+                   'int main(void) { int n = 0; (void)hexl_amd_device_count(&n);\n'
+                   '  return hexl_amd_last_error() == 0; }\n')
+    exe = tmp_path / "c_abi_check"
+    lib = os.path.join(ROOT, "hexl_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic",
+                           "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L" + lib, "-lhexl_amd", "-Wl,-rpath," + lib])
+    assert os.path.exists(exe)

@@ -660,3 +660,20 @@ def test_key_switch_rejects_bad_arguments(hx, ho):
         hx.KeySwitch(d, d, n, 2, 3, 2, 2, q, [d, d], [1, 1])
     with pytest.raises(hx.HexlAmdError):   # composite modulus
         hx.KeySwitch(d, d, n, 2, 3, 3, 2, [q[0], 1000, q[2]], [d, d], [1, 1])
+
+
+# ---------------------------------------------------------------- maximum degree
+@pytest.mark.parametrize("log_n,bits", [(18, 54), (19, 61), (20, 54), (20, 29)])
+def test_ntt_maximum_degrees(hx, ho, log_n, bits):
+    """N up to 2^20 = NTT::MaxDegreeBits() (hexl/include/hexl/ntt/ntt.hpp:197): plans with two
+    strided passes in front of the tile pass, all three arithmetic policies."""
+    n = 1 << log_n
+    q = ho.generate_primes(1, bits, True, n)[0]
+    x = ho.fill_splitmix(n, log_n * 31 + bits, q)
+    want = ho.NTT(n, q).forward(x, 1, 1)
+    gnt = hx.NTT(n, q)
+    d = dev(hx, x)
+    gnt.ComputeForward(d, d, 1, 1)
+    assert np.array_equal(host(hx, d), want)
+    gnt.ComputeInverse(d, d, 1, 1)
+    assert np.array_equal(host(hx, d), x)

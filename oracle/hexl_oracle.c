@@ -754,6 +754,24 @@ void ho_key_switch(uint64_t* result, const uint64_t* t_target_iter, uint64_t n,
   free(plans);
 }
 
+void ho_ntt_forward_batch_avx512(const ho_ntt* p, uint64_t* result,
+                                 const uint64_t* operand, uint64_t batch,
+                                 uint64_t in_mf, uint64_t out_mf) {
+  for (uint64_t b = 0; b < batch; ++b)
+    ho_ntt_forward_radix2_avx512(result + b * p->n, operand + b * p->n, p->n,
+                                 p->q, p->root_pows, p->precon_root_pows,
+                                 in_mf, out_mf);
+}
+
+void ho_ntt_inverse_batch_avx512(const ho_ntt* p, uint64_t* result,
+                                 const uint64_t* operand, uint64_t batch,
+                                 uint64_t in_mf, uint64_t out_mf) {
+  for (uint64_t b = 0; b < batch; ++b)
+    ho_ntt_inverse_radix2_avx512(result + b * p->n, operand + b * p->n, p->n,
+                                 p->q, p->inv_root_pows,
+                                 p->precon_inv_root_pows, in_mf, out_mf);
+}
+
 /* splitmix64 stream shared by tests, bench and the device-side generator:
  * coefficient i of polynomial `seed` = next() mod bound. */
 void ho_fill_splitmix(uint64_t* out, uint64_t n, uint64_t seed,

@@ -47,6 +47,19 @@ void ho_ntt_inverse_radix2(uint64_t* result, const uint64_t* operand,
                            const uint64_t* inv_root_pows,
                            const uint64_t* precon_inv_root_pows, uint64_t in_mf,
                            uint64_t out_mf);
+/* hexl_oracle_avx512.c: 8-lane variants of the two transforms above (cpu_baseline
+ * of bench.py); call only when ho_has_avx512() != 0. */
+int ho_has_avx512(void);
+void ho_ntt_forward_radix2_avx512(uint64_t* result, const uint64_t* operand,
+                                  uint64_t n, uint64_t q,
+                                  const uint64_t* root_pows,
+                                  const uint64_t* precon_root_pows,
+                                  uint64_t in_mf, uint64_t out_mf);
+void ho_ntt_inverse_radix2_avx512(uint64_t* result, const uint64_t* operand,
+                                  uint64_t n, uint64_t q,
+                                  const uint64_t* inv_root_pows,
+                                  const uint64_t* precon_inv_root_pows,
+                                  uint64_t in_mf, uint64_t out_mf);
 void ho_ntt_forward_reference(uint64_t* operand, uint64_t n, uint64_t q,
                               const uint64_t* root_pows);
 void ho_ntt_inverse_reference(uint64_t* operand, uint64_t n, uint64_t q,
@@ -104,6 +117,12 @@ void ho_key_switch(uint64_t* result, const uint64_t* t_target_iter, uint64_t n,
                    uint64_t rns_modulus_size, uint64_t key_component_count,
                    const uint64_t* moduli, const uint64_t* const* k_switch_keys,
                    const uint64_t* modswitch_factors);
+void ho_ntt_forward_batch_avx512(const ho_ntt* p, uint64_t* result,
+                                 const uint64_t* operand, uint64_t batch,
+                                 uint64_t in_mf, uint64_t out_mf);
+void ho_ntt_inverse_batch_avx512(const ho_ntt* p, uint64_t* result,
+                                 const uint64_t* operand, uint64_t batch,
+                                 uint64_t in_mf, uint64_t out_mf);
 void ho_fill_splitmix(uint64_t* out, uint64_t n, uint64_t seed,
                       uint64_t bound);
 

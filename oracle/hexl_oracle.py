@@ -73,6 +73,11 @@ def _load():
     sig("ho_ntt_forward_batch", None, C.c_void_p, p64, p64, u64, u64, u64)
     sig("ho_ntt_inverse_batch", None, C.c_void_p, p64, p64, u64, u64, u64)
     sig("ho_key_switch", None, p64, p64, u64, u64, u64, u64, u64, p64, C.POINTER(p64), p64)
+    sig("ho_has_avx512", C.c_int)
+    sig("ho_ntt_forward_radix2_avx512", None, p64, p64, u64, u64, p64, p64, u64, u64)
+    sig("ho_ntt_inverse_radix2_avx512", None, p64, p64, u64, u64, p64, p64, u64, u64)
+    sig("ho_ntt_forward_batch_avx512", None, C.c_void_p, p64, p64, u64, u64, u64)
+    sig("ho_ntt_inverse_batch_avx512", None, C.c_void_p, p64, p64, u64, u64, u64)
     sig("ho_fill_splitmix", None, p64, u64, u64, u64)
     return lib
 

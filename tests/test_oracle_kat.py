@@ -396,3 +396,33 @@ def test_key_switch_kat(case):
     FMAMod(8) in one composite known answer."""
     got = ho.key_switch(case["input"], case["t_target"], *_key_switch_args(case))
     assert got.tolist() == case["out"]
+
+
+# ---------------------------------------------------------------- AVX-512 baseline variant
+def test_avx512_variant_matches_scalar():
+    """oracle/hexl_oracle_avx512.c (the cpu_baseline of bench.py) against the scalar
+    restatement: every (in_mf, out_mf), in place and out of place, N = 2 .. 65536; the
+    values are identical bit for bit, lazy outputs included."""
+    import ctypes as C
+    if not ho.lib.ho_has_avx512():
+        pytest.skip("host CPU has no AVX-512 F/DQ")
+    rng = np.random.default_rng(3)
+    for n, bits in ((2, 20), (8, 30), (16, 54), (64, 61), (1024, 45), (8192, 54), (65536, 54),
+                    (65536, 61)):
+        q = ho.generate_primes(1, bits, True, n)[0]
+        plan = ho.lib.ho_ntt_create(n, q, 0)
+        P = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint64))
+        for fwd, in_mf, out_mf in ((1, 1, 1), (1, 4, 4), (1, 2, 1), (1, 4, 1), (0, 1, 1),
+                                   (0, 2, 2), (0, 2, 1), (0, 1, 2)):
+            x = rng.integers(0, in_mf * q, 2 * n, dtype=np.uint64)
+            x[0] = in_mf * q - 1
+            a, b = np.empty_like(x), np.empty_like(x)
+            scalar = ho.lib.ho_ntt_forward_batch if fwd else ho.lib.ho_ntt_inverse_batch
+            simd = ho.lib.ho_ntt_forward_batch_avx512 if fwd else ho.lib.ho_ntt_inverse_batch_avx512
+            scalar(plan, P(a), P(x), 2, in_mf, out_mf)
+            simd(plan, P(b), P(x), 2, in_mf, out_mf)
+            assert np.array_equal(a, b), (n, bits, fwd, in_mf, out_mf)
+            y = x.copy()
+            simd(plan, P(y), P(y), 2, in_mf, out_mf)  # in place
+            assert np.array_equal(a, y)
+        ho.lib.ho_ntt_destroy(plan)

@@ -627,7 +627,7 @@ def test_key_switch_kat(hx, case):
     assert case["input"][C * D * n:] == case["out"][C * D * n:]  # the tail is never written
 
 
-@pytest.mark.parametrize("n,D,K,C,bits", [(1024, 1, 2, 2, 40), (4096, 3, 4, 2, 50),
+@pytest.mark.parametrize("n,D,K,C,bits", [(1024, 1, 2, 2, 40), (4096, 3, 4, 2, 50), (16384, 7, 8, 2, 54),
                                           (8192, 4, 6, 3, 60), (2048, 2, 3, 2, 30)])
 def test_key_switch_random_vs_oracle(hx, ho, n, D, K, C, bits):
     """Random RNS bases (mixed sizes so that both the reduce and the copy branches of

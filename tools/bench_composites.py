@@ -1,0 +1,62 @@
+"""Composite callers on the device: DyadicMultiply and KeySwitch timings
+at a CKKS-like shape, next to the oracle (scalar CPU restatement) on one host thread."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import hexl_amd as hx  # noqa: E402
+from oracle import hexl_oracle as ho  # noqa: E402  (checker / CPU timing only)
+
+rng = np.random.default_rng(1)
+
+
+def gpu_time(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+# ---- DyadicMultiply: n = 32768, 16 moduli
+n, k = 32768, 16
+moduli = [int(q) for q in ho.generate_primes(k, 54, True, n)]
+x = np.concatenate([rng.integers(0, q, n, dtype=np.uint64) for q in moduli] * 2)
+y = np.concatenate([rng.integers(0, q, n, dtype=np.uint64) for q in moduli] * 2)
+dx, dy = hx.from_numpy(x), hx.from_numpy(y)
+out = hx.from_numpy(np.zeros(3 * n * k, dtype=np.uint64))
+t = gpu_time(lambda: hx.DyadicMultiply(out, dx, dy, n, moduli))
+t0 = time.perf_counter()
+want = ho.dyadic_multiply(x, y, n, moduli)
+tc = time.perf_counter() - t0
+assert np.array_equal(hx.to_numpy(out), want)
+print(f"DyadicMultiply n={n} x {k} moduli: GPU {t * 1e6:8.1f} us "
+      f"({56.0 * n * k / t / 1e9:6.0f} GB/s at 56 B/coefficient), oracle 1 thread {tc * 1e3:7.2f} ms")
+
+# ---- KeySwitch: n = 16384, 7 decomposition moduli + special prime, 2 key components
+n, D, K, C = 16384, 7, 8, 2
+moduli = [int(q) for q in ho.generate_primes(K, 54, True, n)]
+target = np.concatenate([rng.integers(0, moduli[j], n, dtype=np.uint64) for j in range(D)])
+keys = [np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                        for _ in range(C) for i in range(K)]) for _ in range(D)]
+msf = [int(rng.integers(1, moduli[i], dtype=np.uint64)) for i in range(D)]
+result = np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                         for _ in range(C) for i in range(D)])
+d_keys = [hx.from_numpy(kk) for kk in keys]
+d_t = hx.from_numpy(target)
+d_r = hx.from_numpy(result)
+hx.KeySwitch(d_r, d_t, n, D, K, D + 1, C, moduli, d_keys, msf)
+t0 = time.perf_counter()
+want = ho.key_switch(result, target, n, D, K, D + 1, C, moduli, keys, msf)
+tc = time.perf_counter() - t0
+assert np.array_equal(hx.to_numpy(d_r), want)
+t = gpu_time(lambda: hx.KeySwitch(d_r, d_t, n, D, K, D + 1, C, moduli, d_keys, msf), reps=10)
+print(f"KeySwitch n={n}, {D} decomposition moduli, {C} key components: GPU {t * 1e6:8.1f} us per call "
+      f"(launch-bound: about {2 * D + (D + 1) * 4 + C * (4 + 2 * D)} kernel launches), oracle 1 thread {tc * 1e3:7.2f} ms")

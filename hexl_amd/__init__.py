@@ -105,6 +105,7 @@ def _load():
     sig("hexl_amd_profile_start", ci, ci)
     sig("hexl_amd_profile_stop", ci, C.POINTER(ci))
     sig("hexl_amd_profile_get", ci, ci, C.POINTER(C.c_char_p), C.POINTER(C.c_float))
+    sig("hexl_amd_set_tuning", ci, C.c_char_p, u64)
     return lib
 
 
@@ -129,6 +130,7 @@ C_ABI_SYMBOLS = [
     "hexl_amd_minimal_primitive_root", "hexl_amd_reverse_bits", "hexl_amd_is_prime",
     "hexl_amd_generate_primes", "hexl_amd_ntt_check_arguments", "hexl_amd_fill_splitmix",
     "hexl_amd_profile_start", "hexl_amd_profile_stop", "hexl_amd_profile_get",
+    "hexl_amd_set_tuning",
 ]
 
 
@@ -429,6 +431,16 @@ def profile_stop():
         _check(lib.hexl_amd_profile_get(i, C.byref(name), C.byref(ms)))
         out.append((name.value.decode(), ms.value))
     return out
+
+
+PLAN_FUSED, PLAN_SPLIT, PLAN_TILED = 0, 1, 2
+
+
+def set_tuning(key, value):
+    """Tuning / diagnostic knobs of the transform launch logic (include/hexl_amd.h):
+    "plan" (PLAN_FUSED / PLAN_SPLIT / PLAN_TILED), "fused_window", "fused_min_batch",
+    "fused_wg_per_cu".  Results never depend on them."""
+    _check(lib.hexl_amd_set_tuning(key.encode(), int(value)))
 
 
 def fill_splitmix(data, n, batch, seed0, bound):

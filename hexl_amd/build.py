@@ -19,7 +19,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 CORE_SOURCES = ["ntt_kernels.hip", "eltwise_kernels.hip", "keyswitch_kernels.hip", "capi.cpp",
-                "number_theory.cpp"]
+                "number_theory.cpp", "workspace.cpp"]
 SHIM_SOURCES = ["hexl_shim.cpp"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-command-line-argument",
           f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]

@@ -867,6 +867,13 @@ int hexl_amd_profile_get(int i, const char** name, float* ms) {
   return HEXL_AMD_OK;
 }
 
+int hexl_amd_set_tuning(const char* key, uint64_t value) {
+  if (!key) return fail(HEXL_AMD_ERR_INVALID_ARG, "key == nullptr");
+  if (set_tuning(key, value) != 0)
+    return fail(HEXL_AMD_ERR_INVALID_ARG, "unknown tuning key or value out of range: %s", key);
+  return HEXL_AMD_OK;
+}
+
 int hexl_amd_fill_splitmix(uint64_t* data, uint64_t n, uint64_t batch, uint64_t seed0,
                            uint64_t bound, void* stream) {
   if (!data) return fail(HEXL_AMD_ERR_INVALID_ARG, "data == nullptr");

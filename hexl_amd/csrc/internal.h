@@ -67,6 +67,9 @@ hipError_t ntt_forward_launch(const NttTables& t, u64* result, const u64* operan
 hipError_t ntt_inverse_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
                               u64 out_mf, hipStream_t st);
 
+// Tuning / diagnostic knobs of the NTT launch logic (ntt_kernels.hip); 0 on success.
+int set_tuning(const char* key, u64 value);
+
 // Element-wise launchers (eltwise_kernels.hip)
 enum EltOp {
   ELT_ADD = 0,

@@ -47,8 +47,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "internal.h"
 #include "modarith.h"
+#include "workspace.h"
 
 namespace hexl_amd {
 
@@ -82,22 +86,37 @@ constexpr u32 kFirstPass = 4;
 // Global access as wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte
 // offset: `global_load/store v, v_off, s[base]`, no 64-bit vector address math and
 // no address registers kept live between the load and the in-place store.
-// NT = nontemporal (the `nt` bit): every pass streams its data exactly once, and
-// marking the accesses so is worth 4-6 % on the HBM-bound strided pass and 3 % on
-// the forward tile pass (measured; on the inverse tile pass it is neutral and slows
-// the strided pass that follows, so it is not used there).
-template <bool NT>
-__device__ __forceinline__ u64 load_global(const u64* uniform_base, u32 byte_off) {
-  const u64* p = reinterpret_cast<const u64*>(reinterpret_cast<const char*>(uniform_base) + byte_off);
-  return NT ? __builtin_nontemporal_load(p) : *p;
+//
+// Access kinds.  kStream = nontemporal (the `nt` bit): a pass streams its data
+// exactly once, and marking the accesses so is worth 4-6 % on the HBM-bound strided
+// pass and 3 % on the forward tile pass (measured; on the inverse tile pass it is
+// neutral and slows the strided pass that follows, so it is not used there).
+// kL2 (loads only) = agent-scope relaxed atomic load, `global_load ... sc1`: served
+// by the XCD's L2, never by the CU's vector L1 -- how the second phase of
+// fused_pass reads what another CU of the same XCD has just written.
+enum : int { kPlain = 0, kStream = 1, kL2 = 2 };
+
+template <int KIND>
+__device__ __forceinline__ u64 ld_global(const u64* p) {
+  if (KIND == kStream) return __builtin_nontemporal_load(p);
+  if (KIND == kL2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
 }
-template <bool NT>
-__device__ __forceinline__ void store_global(u64* uniform_base, u32 byte_off, u64 v) {
-  u64* p = reinterpret_cast<u64*>(reinterpret_cast<char*>(uniform_base) + byte_off);
-  if (NT)
+template <int KIND>
+__device__ __forceinline__ void st_global(u64* p, u64 v) {
+  if (KIND == kStream)
     __builtin_nontemporal_store(v, p);
   else
     *p = v;
+}
+template <int KIND>
+__device__ __forceinline__ u64 load_global(const u64* uniform_base, u32 byte_off) {
+  return ld_global<KIND>(
+      reinterpret_cast<const u64*>(reinterpret_cast<const char*>(uniform_base) + byte_off));
+}
+template <int KIND>
+__device__ __forceinline__ void store_global(u64* uniform_base, u32 byte_off, u64 v) {
+  st_global<KIND>(reinterpret_cast<u64*>(reinterpret_cast<char*>(uniform_base) + byte_off), v);
 }
 
 // ---------------------------------------------------------------------------
@@ -292,26 +311,20 @@ __device__ __forceinline__ void inv_subtree5_streamed(u64* x, const ulonglong2* 
 template <int R>
 constexpr int strided_min_waves() { return R >= 5 ? 4 : 6; }
 
+// The work of one 256-thread workgroup `bid` of the pass (4 waves x 64 columns).
 // LAST (inverse only): the pass contains the root stage of the transform (a0 == 0).
-template <bool FWD, int R, class A, bool LAST>
-__global__ void __launch_bounds__(256, (strided_min_waves<R>()))
-strided_pass(u64* __restrict__ out, const u64* __restrict__ in,
-             const ulonglong2* __restrict__ tw, ModConst m, u32 log_n, u32 a0, u32 flags,
-             u64 items, InvLast il) {
+// LDK / STK: access kinds of the loads and stores (see ld_global).
+// The data pointers are not __restrict__: transforms run in place (out == in).
+template <bool FWD, int R, class A, bool LAST, int LDK, int STK>
+__device__ __forceinline__ void strided_body(u64* out, const u64* in,
+                                             const ulonglong2* __restrict__ tw, const ModConst& m,
+                                             u32 log_n, u32 a0, u32 flags, u32 bid,
+                                             const InvLast& il) {
   constexpr int E = 1 << R;
   const u32 finish = flags & kFinishMask;
-  // items is a multiple of 64 (>= 64 columns per subtree): waves are whole, and a
-  // wave covers 64 adjacent columns of ONE subtree, so everything but the lane's
+  // A wave covers 64 adjacent columns of ONE subtree, so everything but the lane's
   // column offset is wave-uniform, in particular the twiddles (scalar loads into
   // SGPRs).
-  // XCD-aware block order: the dispatcher deals consecutive workgroups round-robin
-  // to the 8 XCDs; remapped, each XCD walks one contiguous eighth of the work, so
-  // the rows it has open in HBM are few and long (measured: 0.79 -> 0.71 ms at full
-  // occupancy; without it the pass only reaches 0.70 ms when occupancy is throttled
-  // to 2 waves per SIMD).
-  u32 bid = blockIdx.x;
-  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
-  if ((u64)bid * 256 + threadIdx.x >= items) return;
   const u32 lane = threadIdx.x & 63;
   const u64 wi = __builtin_amdgcn_readfirstlane(bid * 4 + (threadIdx.x >> 6));  // wave index
   const u32 log_s = log_n - a0 - R;
@@ -331,7 +344,7 @@ strided_pass(u64* __restrict__ out, const u64* __restrict__ in,
   // measured 2 % slower with it)
   if (FWD) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-  for (int e = 0; e < E; ++e) x[e] = __builtin_nontemporal_load(&in[vbase + ((u64)e << log_s)]);
+  for (int e = 0; e < E; ++e) x[e] = ld_global<LDK>(&in[vbase + ((u64)e << log_s)]);
   if (FWD) __builtin_amdgcn_s_setprio(0);
   if (flags & kFirstPass) {
 #pragma unroll
@@ -358,7 +371,23 @@ strided_pass(u64* __restrict__ out, const u64* __restrict__ in,
     }
   }
 #pragma unroll
-  for (int e = 0; e < E; ++e) __builtin_nontemporal_store(x[e], &out[vbase + ((u64)e << log_s)]);
+  for (int e = 0; e < E; ++e) st_global<STK>(&out[vbase + ((u64)e << log_s)], x[e]);
+}
+
+template <bool FWD, int R, class A, bool LAST>
+__global__ void __launch_bounds__(256, (strided_min_waves<R>()))
+strided_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst m, u32 log_n,
+             u32 a0, u32 flags, u64 items, InvLast il) {
+  // items is a multiple of 64 (>= 64 columns per subtree): waves are whole.
+  // XCD-aware block order: the dispatcher deals consecutive workgroups round-robin
+  // to the 8 XCDs; remapped, each XCD walks one contiguous eighth of the work, so
+  // the rows it has open in HBM are few and long (measured: 0.79 -> 0.71 ms at full
+  // occupancy; without it the pass only reaches 0.70 ms when occupancy is throttled
+  // to 2 waves per SIMD).
+  u32 bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  if ((u64)bid * 256 + threadIdx.x >= items) return;
+  strided_body<FWD, R, A, LAST, kStream, kStream>(out, in, tw, m, log_n, a0, flags, bid, il);
 }
 
 // ---------------------------------------------------------------------------
@@ -626,8 +655,8 @@ __device__ __forceinline__ constexpr u32 xfer_dp(int i) {
 
 // GUARD: the batch may end inside the tile (only possible for CB == 0 and a batch
 // smaller than / not a multiple of the tile); otherwise every access is in range.
-template <bool ROUND0, int S, int CB, int TL, bool GUARD, class A>
-__device__ __forceinline__ void fetch_tile(u64* x, const u64* __restrict__ in, u32 tid,
+template <bool ROUND0, int S, int CB, int TL, bool GUARD, class A, int LDK>
+__device__ __forceinline__ void fetch_tile(u64* x, const u64* in, u32 tid,
                                            const TileGeom& g, u64 total, bool first) {
 #pragma unroll
   for (int i = 0; i < kE; ++i) {
@@ -638,9 +667,9 @@ __device__ __forceinline__ void fetch_tile(u64* x, const u64* __restrict__ in, u
 #else
     const u64* src = in + tile_uniform_offset<CB>(g, dp);
     if (GUARD)
-      x[i] = (g.base + p0 + dp < total) ? load_global<ROUND0>(src, tile_byte_offset<CB>(g, p0)) : 0;
+      x[i] = (g.base + p0 + dp < total) ? load_global<LDK>(src, tile_byte_offset<CB>(g, p0)) : 0;
     else
-      x[i] = load_global<ROUND0>(src, tile_byte_offset<CB>(g, p0));
+      x[i] = load_global<LDK>(src, tile_byte_offset<CB>(g, p0));
 #endif
   }
   if (first) {
@@ -649,8 +678,8 @@ __device__ __forceinline__ void fetch_tile(u64* x, const u64* __restrict__ in, u
   }
 }
 
-template <bool ROUND0, int S, int CB, int TL, bool GUARD>
-__device__ __forceinline__ void store_elem(u64* __restrict__ out, u32 tid, int i, u64 v,
+template <bool ROUND0, int S, int CB, int TL, bool GUARD, int STK>
+__device__ __forceinline__ void store_elem(u64* out, u32 tid, int i, u64 v,
                                            const TileGeom& g, u64 total) {
   const u32 p0 = xfer_p0<ROUND0, S, CB, TL>(tid, i);
   const u32 dp = xfer_dp<ROUND0, S, CB>(i);
@@ -658,7 +687,7 @@ __device__ __forceinline__ void store_elem(u64* __restrict__ out, u32 tid, int i
   if (v == 0x123456789ULL) out[g.base + p0 + dp] = v;  // keeps the value live, ~never stores
 #else
   if (!GUARD || g.base + p0 + dp < total)
-    store_global<!ROUND0>(out + tile_uniform_offset<CB>(g, dp), tile_byte_offset<CB>(g, p0), v);
+    store_global<STK>(out + tile_uniform_offset<CB>(g, dp), tile_byte_offset<CB>(g, p0), v);
 #endif
 }
 
@@ -679,18 +708,19 @@ template <int S, int CB>
 constexpr int min_waves() { return (S >= 10 || CB > 0) ? 8 : 6; }
 
 // LAST (inverse only): the pass contains the root stage of the transform.
-template <bool FWD, int S, int CB, int TL, bool GUARD, class A, bool LAST>
-__global__ void __launch_bounds__(1 << (TL - kRE), (min_waves<S, CB>()))
-tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* __restrict__ tw,
-          ModConst m, u32 log_n, u32 flags, u64 total, InvLast il) {
+// tile_body: the work of one workgroup on tile `bid`; `lds` = 2^TL words of LDS.
+// LDK / STK: access kinds of the global loads and stores (see ld_global).  The data
+// pointers are not __restrict__: transforms run in place (out == in).
+template <bool FWD, int S, int CB, int TL, bool GUARD, class A, bool LAST, int LDK, int STK>
+__device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
+                                          const ulonglong2* __restrict__ tw, const ModConst& m,
+                                          u32 log_n, u32 flags, u64 total, const InvLast& il,
+                                          u32 bid) {
   using RD = Rounds<S, CB>;
   constexpr int NR = RD::NR;
   const u32 finish = flags & kFinishMask;
   const bool first = (flags & kFirstPass) != 0;
-  __shared__ u64 lds[1 << TL];
   const u32 tid = threadIdx.x;
-  // (The XCD-aware block order of strided_pass was measured here too: 2-7 % slower.)
-  const u32 bid = blockIdx.x;
   // A new wave first gets its tile's loads out, at raised priority, before it
   // competes with seven computing waves for VALU issue slots: its address
   // arithmetic would otherwise trickle through and delay the loads by ~1 us
@@ -705,7 +735,7 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
     {  // round 0 straight from global memory; its twiddles are requested first
       ulonglong2 wv[kE];
       round_twiddles<S, CB, TL, 0>(wv, tw, tid, g);
-      fetch_tile<true, S, CB, TL, GUARD, A>(x, in, tid, g, total, first);  // round-0 set
+      fetch_tile<true, S, CB, TL, GUARD, A, LDK>(x, in, tid, g, total, first);  // round-0 set
       __builtin_amdgcn_s_setprio(0);
       if constexpr (RD::pre_fwd(1)) round_twiddles<S, CB, TL, 1>(wn, tw, tid, g);
       HX_PROFILE_WAIT_VMEM();
@@ -725,7 +755,7 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
       for (int i = 0; i < kE; ++i) {
         u64 v = lds_at(lds, a0 ^ (lds_slot(xfer_dp<false, S, CB>(i)) << 3));
         if (finish) v = fwd_finish<A>(v, m, finish == 2);
-        store_elem<false, S, CB, TL, GUARD>(out, tid, i, v, g, total);
+        store_elem<false, S, CB, TL, GUARD, STK>(out, tid, i, v, g, total);
       }
     }
     HX_STAMP(8);
@@ -736,7 +766,7 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
     // round are requested first
     ulonglong2 wtop[kE], w0[kE];
     if constexpr (NR > 1) round_twiddles<S, CB, TL, NR - 1>(wtop, tw, tid, g);
-    fetch_tile<false, S, CB, TL, GUARD, A>(x, in, tid, g, total, first);
+    fetch_tile<false, S, CB, TL, GUARD, A, LDK>(x, in, tid, g, total, first);
     __builtin_amdgcn_s_setprio(0);
     {
       const u32 a0 = lds_slot(xfer_p0<false, S, CB, TL>(tid, 0)) << 3;
@@ -753,10 +783,21 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
       for (int i = 0; i < kE; ++i) {
         u64 v = x[i];
         if (finish) v = inv_finish<A>(v, m, finish == 2);
-        store_elem<true, S, CB, TL, GUARD>(out, tid, i, v, g, total);
+        store_elem<true, S, CB, TL, GUARD, STK>(out, tid, i, v, g, total);
       }
     }
   }
+}
+
+template <bool FWD, int S, int CB, int TL, bool GUARD, class A, bool LAST>
+__global__ void __launch_bounds__(1 << (TL - kRE), (min_waves<S, CB>()))
+tile_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst m, u32 log_n,
+          u32 flags, u64 total, InvLast il) {
+  __shared__ u64 lds[1 << TL];
+  // (The XCD-aware block order of strided_pass was measured here too: 2-7 % slower.)
+  // forward: streamed loads and stores; inverse: plain (see ld_global)
+  tile_body<FWD, S, CB, TL, GUARD, A, LAST, FWD ? kStream : kPlain, FWD ? kStream : kPlain>(
+      lds, out, in, tw, m, log_n, flags, total, il, blockIdx.x);
 }
 
 // (Round-1 experiment, removed: `tile_stream`, a persistent variant of the bottom pass
@@ -767,6 +808,220 @@ tile_pass(u64* __restrict__ out, const u64* __restrict__ in, const ulonglong2* _
 // for HBM it waits for the VALU and the extra barrier instead.  A second persistent
 // variant prefetching the next tile into 16 spare VGPRs (6 waves/SIMD) measured
 // 1.25 ms against 1.04 ms.  See DESIGN.md.)
+
+// ---------------------------------------------------------------------------
+// fused_pass: both passes of a transform in ONE launch -- one HBM round trip
+// ---------------------------------------------------------------------------
+// Two launches move every polynomial through HBM twice (the whole transform then
+// sits at ~80 % of the achievable HBM rate with neither pass able to go faster).
+// fused_pass runs the strided pass and the tile pass of a polynomial inside one
+// persistent launch, a few microseconds apart and on CUs of the SAME XCD, so that
+// the intermediate polynomial is written to and read back from that XCD's 4 MiB L2
+// instead of HBM: the second phase's loads hit in L2, and its in-place stores
+// overwrite the still-dirty lines, so only the final values are ever evicted.
+//
+// Scheduling.  Workgroups are persistent and pull tasks.  A polynomial is a "slot"
+// of the XCD that first touches it; a slot has n1 phase-1 tasks (forward: strided
+// chunks of 256 columns; inverse: tiles) and n2 phase-2 tasks (forward: tiles;
+// inverse: strided chunks).  Phase 2 of a slot may start once all n1 phase-1 tasks
+// have signalled (all-to-all dependency: every tile needs every column chunk).
+//   * A workgroup identifies its XCD with s_getreg(HW_REG_XCC_ID) and only ever
+//     touches that XCD's control block and slots, so both phases of a polynomial
+//     are executed by CUs that share one L2 -- by construction, not by assuming a
+//     dispatch order.  Polynomials are handed to XCDs on demand from one
+//     device-wide counter (dynamic balance; any placement of workgroups works).
+//   * Phase-2 tasks of the oldest ready slot are taken first (the intermediate's
+//     residence time in L2 is then a few microseconds, ~1-2 MiB per XCD); phase-1
+//     tasks are claimed only while fewer than `window` slots are in flight.
+//   * Phase-1 tasks never wait for anything, so every wait in the scheduler is for
+//     work that a running workgroup holds: no deadlock for any grid size or
+//     residency.  All spins are bounded; on timeout the kernel traps (a loud HIP
+//     error instead of a hang).
+// Hand-off inside the XCD: the producer's plain stores are complete in L2 when
+// `s_waitcnt vmcnt(0)` returns (the vector L1 is write-through); it then bumps the
+// slot's counter.  The consumer observes the counter, and reads the data with
+// agent-scope loads (`sc1`: L2-served, never the CU's possibly stale L1).  No
+// L2 write-back (`buffer_wbl2`) is needed -- or wanted: it is exactly the HBM
+// traffic this kernel exists to avoid -- because producer and consumer share the
+// L2.  If a line is evicted early it is simply read back from HBM: still correct.
+constexpr u32 kFusedMaxXcd = 16;        // HW_REG_XCC_ID is a 4-bit field
+constexpr u32 kFusedEnd = 0xFFFFFFFFu;  // FusedSlot::poly1 of a slot past the batch
+constexpr u32 kFusedSpinLimit = 1u << 24;
+
+struct FusedSlot {  // 16 bytes; zero = untouched
+  u32 poly1;     // polynomial index + 1, or kFusedEnd
+  u32 p1_done;   // phase-1 tasks finished
+  u32 p2_claim;  // phase-2 tickets handed out
+  u32 pad;
+};
+struct FusedXcd {  // two 128-byte lines
+  u32 p1_claim;  // phase-1 tickets handed out: ticket k = slot k / n1, task k % n1
+  u32 pad0[31];
+  u32 p2_scan;   // every slot below has all its phase-2 tickets handed out
+  u32 pad1[31];
+};
+struct FusedCtl {
+  u32 next_poly;  // device-wide
+  u32 pad[31];
+  FusedXcd xcd[kFusedMaxXcd];
+  // followed by FusedSlot[kFusedMaxXcd][cap]
+};
+
+__device__ __forceinline__ u32 ctl_ld(const u32* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ctl_st(u32* p, u32 v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u32 ctl_add(u32* p, u32 v) {
+  return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ctl_max(u32* p, u32 v) {
+  (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void fused_backoff(u32& spins) {
+  __builtin_amdgcn_s_sleep(8);
+  if (++spins > kFusedSpinLimit) __builtin_trap();
+}
+
+struct FusedTask {
+  u32 kind;  // 0 = no more work, 1 = phase 1, 2 = phase 2
+  u32 poly;
+  u32 idx;   // task index within the polynomial's phase
+  u32 slot;
+};
+
+// One lane's scheduler step: the next task for this workgroup.  `end_slot` is this
+// workgroup's knowledge of the first slot past the batch (kFusedEnd: unknown).
+__device__ __forceinline__ FusedTask fused_claim(FusedCtl* ctl, FusedXcd* X, FusedSlot* slots, u32 n1,
+                                              u32 n2, u32 batch, u32 cap, u32 window,
+                                              u32& end_slot) {
+  u32 spins = 0;
+  for (;;) {
+    const u32 head = ctl_ld(&X->p2_scan);
+    if (head >= end_slot) return FusedTask{0, 0, 0, 0};
+    // ---- phase 2, oldest slot first (a short look-ahead covers out-of-order
+    // completion of phase 1)
+    bool all_exhausted = true;  // every slot in [head, t) has no ticket left
+    for (u32 t = head; t < head + 4 && t < end_slot && t < cap; ++t) {
+      const u32 poly1 = ctl_ld(&slots[t].poly1);
+      if (poly1 == kFusedEnd) {
+        end_slot = t;
+        break;
+      }
+      if (poly1 == 0) break;  // not assigned yet; nothing behind it is either
+      if (ctl_ld(&slots[t].p1_done) == n1) {
+        if (ctl_ld(&slots[t].p2_claim) < n2) {
+          const u32 j = ctl_add(&slots[t].p2_claim, 1);
+          if (j < n2) return FusedTask{2, poly1 - 1, j, t};
+        }
+        if (all_exhausted) ctl_max(&X->p2_scan, t + 1);
+      } else {
+        all_exhausted = false;
+      }
+    }
+    if (ctl_ld(&X->p2_scan) >= end_slot) return FusedTask{0, 0, 0, 0};
+    // ---- phase 1
+    if (end_slot == kFusedEnd) {
+      const u32 k0 = ctl_ld(&X->p1_claim);
+      if (k0 / n1 < head + window) {
+        const u32 k = ctl_add(&X->p1_claim, 1);
+        const u32 slot = k / n1, sub = k - slot * n1;
+        if (slot >= cap) {  // cannot happen with the host's cap; fail safe
+          end_slot = cap;
+          continue;
+        }
+        u32 poly1;
+        if (sub == 0) {
+          // Polynomials are assigned in slot order (wait for the previous slot's
+          // assignment), so the slots past the batch form a suffix.
+          if (slot > 0) {
+            u32 sp = 0;
+            while (ctl_ld(&slots[slot - 1].poly1) == 0) fused_backoff(sp);
+          }
+          const u32 p = ctl_add(&ctl->next_poly, 1);
+          poly1 = p < batch ? p + 1 : kFusedEnd;
+          ctl_st(&slots[slot].poly1, poly1);
+        } else {
+          u32 sp = 0;
+          while ((poly1 = ctl_ld(&slots[slot].poly1)) == 0) fused_backoff(sp);
+        }
+        if (poly1 == kFusedEnd) {
+          end_slot = slot;
+          continue;
+        }
+        return FusedTask{1, poly1 - 1, sub, slot};
+      }
+    }
+    fused_backoff(spins);
+  }
+}
+
+// Workgroups per CU the register budget is set for: the 5-stage strided subtree
+// (32 elements per thread) spills under the 96-VGPR cap of 5, so it gets 4.
+template <int R>
+constexpr int fused_waves() { return R >= 5 ? 4 : 5; }
+
+// R strided stages + S tile stages (N = 2^(R+S), tile = 2^S elements, S = 11).
+template <bool FWD, int R, int S, class A>
+__global__ void __launch_bounds__(256, (fused_waves<R>()))
+fused_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst m, u32 finish,
+           u32 batch, InvLast il, FusedCtl* ctl, u32 cap, u32 window) {
+  constexpr u32 log_n = R + S;
+  constexpr u32 kStridedTasks = 1u << (S - 8);  // 256 columns each
+  constexpr u32 kTileTasks = 1u << R;
+  constexpr u32 n1 = FWD ? kStridedTasks : kTileTasks;
+  constexpr u32 n2 = FWD ? kTileTasks : kStridedTasks;
+  __shared__ u64 lds[1 << S];
+  __shared__ u32 task_sh[2][4];
+  const u32 tid = threadIdx.x;
+  // HW_REG_XCC_ID (hwreg 20), bits [3:0]: the XCD this workgroup runs on
+  const u32 xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) & (kFusedMaxXcd - 1);
+  FusedXcd* X = &ctl->xcd[xcc];
+  FusedSlot* slots = reinterpret_cast<FusedSlot*>(ctl + 1) + (size_t)xcc * cap;
+  u32 end_slot = kFusedEnd;
+  const u64 total = (u64)batch << log_n;
+
+  for (u32 it = 0;; ++it) {
+    u32* ts = task_sh[it & 1];
+    if (tid == 0) {
+      const FusedTask t = fused_claim(ctl, X, slots, n1, n2, batch, cap, window, end_slot);
+      ts[0] = t.kind;
+      ts[1] = t.poly;
+      ts[2] = t.idx;
+      ts[3] = t.slot;
+    }
+    // publishes the task; also separates the LDS use of consecutive tasks
+    __syncthreads();
+    const u32 kind = __builtin_amdgcn_readfirstlane(ts[0]);
+    const u32 poly = __builtin_amdgcn_readfirstlane(ts[1]);
+    const u32 idx = __builtin_amdgcn_readfirstlane(ts[2]);
+    if (kind == 0) break;
+    if (FWD) {
+      if (kind == 1) {  // first R stages: HBM (streamed) -> L2 (plain stores stay there)
+        strided_body<true, R, A, false, kStream, kPlain>(out, in, tw, m, log_n, 0, kFirstPass,
+                                                        poly * kStridedTasks + idx, il);
+      } else {  // last S stages: L2 -> HBM (streamed)
+        tile_body<true, S, 0, S, false, A, false, kL2, kStream>(lds, out, out, tw, m, log_n, finish,
+                                                               total, il, poly * kTileTasks + idx);
+      }
+    } else {
+      if (kind == 1) {  // deepest S stages: HBM -> L2
+        tile_body<false, S, 0, S, false, A, false, kPlain, kPlain>(
+            lds, out, in, tw, m, log_n, kFirstPass, total, il, poly * kTileTasks + idx);
+      } else {  // root R stages with N^-1 folded in: L2 -> HBM (streamed)
+        strided_body<false, R, A, true, kL2, kStream>(out, out, tw, m, log_n, 0, finish,
+                                                     poly * kStridedTasks + idx, il);
+      }
+    }
+    if (kind == 1) {
+      // all of this task's stores are in L2 before the slot's counter moves
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) ctl_add(&slots[__builtin_amdgcn_readfirstlane(ts[3])].p1_done, 1);
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------
 // Host-side planning and launch
@@ -898,15 +1153,50 @@ struct Plan {
 };
 
 // Default for N >= 2^13: register-only strided pass(es) + an 11- or 12-stage
-// bottom tile_pass.  HEXL_AMD_PLAN=tiled selects two LDS-tiled kernels instead
-// (6 + 10 stages on 1024-element tiles for N = 2^16); slower, see DESIGN.md.
-static bool plan_strided_requested() {
-  static const bool v = [] {
-    const char* e = getenv("HEXL_AMD_PLAN");
-    return !(e && strcmp(e, "tiled") == 0);
-  }();
-  return v;
+// bottom tile_pass; for N = 2^13 .. 2^16 and batches that fill the chip the two are
+// run as ONE launch (fused_pass, one HBM round trip).  HEXL_AMD_PLAN=split keeps the
+// two launches; HEXL_AMD_PLAN=tiled selects two LDS-tiled kernels instead (6 + 10
+// stages on 1024-element tiles for N = 2^16; slower).
+enum PlanMode { kPlanFused = 0, kPlanSplit = 1, kPlanTiled = 2 };
+static u32 env_u32(const char* name, u32 dflt) {
+  const char* e = getenv(name);
+  if (!e || !*e) return dflt;
+  const long v = atol(e);
+  return v > 0 ? (u32)v : dflt;
 }
+// Process-wide tuning state: defaults from the environment, changeable at run time
+// through hexl_amd_set_tuning (tests compare the plans in one process).
+struct Tuning {
+  std::atomic<u32> plan, fused_window, fused_min_batch, fused_wg_per_cu;
+  Tuning() {
+    const char* e = getenv("HEXL_AMD_PLAN");
+    plan = (e && strcmp(e, "tiled") == 0) ? kPlanTiled : (e && strcmp(e, "split") == 0) ? kPlanSplit
+                                                                                       : kPlanFused;
+    // Slots (polynomials) an XCD may have in flight between the first phase-1 claim
+    // and the last phase-2 claim; the smallest batch the fused launch is used for;
+    // workgroups per CU of the persistent grid (0 = occupancy query).
+    fused_window = env_u32("HEXL_AMD_FUSED_WINDOW", 12);
+    fused_min_batch = env_u32("HEXL_AMD_FUSED_MIN_BATCH", 64);
+    fused_wg_per_cu = env_u32("HEXL_AMD_FUSED_WG_PER_CU", 0);
+  }
+};
+static Tuning& tuning() {
+  static Tuning t;
+  return t;
+}
+int set_tuning(const char* key, u64 value) {
+  Tuning& t = tuning();
+  if (strcmp(key, "plan") == 0 && value <= kPlanTiled) t.plan = (u32)value;
+  else if (strcmp(key, "fused_window") == 0 && value >= 1) t.fused_window = (u32)value;
+  else if (strcmp(key, "fused_min_batch") == 0 && value >= 1) t.fused_min_batch = (u32)value;
+  else if (strcmp(key, "fused_wg_per_cu") == 0) t.fused_wg_per_cu = (u32)value;
+  else return -1;
+  return 0;
+}
+static PlanMode plan_mode() { return (PlanMode)tuning().plan.load(); }
+static bool plan_strided_requested() { return plan_mode() != kPlanTiled; }
+static u32 fused_window() { return tuning().fused_window.load(); }
+static u64 fused_min_batch() { return tuning().fused_min_batch.load(); }
 
 static Plan make_plan(int L) {
   Plan p{};
@@ -968,6 +1258,73 @@ static hipError_t launch_bottom_tl(int tl, int S, u64* out, const u64* in, const
   return launch_bottom<FWD, 12, A>(S, out, in, tw, m, log_n, finish, batch, il, st);
 }
 
+// Resident workgroups of a fused_pass instantiation on the current device
+// (blocks per CU by the occupancy query x CUs).  The scheduler needs no particular
+// grid size -- a workgroup that is not resident yet simply starts pulling tasks
+// later -- so the query's known off-by-one (MI355X_MICROARCH.md) is harmless.
+template <bool FWD, int R, class A>
+static hipError_t fused_grid(unsigned* grid) {
+  static std::mutex mu;
+  static int cached[64], cached_cus[64];  // per device; 0 = unknown
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!cached[dev]) {
+    int per_cu = 0, cus = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pass<FWD, R, 11, A>, 256, 0);
+    if (e != hipSuccess) return e;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > fused_waves<R>() + 1) per_cu = fused_waves<R>() + 1;
+    cached[dev] = per_cu;
+    cached_cus[dev] = cus > 0 ? cus : 1;
+  }
+  const u32 override_per_cu = tuning().fused_wg_per_cu.load();
+  *grid = (unsigned)((override_per_cu ? (int)override_per_cu : cached[dev]) * cached_cus[dev]);
+  return hipSuccess;
+}
+
+// The whole transform (R strided + 11 tile stages, N = 2^(R+11)) as one launch.
+template <bool FWD, int R, class A>
+static hipError_t launch_fused_r(const NttTables& t, u64* result, const u64* operand, u64 batch,
+                                 u32 fin, hipStream_t st) {
+  unsigned grid = 0;
+  hipError_t e = fused_grid<FWD, R, A>(&grid);
+  if (e != hipSuccess) return e;
+  // An XCD creates at most `batch` slots that hold a polynomial plus one per
+  // workgroup that asks after the batch is exhausted.
+  const u32 cap = (u32)batch + grid + 2;
+  const size_t bytes = sizeof(FusedCtl) + (size_t)kFusedMaxXcd * cap * sizeof(FusedSlot);
+  void* ws = nullptr;
+  e = stream_workspace(kWsFusedNtt, st, bytes, &ws);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(ws, 0, bytes, st);
+  if (e != hipSuccess) return e;
+  // no more workgroups than tasks of the larger phase
+  const u64 tasks = batch << (R > 3 ? R : 3);
+  if (tasks < grid) grid = (unsigned)tasks;
+  ScopedKernelTimer timer(FWD ? "ntt_fwd_fused_pass" : "ntt_inv_fused_pass", st);
+  hipLaunchKernelGGL((fused_pass<FWD, R, 11, A>), dim3(grid), dim3(256), 0, st, result, operand,
+                     FWD ? t.fwd : t.inv, t.mod, fin, (u32)batch, t.inv_last, (FusedCtl*)ws, cap,
+                     fused_window());
+  return hipGetLastError();
+}
+
+template <bool FWD, class A>
+static hipError_t launch_fused(int R, const NttTables& t, u64* result, const u64* operand,
+                               u64 batch, u32 fin, hipStream_t st) {
+  switch (R) {
+    case 2: return launch_fused_r<FWD, 2, A>(t, result, operand, batch, fin, st);
+    case 3: return launch_fused_r<FWD, 3, A>(t, result, operand, batch, fin, st);
+    case 4: return launch_fused_r<FWD, 4, A>(t, result, operand, batch, fin, st);
+    case 5: return launch_fused_r<FWD, 5, A>(t, result, operand, batch, fin, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 // One transform of `batch` polynomials on stream `st`.
 template <class A>
 static hipError_t forward_seq(const NttTables& t, const Plan& p, u64* result, const u64* operand,
@@ -1027,6 +1384,9 @@ template <bool FWD, class A>
 static hipError_t transform_impl(const NttTables& t, u64* result, const u64* operand, u64 batch,
                                  u64 out_mf, hipStream_t st) {
   const Plan p = make_plan((int)t.log_n);
+  if (plan_mode() == kPlanFused && p.n_strided == 1 && p.bottom == 11 && !p.top_tile &&
+      p.strided[0] >= 2 && batch >= fused_min_batch() && batch < (1ull << 26))
+    return launch_fused<FWD, A>(p.strided[0], t, result, operand, batch, out_mf == 1 ? 2 : 1, st);
   return FWD ? forward_seq<A>(t, p, result, operand, batch, out_mf, st)
              : inverse_seq<A>(t, p, result, operand, batch, out_mf, st);
 }

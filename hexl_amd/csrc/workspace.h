@@ -1,0 +1,29 @@
+// workspace.h -- stream-keyed device scratch buffers.
+//
+// Work enqueued on one HIP stream executes in order, so successive operations on a
+// stream may reuse one scratch buffer; operations on DIFFERENT streams may overlap
+// on the device and must not share scratch.  Buffers are therefore keyed by
+// (device, stream, purpose), grow on demand and live until the process ends (or
+// release_workspaces()).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+
+namespace hexl_amd {
+
+enum WorkspacePurpose : int {
+  kWsFusedNtt = 0,   // scheduler state of fused_pass (ntt_kernels.hip)
+  kWsKeySwitch = 1,  // t_target | ntt_buf | t_poly_prod of KeySwitch (capi.cpp)
+  kWsTwiddlePtrs = 2,
+};
+
+// Device buffer of at least `bytes` bytes for `purpose` on (current device, stream).
+// Growing synchronises the device (hipFree) -- it happens once per size class.
+hipError_t stream_workspace(WorkspacePurpose purpose, hipStream_t stream, size_t bytes,
+                            void** out);
+
+// Frees every cached buffer of the current process (all devices).  The caller
+// guarantees no operation that uses them is in flight.
+void release_workspaces();
+
+}  // namespace hexl_amd

@@ -15,7 +15,7 @@ for f in ntt_kernels.hip eltwise_kernels.hip keyswitch_kernels.hip; do
     -Wno-unused-command-line-argument -I$ROOT/include -I$ROOT/hexl_amd/csrc \
     -c $ROOT/hexl_amd/csrc/$f -o $T/$f.o &
 done
-for f in capi.cpp number_theory.cpp; do
+for f in capi.cpp number_theory.cpp workspace.cpp; do
   /opt/rocm/lib/llvm/bin/clang++ -x c++ -O3 -std=c++17 -fPIC -I$ROOT/include -I$ROOT/hexl_amd/csrc \
     -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -c $ROOT/hexl_amd/csrc/$f -o $T/$f.o &
 done

@@ -820,23 +820,28 @@ tile_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst m
 // instead of HBM: the second phase's loads hit in L2, and its in-place stores
 // overwrite the still-dirty lines, so only the final values are ever evicted.
 //
-// Scheduling.  Workgroups are persistent and pull tasks.  A polynomial is a "slot"
+// Scheduling.  Workgroups are persistent and pull tickets.  A polynomial is a "slot"
 // of the XCD that first touches it; a slot has n1 phase-1 tasks (forward: strided
 // chunks of 256 columns; inverse: tiles) and n2 phase-2 tasks (forward: tiles;
 // inverse: strided chunks).  Phase 2 of a slot may start once all n1 phase-1 tasks
 // have signalled (all-to-all dependency: every tile needs every column chunk).
 //   * A workgroup identifies its XCD with s_getreg(HW_REG_XCC_ID) and only ever
-//     touches that XCD's control block and slots, so both phases of a polynomial
+//     touches that XCD's ticket counter and slots, so both phases of a polynomial
 //     are executed by CUs that share one L2 -- by construction, not by assuming a
 //     dispatch order.  Polynomials are handed to XCDs on demand from one
 //     device-wide counter (dynamic balance; any placement of workgroups works).
-//   * Phase-2 tasks of the oldest ready slot are taken first (the intermediate's
-//     residence time in L2 is then a few microseconds, ~1-2 MiB per XCD); phase-1
-//     tasks are claimed only while fewer than `window` slots are in flight.
-//   * Phase-1 tasks never wait for anything, so every wait in the scheduler is for
-//     work that a running workgroup holds: no deadlock for any grid size or
-//     residency.  All spins are bounded; on timeout the kernel traps (a loud HIP
-//     error instead of a hang).
+//   * Each XCD has ONE ticket counter over a software-pipelined task list: step s
+//     of the list is the n1 phase-1 tasks of slot s followed by the n2 phase-2 tasks
+//     of slot s - D (D = `window`).  A claim is a single atomic add; a phase-2
+//     ticket whose slot is not ready yet waits for it (and then starts the moment it
+//     is: the intermediate's residence time in L2 is a few microseconds, ~1-2 MiB
+//     per XCD).  (A first version with per-slot claim counters and a scan for ready
+//     slots was bit-exact but 3x slower than two launches: ~10 control accesses per
+//     claim on three hot words per XCD serialised the whole chip.)
+//   * No deadlock for any grid size or residency: a waiting ticket only ever waits
+//     for phase-1 tasks with SMALLER ticket numbers, which are held by workgroups
+//     that are already running and never wait themselves.  All spins are bounded;
+//     on timeout the kernel traps (a loud HIP error instead of a hang).
 // Hand-off inside the XCD: the producer's plain stores are complete in L2 when
 // `s_waitcnt vmcnt(0)` returns (the vector L1 is write-through); it then bumps the
 // slot's counter.  The consumer observes the counter, and reads the data with
@@ -844,21 +849,37 @@ tile_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst m
 // L2 write-back (`buffer_wbl2`) is needed -- or wanted: it is exactly the HBM
 // traffic this kernel exists to avoid -- because producer and consumer share the
 // L2.  If a line is evicted early it is simply read back from HBM: still correct.
-constexpr u32 kFusedMaxXcd = 16;        // HW_REG_XCC_ID is a 4-bit field
-constexpr u32 kFusedEnd = 0xFFFFFFFFu;  // FusedSlot::poly1 of a slot past the batch
+// The control words of an XCD are only touched by that XCD's workgroups; only the
+// polynomial counter is shared by the whole device.
+constexpr u32 kFusedMaxXcd = 16;       // HW_REG_XCC_ID is a 4-bit field
+constexpr u32 kFusedEnd = 0xFFFFFFu;   // polynomial field of a slot past the batch
 constexpr u32 kFusedSpinLimit = 1u << 24;
+#ifndef HEXL_AMD_FUSED_TT
+#define HEXL_AMD_FUSED_TT 2
+#endif
+constexpr u32 kFusedTT = HEXL_AMD_FUSED_TT;  // tiles per tile ticket
 
-struct FusedSlot {  // 16 bytes; zero = untouched
-  u32 poly1;     // polynomial index + 1, or kFusedEnd
-  u32 p1_done;   // phase-1 tasks finished
-  u32 p2_claim;  // phase-2 tickets handed out
-  u32 pad;
-};
-struct FusedXcd {  // two 128-byte lines
-  u32 p1_claim;  // phase-1 tickets handed out: ticket k = slot k / n1, task k % n1
-  u32 pad0[31];
-  u32 p2_scan;   // every slot below has all its phase-2 tickets handed out
-  u32 pad1[31];
+// Developer diagnostic (tools/fused_stats.py, -DHEXL_AMD_FUSED_STATS builds only):
+// per-workgroup cycle totals of the scheduler and the two task bodies.
+#ifdef HEXL_AMD_FUSED_STATS
+__device__ unsigned long long* g_fused_stats = nullptr;  // [workgroup][8]
+extern "C" int hexl_amd_debug_set_fused_stats(void* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fused_stats), &buf, sizeof(buf));
+}
+#define HX_FS_NOW() __builtin_readcyclecounter()
+#define HX_FS(...) __VA_ARGS__
+#else
+#define HX_FS_NOW() 0ull
+#define HX_FS(...)
+#endif
+
+// A slot is one word: (polynomial index + 1, or kFusedEnd) << 8 | phase-1 tasks
+// finished.  Zero = not assigned yet.  One load tells a phase-2 ticket both which
+// polynomial it works on and whether it may start.
+typedef u32 FusedSlot;
+struct FusedXcd {  // one 128-byte line
+  u32 ticket;
+  u32 pad[31];
 };
 struct FusedCtl {
   u32 next_poly;  // device-wide
@@ -867,17 +888,14 @@ struct FusedCtl {
   // followed by FusedSlot[kFusedMaxXcd][cap]
 };
 
-__device__ __forceinline__ u32 ctl_ld(const u32* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void ctl_st(u32* p, u32 v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ u32 ctl_add(u32* p, u32 v) {
+// Control accesses.  Reads are agent-scope loads (`sc1`): never served by the vector
+// L1.  (A workgroup-scope fetch_add(p, 0) is folded into an `sc0` load by the
+// compiler, which the L1 may serve with a stale line: seen as a memory fault.)
+__device__ __forceinline__ u32 xcd_add(u32* p, u32 v) {
   return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void ctl_max(u32* p, u32 v) {
-  (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ u32 xcd_read(u32* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void fused_backoff(u32& spins) {
   __builtin_amdgcn_s_sleep(8);
@@ -891,69 +909,53 @@ struct FusedTask {
   u32 slot;
 };
 
-// One lane's scheduler step: the next task for this workgroup.  `end_slot` is this
-// workgroup's knowledge of the first slot past the batch (kFusedEnd: unknown).
-__device__ __forceinline__ FusedTask fused_claim(FusedCtl* ctl, FusedXcd* X, FusedSlot* slots, u32 n1,
-                                              u32 n2, u32 batch, u32 cap, u32 window,
-                                              u32& end_slot) {
-  u32 spins = 0;
-  for (;;) {
-    const u32 head = ctl_ld(&X->p2_scan);
-    if (head >= end_slot) return FusedTask{0, 0, 0, 0};
-    // ---- phase 2, oldest slot first (a short look-ahead covers out-of-order
-    // completion of phase 1)
-    bool all_exhausted = true;  // every slot in [head, t) has no ticket left
-    for (u32 t = head; t < head + 4 && t < end_slot && t < cap; ++t) {
-      const u32 poly1 = ctl_ld(&slots[t].poly1);
-      if (poly1 == kFusedEnd) {
-        end_slot = t;
-        break;
+// The slot's word, waiting for the assignment if it is still under way.
+__device__ __forceinline__ u32 fused_slot_word(FusedSlot* slots, u32 slot) {
+  u32 w, sp = 0;
+  while (((w = xcd_read(&slots[slot])) >> 8) == 0) fused_backoff(sp);
+  return w;
+}
+// Hands the next polynomial of the batch (or the end marker) to `slot`.
+__device__ __forceinline__ void fused_assign(FusedCtl* ctl, FusedSlot* slots, u32 slot, u32 batch) {
+  const u32 p = xcd_add(&ctl->next_poly, 1);
+  xcd_add(&slots[slot], (p < batch ? p + 1 : kFusedEnd) << 8);  // was 0
+}
+
+// One lane's scheduler step: ticket k -> the task it stands for (tickets that stand
+// for nothing -- pipeline fill, slots past the batch -- are replaced by fresh ones).
+__device__ __forceinline__ FusedTask fused_resolve(u32 k, FusedCtl* ctl, FusedXcd* X,
+                                                   FusedSlot* slots, u32 n1, u32 n2, u32 batch,
+                                                   u32 cap, u32 window,
+                                                   unsigned long long& dep_wait) {
+  for (;; k = xcd_add(&X->ticket, 1)) {
+    const u32 step = k / (n1 + n2), r = k - step * (n1 + n2);
+    if (r < n1) {  // phase 1 of slot `step`
+      if (step + 1 >= cap) return FusedTask{0, 0, 0, 0};  // cannot happen with the host's cap
+      if (r == 0) {
+        // This ticket also assigns polynomials, one slot ahead and in slot order
+        // (slot `step` was assigned by the previous step's ticket), so that the
+        // slots past the batch form a suffix.
+        if (step == 0) fused_assign(ctl, slots, 0, batch);
+        (void)fused_slot_word(slots, step);
+        fused_assign(ctl, slots, step + 1, batch);
       }
-      if (poly1 == 0) break;  // not assigned yet; nothing behind it is either
-      if (ctl_ld(&slots[t].p1_done) == n1) {
-        if (ctl_ld(&slots[t].p2_claim) < n2) {
-          const u32 j = ctl_add(&slots[t].p2_claim, 1);
-          if (j < n2) return FusedTask{2, poly1 - 1, j, t};
-        }
-        if (all_exhausted) ctl_max(&X->p2_scan, t + 1);
-      } else {
-        all_exhausted = false;
-      }
+      const u32 poly1 = fused_slot_word(slots, step) >> 8;
+      if (poly1 == kFusedEnd) continue;  // phase-2 tickets of earlier slots still follow
+      return FusedTask{1, poly1 - 1, r, step};
     }
-    if (ctl_ld(&X->p2_scan) >= end_slot) return FusedTask{0, 0, 0, 0};
-    // ---- phase 1
-    if (end_slot == kFusedEnd) {
-      const u32 k0 = ctl_ld(&X->p1_claim);
-      if (k0 / n1 < head + window) {
-        const u32 k = ctl_add(&X->p1_claim, 1);
-        const u32 slot = k / n1, sub = k - slot * n1;
-        if (slot >= cap) {  // cannot happen with the host's cap; fail safe
-          end_slot = cap;
-          continue;
-        }
-        u32 poly1;
-        if (sub == 0) {
-          // Polynomials are assigned in slot order (wait for the previous slot's
-          // assignment), so the slots past the batch form a suffix.
-          if (slot > 0) {
-            u32 sp = 0;
-            while (ctl_ld(&slots[slot - 1].poly1) == 0) fused_backoff(sp);
-          }
-          const u32 p = ctl_add(&ctl->next_poly, 1);
-          poly1 = p < batch ? p + 1 : kFusedEnd;
-          ctl_st(&slots[slot].poly1, poly1);
-        } else {
-          u32 sp = 0;
-          while ((poly1 = ctl_ld(&slots[slot].poly1)) == 0) fused_backoff(sp);
-        }
-        if (poly1 == kFusedEnd) {
-          end_slot = slot;
-          continue;
-        }
-        return FusedTask{1, poly1 - 1, sub, slot};
-      }
+    if (step < window) continue;  // pipeline fill
+    const u32 slot = step - window;
+    u32 w = fused_slot_word(slots, slot);
+    // past the batch: so is every slot any later ticket refers to
+    if ((w >> 8) == kFusedEnd) return FusedTask{0, 0, 0, 0};
+    u32 sp = 0;
+    HX_FS(const unsigned long long w0 = HX_FS_NOW());
+    while ((w & 255) != n1) {
+      fused_backoff(sp);
+      w = xcd_read(&slots[slot]);
     }
-    fused_backoff(spins);
+    HX_FS(dep_wait += HX_FS_NOW() - w0);
+    return FusedTask{2, (w >> 8) - 1, r - n1, slot};
   }
 }
 
@@ -969,9 +971,11 @@ fused_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst 
            u32 batch, InvLast il, FusedCtl* ctl, u32 cap, u32 window) {
   constexpr u32 log_n = R + S;
   constexpr u32 kStridedTasks = 1u << (S - 8);  // 256 columns each
-  constexpr u32 kTileTasks = 1u << R;
+  constexpr u32 kTT = kFusedTT <= (1u << R) ? kFusedTT : (1u << R);
+  constexpr u32 kTileTasks = (1u << R) / kTT;   // kTT tiles each
   constexpr u32 n1 = FWD ? kStridedTasks : kTileTasks;
   constexpr u32 n2 = FWD ? kTileTasks : kStridedTasks;
+  static_assert(n1 < 256, "the slot word counts phase-1 tasks in 8 bits");
   __shared__ u64 lds[1 << S];
   __shared__ u32 task_sh[2][4];
   const u32 tid = threadIdx.x;
@@ -979,13 +983,21 @@ fused_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst 
   const u32 xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) & (kFusedMaxXcd - 1);
   FusedXcd* X = &ctl->xcd[xcc];
   FusedSlot* slots = reinterpret_cast<FusedSlot*>(ctl + 1) + (size_t)xcc * cap;
-  u32 end_slot = kFusedEnd;
   const u64 total = (u64)batch << log_n;
+  unsigned long long fs_dep = 0;
+  HX_FS(unsigned long long fs_claim = 0; unsigned long long fs_body[2] = {0, 0};
+        unsigned long long fs_n[2] = {0, 0}; const unsigned long long fs_t0 = HX_FS_NOW());
 
+  // (Drawing the ticket of the NEXT task before the current body runs -- to hide the
+  // atomic's latency behind it -- was measured slower, 5.2 vs 4.2 ms per step: the
+  // atomic's return sits in front of the body's own loads in the in-order vmcnt
+  // queue.)
   for (u32 it = 0;; ++it) {
     u32* ts = task_sh[it & 1];
+    HX_FS(const unsigned long long c0 = HX_FS_NOW());
     if (tid == 0) {
-      const FusedTask t = fused_claim(ctl, X, slots, n1, n2, batch, cap, window, end_slot);
+      const FusedTask t = fused_resolve(xcd_add(&X->ticket, 1), ctl, X, slots, n1, n2, batch, cap,
+                                        window, fs_dep);
       ts[0] = t.kind;
       ts[1] = t.poly;
       ts[2] = t.idx;
@@ -996,31 +1008,48 @@ fused_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst 
     const u32 kind = __builtin_amdgcn_readfirstlane(ts[0]);
     const u32 poly = __builtin_amdgcn_readfirstlane(ts[1]);
     const u32 idx = __builtin_amdgcn_readfirstlane(ts[2]);
+    HX_FS(const unsigned long long c1 = HX_FS_NOW(); fs_claim += c1 - c0);
     if (kind == 0) break;
-    if (FWD) {
-      if (kind == 1) {  // first R stages: HBM (streamed) -> L2 (plain stores stay there)
+    if ((kind == 1) == FWD) {
+      // strided stages.  Forward: the first R stages, HBM (streamed) -> L2 (plain
+      // stores stay there).  Inverse: the root R stages with N^-1 folded in,
+      // L2 -> HBM (streamed).
+      if (FWD)
         strided_body<true, R, A, false, kStream, kPlain>(out, in, tw, m, log_n, 0, kFirstPass,
                                                         poly * kStridedTasks + idx, il);
-      } else {  // last S stages: L2 -> HBM (streamed)
-        tile_body<true, S, 0, S, false, A, false, kL2, kStream>(lds, out, out, tw, m, log_n, finish,
-                                                               total, il, poly * kTileTasks + idx);
-      }
-    } else {
-      if (kind == 1) {  // deepest S stages: HBM -> L2
-        tile_body<false, S, 0, S, false, A, false, kPlain, kPlain>(
-            lds, out, in, tw, m, log_n, kFirstPass, total, il, poly * kTileTasks + idx);
-      } else {  // root R stages with N^-1 folded in: L2 -> HBM (streamed)
+      else
         strided_body<false, R, A, true, kL2, kStream>(out, out, tw, m, log_n, 0, finish,
                                                      poly * kStridedTasks + idx, il);
+    } else {
+      // tile stages.  Forward: the last S stages, L2 -> HBM (streamed).  Inverse: the
+      // deepest S stages, HBM -> L2.
+#pragma unroll 1
+      for (u32 tt = 0; tt < kTT; ++tt) {
+        const u32 tile = (poly << R) + idx * kTT + tt;
+        if (tt) __syncthreads();  // the previous tile's LDS reads are done
+        if (FWD)
+          tile_body<true, S, 0, S, false, A, false, kL2, kStream>(lds, out, out, tw, m, log_n,
+                                                                 finish, total, il, tile);
+        else
+          tile_body<false, S, 0, S, false, A, false, kPlain, kPlain>(lds, out, in, tw, m, log_n,
+                                                                    kFirstPass, total, il, tile);
       }
     }
     if (kind == 1) {
       // all of this task's stores are in L2 before the slot's counter moves
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) ctl_add(&slots[__builtin_amdgcn_readfirstlane(ts[3])].p1_done, 1);
+      if (tid == 0) xcd_add(&slots[__builtin_amdgcn_readfirstlane(ts[3])], 1);
     }
+    HX_FS(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); fs_body[kind - 1] += HX_FS_NOW() - c1;
+          fs_n[kind - 1] += 1);
   }
+  HX_FS(if (tid == 0 && g_fused_stats) {
+    unsigned long long* o = g_fused_stats + (size_t)blockIdx.x * 8;
+    o[0] = fs_n[0]; o[1] = fs_n[1]; o[2] = fs_claim; o[3] = fs_dep; o[4] = fs_body[0];
+    o[5] = fs_body[1]; o[6] = HX_FS_NOW() - fs_t0; o[7] = xcc;
+  });
+  (void)fs_dep;
 }
 
 // ---------------------------------------------------------------------------
@@ -1153,10 +1182,11 @@ struct Plan {
 };
 
 // Default for N >= 2^13: register-only strided pass(es) + an 11- or 12-stage
-// bottom tile_pass; for N = 2^13 .. 2^16 and batches that fill the chip the two are
-// run as ONE launch (fused_pass, one HBM round trip).  HEXL_AMD_PLAN=split keeps the
-// two launches; HEXL_AMD_PLAN=tiled selects two LDS-tiled kernels instead (6 + 10
-// stages on 1024-element tiles for N = 2^16; slower).
+// bottom tile_pass, two launches (kPlanSplit).  HEXL_AMD_PLAN=fused runs the two as
+// ONE persistent launch for N = 2^15, 2^16 (fused_pass; bit-exact, measured 10 %
+// slower than two launches, see its header and DESIGN.md); HEXL_AMD_PLAN=tiled
+// selects two LDS-tiled kernels (6 + 10 stages on 1024-element tiles for N = 2^16;
+// 4 % slower).
 enum PlanMode { kPlanFused = 0, kPlanSplit = 1, kPlanTiled = 2 };
 static u32 env_u32(const char* name, u32 dflt) {
   const char* e = getenv(name);
@@ -1170,12 +1200,12 @@ struct Tuning {
   std::atomic<u32> plan, fused_window, fused_min_batch, fused_wg_per_cu;
   Tuning() {
     const char* e = getenv("HEXL_AMD_PLAN");
-    plan = (e && strcmp(e, "tiled") == 0) ? kPlanTiled : (e && strcmp(e, "split") == 0) ? kPlanSplit
-                                                                                       : kPlanFused;
+    plan = (e && strcmp(e, "tiled") == 0) ? kPlanTiled : (e && strcmp(e, "fused") == 0) ? kPlanFused
+                                                                                       : kPlanSplit;
     // Slots (polynomials) an XCD may have in flight between the first phase-1 claim
     // and the last phase-2 claim; the smallest batch the fused launch is used for;
     // workgroups per CU of the persistent grid (0 = occupancy query).
-    fused_window = env_u32("HEXL_AMD_FUSED_WINDOW", 12);
+    fused_window = env_u32("HEXL_AMD_FUSED_WINDOW", 10);
     fused_min_batch = env_u32("HEXL_AMD_FUSED_MIN_BATCH", 64);
     fused_wg_per_cu = env_u32("HEXL_AMD_FUSED_WG_PER_CU", 0);
   }
@@ -1187,7 +1217,7 @@ static Tuning& tuning() {
 int set_tuning(const char* key, u64 value) {
   Tuning& t = tuning();
   if (strcmp(key, "plan") == 0 && value <= kPlanTiled) t.plan = (u32)value;
-  else if (strcmp(key, "fused_window") == 0 && value >= 1) t.fused_window = (u32)value;
+  else if (strcmp(key, "fused_window") == 0 && value < (1u << 16)) t.fused_window = (u32)value;
   else if (strcmp(key, "fused_min_batch") == 0 && value >= 1) t.fused_min_batch = (u32)value;
   else if (strcmp(key, "fused_wg_per_cu") == 0) t.fused_wg_per_cu = (u32)value;
   else return -1;
@@ -1294,9 +1324,10 @@ static hipError_t launch_fused_r(const NttTables& t, u64* result, const u64* ope
   unsigned grid = 0;
   hipError_t e = fused_grid<FWD, R, A>(&grid);
   if (e != hipSuccess) return e;
-  // An XCD creates at most `batch` slots that hold a polynomial plus one per
-  // workgroup that asks after the batch is exhausted.
-  const u32 cap = (u32)batch + grid + 2;
+  // An XCD's ticket list reaches at most `batch` steps that hold a polynomial, the
+  // `window` steps that drain the pipeline, and one ticket per workgroup after that.
+  const u32 window = fused_window();
+  const u32 cap = (u32)batch + window + grid + 4;
   const size_t bytes = sizeof(FusedCtl) + (size_t)kFusedMaxXcd * cap * sizeof(FusedSlot);
   void* ws = nullptr;
   e = stream_workspace(kWsFusedNtt, st, bytes, &ws);
@@ -1304,12 +1335,12 @@ static hipError_t launch_fused_r(const NttTables& t, u64* result, const u64* ope
   e = hipMemsetAsync(ws, 0, bytes, st);
   if (e != hipSuccess) return e;
   // no more workgroups than tasks of the larger phase
-  const u64 tasks = batch << (R > 3 ? R : 3);
+  const u64 tasks = batch << 3;
   if (tasks < grid) grid = (unsigned)tasks;
   ScopedKernelTimer timer(FWD ? "ntt_fwd_fused_pass" : "ntt_inv_fused_pass", st);
   hipLaunchKernelGGL((fused_pass<FWD, R, 11, A>), dim3(grid), dim3(256), 0, st, result, operand,
                      FWD ? t.fwd : t.inv, t.mod, fin, (u32)batch, t.inv_last, (FusedCtl*)ws, cap,
-                     fused_window());
+                     window);
   return hipGetLastError();
 }
 
@@ -1317,8 +1348,6 @@ template <bool FWD, class A>
 static hipError_t launch_fused(int R, const NttTables& t, u64* result, const u64* operand,
                                u64 batch, u32 fin, hipStream_t st) {
   switch (R) {
-    case 2: return launch_fused_r<FWD, 2, A>(t, result, operand, batch, fin, st);
-    case 3: return launch_fused_r<FWD, 3, A>(t, result, operand, batch, fin, st);
     case 4: return launch_fused_r<FWD, 4, A>(t, result, operand, batch, fin, st);
     case 5: return launch_fused_r<FWD, 5, A>(t, result, operand, batch, fin, st);
     default: return hipErrorInvalidValue;
@@ -1385,7 +1414,7 @@ static hipError_t transform_impl(const NttTables& t, u64* result, const u64* ope
                                  u64 out_mf, hipStream_t st) {
   const Plan p = make_plan((int)t.log_n);
   if (plan_mode() == kPlanFused && p.n_strided == 1 && p.bottom == 11 && !p.top_tile &&
-      p.strided[0] >= 2 && batch >= fused_min_batch() && batch < (1ull << 26))
+      p.strided[0] >= 4 && batch >= fused_min_batch() && batch < (1ull << 23))
     return launch_fused<FWD, A>(p.strided[0], t, result, operand, batch, out_mf == 1 ? 2 : 1, st);
   return FWD ? forward_seq<A>(t, p, result, operand, batch, out_mf, st)
              : inverse_seq<A>(t, p, result, operand, batch, out_mf, st);

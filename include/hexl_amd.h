@@ -304,9 +304,11 @@ int hexl_amd_profile_get(int i, const char** name, float* ms);
 /* Tuning / diagnostic knobs of the transform launch logic (process-wide; the
  * HEXL_AMD_* environment variables give the defaults).  Results never depend on
  * them, only speed.  Keys:
- *   "plan"             0 = fused (N = 2^13..2^16: both passes in one launch, the
- *                      intermediate stays in the XCD's L2), 1 = split (two
- *                      launches), 2 = tiled (two LDS-tiled launches)
+ *   "plan"             1 = split (default: strided pass + tile pass, two
+ *                      launches), 0 = fused (N = 2^15, 2^16: both passes in one
+ *                      persistent launch, the intermediate read back from the
+ *                      XCD's L2; slower, kept as an experiment), 2 = tiled (two
+ *                      LDS-tiled launches)
  *   "fused_window"     polynomials one XCD keeps in flight (>= 1)
  *   "fused_min_batch"  smallest batch the fused launch is used for (>= 1)
  *   "fused_wg_per_cu"  persistent workgroups per CU (0 = occupancy query) */

@@ -101,6 +101,21 @@ def cpu_baseline(seconds_single=4.0, seconds_all=8.0):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(gpus, argv, port=None):
+    """`python bench.py --gpus N` outside torchrun: the command that re-runs this script as
+    N ranks of one node (one process per GPU; rendezvous on 127.0.0.1, as the driver does)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+            f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port or free_port()), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +125,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: spawn the ranks ourselves; rank 0's JSON line passes through
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(launcher_command(args.gpus, sys.argv[1:]), env=env))
+
     import torch
 
     import hexl_amd as hx
@@ -118,8 +140,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # Dry-run hooks for a 1-GPU box (tests of the multi-rank code path): BENCH_ONE_DEVICE=1
     # puts every rank on cuda:0, BENCH_BACKEND=gloo replaces RCCL for the barrier / max.
     backend = os.environ.get("BENCH_BACKEND", "nccl")

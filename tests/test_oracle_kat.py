@@ -129,6 +129,31 @@ def test_ntt_matches_definition(n, q):
         assert int(got[int(i)]) == acc
 
 
+DEFN = json.load(open(os.path.join(os.path.dirname(__file__), "golden",
+                                   "ntt_definition_fixtures.json")))
+
+
+@pytest.mark.parametrize("case", DEFN["cases"], ids=lambda c: "n%d" % c["n"])
+def test_ntt_matches_definition_at_benchmark_sizes(case):
+    """The oracle pinned where the benchmark lives (N = 4096 / 65536 / 131072 with the
+    survey's primes): 64 forward and 64 inverse output entries computed from the
+    transform's definition in Python big integers by
+    tests/golden/make_ntt_definition_fixtures.py (independent of the oracle), plus the
+    digest of the full vector those entries belong to."""
+    import hashlib
+    n, q = case["n"], case["q"]
+    ntt = ho.NTT(n, q)
+    assert ntt.w == case["minimal_root"]
+    f = ntt.forward(ho.fill_splitmix(n, case["forward"]["seed"], q), 1, 1)
+    for i, v in case["forward"]["samples"]:
+        assert int(f[i]) == v
+    assert hashlib.sha256(f.astype("<u8").tobytes()).hexdigest() == case["forward"]["sha256_le_u64"]
+    b = ntt.inverse(ho.fill_splitmix(n, case["inverse"]["seed"], q), 1, 1)
+    for j, v in case["inverse"]["samples"]:
+        assert int(b[j]) == v
+    assert hashlib.sha256(b.astype("<u8").tobytes()).hexdigest() == case["inverse"]["sha256_le_u64"]
+
+
 @pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048,
                                4096, 8192])
 @pytest.mark.parametrize("bits", [27, 33, 49, 54, 60])

@@ -74,3 +74,32 @@ def test_two_rank_gloo_partition_matches_single_process(tmp_path, world):
         for p in range(POLYS):
             ref.append(ntt.forward(ho.fill_splitmix(N, 1000 * k + p, q), 1, 1))
     assert (got == np.stack(ref)).all()
+
+
+def test_bench_self_launcher_builds_the_rank_environment(tmp_path):
+    """`python bench.py --gpus N` outside torchrun re-runs itself under
+    torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1; the ranks see
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (checked by running a stub through the very
+    command the launcher builds)."""
+    import subprocess
+    import sys
+
+    import bench
+
+    cmd = bench.launcher_command(2, ["--gpus", "2", "--steps", "3"], port=29123)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29123"
+    assert cmd[-5].endswith("bench.py") and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
+    # run a stub in place of bench.py through the same launcher line
+    stub = tmp_path / "stub.py"
+    stub.write_text(
+        "import os, sys\n"
+        "open(os.path.join(sys.argv[1], 'rank%s' % os.environ['RANK']), 'w').write(\n"
+        "    ' '.join(os.environ[k] for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR')))\n")
+    cmd = bench.launcher_command(2, [str(tmp_path)], port=bench.free_port())
+    cmd[cmd.index(os.path.abspath(bench.__file__))] = str(stub)
+    subprocess.check_call(cmd, timeout=300)
+    assert (tmp_path / "rank0").read_text() == "0 0 2 127.0.0.1"
+    assert (tmp_path / "rank1").read_text() == "1 1 2 127.0.0.1"

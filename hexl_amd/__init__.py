@@ -151,7 +151,9 @@ def _require_gpu():
     return torch
 
 
-def _ptr(t):
+def _ptr(t, need=0, device=None):
+    """Device pointer of tensor `t`, which must hold at least `need` words and live on
+    `device` (default: the current device, where the kernels are launched)."""
     torch = _torch()
     if not isinstance(t, torch.Tensor):
         raise HexlAmdError("expected a torch tensor")
@@ -162,6 +164,11 @@ def _ptr(t):
         raise HexlAmdError(f"expected int64/uint64 storage, got {t.dtype}")
     if not t.is_contiguous():
         raise HexlAmdError("expected a contiguous tensor")
+    if t.numel() < need:
+        raise HexlAmdError(f"tensor holds {t.numel()} words, the call needs {need}")
+    want = torch.cuda.current_device() if device is None else device
+    if t.device.index != want:
+        raise HexlAmdError(f"tensor is on cuda:{t.device.index}, the call runs on cuda:{want}")
     return C.c_void_p(t.data_ptr())
 
 
@@ -261,6 +268,9 @@ class NTT:
     def CheckArguments(degree, modulus):
         return bool(lib.hexl_amd_ntt_check_arguments(degree, modulus))
 
+    def GetDevice(self):
+        return self._device
+
     def GetDegree(self):
         return lib.hexl_amd_ntt_degree(self._h)
 
@@ -305,12 +315,14 @@ class NTT:
 
     def ComputeForward(self, result, operand, input_mod_factor, output_mod_factor):
         b = self._batch(result, operand)
-        _check(lib.hexl_amd_ntt_forward(self._h, _ptr(result), _ptr(operand), b,
+        dev = self.GetDevice()
+        _check(lib.hexl_amd_ntt_forward(self._h, _ptr(result, 0, dev), _ptr(operand, 0, dev), b,
                                         input_mod_factor, output_mod_factor, _stream()))
 
     def ComputeInverse(self, result, operand, input_mod_factor, output_mod_factor):
         b = self._batch(result, operand)
-        _check(lib.hexl_amd_ntt_inverse(self._h, _ptr(result), _ptr(operand), b,
+        dev = self.GetDevice()
+        _check(lib.hexl_amd_ntt_inverse(self._h, _ptr(result, 0, dev), _ptr(operand, 0, dev), b,
                                         input_mod_factor, output_mod_factor, _stream()))
 
 
@@ -320,7 +332,8 @@ def _rns(fn, plans, result, operand, in_mf, out_mf):
     if operand.numel() % (k * n) or result.numel() != operand.numel():
         raise HexlAmdError("operand must hold len(plans) * batch * degree words")
     arr = (C.c_void_p * k)(*[p._h for p in plans])
-    _check(fn(arr, k, _ptr(result), _ptr(operand), operand.numel() // (k * n), in_mf, out_mf,
+    dev = plans[0].GetDevice()
+    _check(fn(arr, k, _ptr(result, 0, dev), _ptr(operand, 0, dev), operand.numel() // (k * n), in_mf, out_mf,
               _stream()))
 
 
@@ -341,35 +354,35 @@ def ComputeInverseRNS(plans, result, operand, input_mod_factor, output_mod_facto
 def EltwiseAddMod(result, operand1, operand2, n, modulus):
     """operand2: tensor (vector-vector) or int (vector-scalar)."""
     if isinstance(operand2, int):
-        _check(lib.hexl_amd_eltwise_add_mod_scalar(_ptr(result), _ptr(operand1), operand2, n,
+        _check(lib.hexl_amd_eltwise_add_mod_scalar(_ptr(result, n), _ptr(operand1, n), operand2, n,
                                                    modulus, _stream()))
     else:
-        _check(lib.hexl_amd_eltwise_add_mod(_ptr(result), _ptr(operand1), _ptr(operand2), n,
+        _check(lib.hexl_amd_eltwise_add_mod(_ptr(result, n), _ptr(operand1, n), _ptr(operand2, n), n,
                                             modulus, _stream()))
 
 
 def EltwiseSubMod(result, operand1, operand2, n, modulus):
     if isinstance(operand2, int):
-        _check(lib.hexl_amd_eltwise_sub_mod_scalar(_ptr(result), _ptr(operand1), operand2, n,
+        _check(lib.hexl_amd_eltwise_sub_mod_scalar(_ptr(result, n), _ptr(operand1, n), operand2, n,
                                                    modulus, _stream()))
     else:
-        _check(lib.hexl_amd_eltwise_sub_mod(_ptr(result), _ptr(operand1), _ptr(operand2), n,
+        _check(lib.hexl_amd_eltwise_sub_mod(_ptr(result, n), _ptr(operand1, n), _ptr(operand2, n), n,
                                             modulus, _stream()))
 
 
 def EltwiseMultMod(result, operand1, operand2, n, modulus, input_mod_factor):
-    _check(lib.hexl_amd_eltwise_mult_mod(_ptr(result), _ptr(operand1), _ptr(operand2), n,
+    _check(lib.hexl_amd_eltwise_mult_mod(_ptr(result, n), _ptr(operand1, n), _ptr(operand2, n), n,
                                          modulus, input_mod_factor, _stream()))
 
 
 def EltwiseFMAMod(result, arg1, arg2, arg3, n, modulus, input_mod_factor):
-    p3 = _ptr(arg3) if arg3 is not None else None
-    _check(lib.hexl_amd_eltwise_fma_mod(_ptr(result), _ptr(arg1), arg2, p3, n, modulus,
+    p3 = _ptr(arg3, n) if arg3 is not None else None
+    _check(lib.hexl_amd_eltwise_fma_mod(_ptr(result, n), _ptr(arg1, n), arg2, p3, n, modulus,
                                         input_mod_factor, _stream()))
 
 
 def EltwiseReduceMod(result, operand, n, modulus, input_mod_factor, output_mod_factor):
-    _check(lib.hexl_amd_eltwise_reduce_mod(_ptr(result), _ptr(operand), n, modulus,
+    _check(lib.hexl_amd_eltwise_reduce_mod(_ptr(result, n), _ptr(operand, n), n, modulus,
                                            input_mod_factor, output_mod_factor, _stream()))
 
 
@@ -377,7 +390,8 @@ def DyadicMultiply(result, operand1, operand2, n, moduli):
     """hexl/include/hexl/experimental/seal/dyadic-multiply.hpp:26-28; `moduli` is a host
     sequence of integers."""
     arr = (C.c_uint64 * len(moduli))(*[int(m) for m in moduli])
-    _check(lib.hexl_amd_dyadic_multiply(_ptr(result), _ptr(operand1), _ptr(operand2), n, arr,
+    k = n * len(moduli)
+    _check(lib.hexl_amd_dyadic_multiply(_ptr(result, 3 * k), _ptr(operand1, 2 * k), _ptr(operand2, 2 * k), n, arr,
                                         len(moduli), _stream()))
 
 
@@ -387,8 +401,13 @@ def KeySwitch(result, t_target_iter, n, decomp_modulus_size, key_modulus_size, r
     entries of k_switch_keys are device tensors; moduli / modswitch_factors host sequences."""
     mod = (C.c_uint64 * len(moduli))(*[int(m) for m in moduli])
     msf = (C.c_uint64 * len(modswitch_factors))(*[int(m) for m in modswitch_factors])
-    keys = (C.c_void_p * len(k_switch_keys))(*[_ptr(k).value for k in k_switch_keys])
-    _check(lib.hexl_amd_key_switch(_ptr(result), _ptr(t_target_iter), n, decomp_modulus_size,
+    if (len(moduli) < key_modulus_size or len(modswitch_factors) < decomp_modulus_size or
+            len(k_switch_keys) < decomp_modulus_size):
+        raise HexlAmdError("moduli / modswitch_factors / k_switch_keys are shorter than the sizes say")
+    key_words = key_component_count * key_modulus_size * n
+    keys = (C.c_void_p * len(k_switch_keys))(*[_ptr(k, key_words).value for k in k_switch_keys])
+    _check(lib.hexl_amd_key_switch(_ptr(result, key_component_count * decomp_modulus_size * n),
+                                   _ptr(t_target_iter, decomp_modulus_size * n), n, decomp_modulus_size,
                                    key_modulus_size, rns_modulus_size, key_component_count, mod,
                                    keys, msf, _stream()))
 
@@ -400,20 +419,20 @@ class CMPINT:
 
 def EltwiseCmpAdd(result, operand1, n, cmp, bound, diff):
     """hexl/include/hexl/eltwise/eltwise-cmp-add.hpp:24-25."""
-    _check(lib.hexl_amd_eltwise_cmp_add(_ptr(result), _ptr(operand1), n, int(cmp), bound, diff,
+    _check(lib.hexl_amd_eltwise_cmp_add(_ptr(result, n), _ptr(operand1, n), n, int(cmp), bound, diff,
                                         _stream()))
 
 
 def EltwiseCmpSubMod(result, operand1, n, modulus, cmp, bound, diff):
     """hexl/include/hexl/eltwise/eltwise-cmp-sub-mod.hpp:26-28."""
-    _check(lib.hexl_amd_eltwise_cmp_sub_mod(_ptr(result), _ptr(operand1), n, modulus, int(cmp),
+    _check(lib.hexl_amd_eltwise_cmp_sub_mod(_ptr(result, n), _ptr(operand1, n), n, modulus, int(cmp),
                                             bound, diff, _stream()))
 
 
 def EltwiseReduceFMAMod(result, arg1, arg2, arg3, n, modulus, input_mod_factor):
     """Fused EltwiseReduceMod(q -> 1) + EltwiseFMAMod (BASELINE config 5)."""
-    p3 = _ptr(arg3) if arg3 is not None else None
-    _check(lib.hexl_amd_eltwise_reduce_fma_mod(_ptr(result), _ptr(arg1), arg2, p3, n, modulus,
+    p3 = _ptr(arg3, n) if arg3 is not None else None
+    _check(lib.hexl_amd_eltwise_reduce_fma_mod(_ptr(result, n), _ptr(arg1, n), arg2, p3, n, modulus,
                                                input_mod_factor, _stream()))
 
 
@@ -445,4 +464,4 @@ def set_tuning(key, value):
 
 def fill_splitmix(data, n, batch, seed0, bound):
     """Device-side synthetic input: poly b = splitmix64(seed0 + b) mod bound."""
-    _check(lib.hexl_amd_fill_splitmix(_ptr(data), n, batch, seed0, bound, _stream()))
+    _check(lib.hexl_amd_fill_splitmix(_ptr(data, n * batch), n, batch, seed0, bound, _stream()))

@@ -17,6 +17,7 @@
 #include "../../include/hexl_amd.h"
 #include "internal.h"
 #include "number_theory.h"
+#include "workspace.h"
 
 using namespace hexl_amd;
 
@@ -72,8 +73,17 @@ struct Staging {
   ~Staging() {
     // Process teardown may already have destroyed the HIP runtime; leak.
   }
+  // `dev` is the current device.
   int ensure(int dev, size_t bytes) {
     if (device != dev) {
+      if (device >= 0 && (buf || stream)) {  // release what belongs to the previous device
+        if (hipSetDevice(device) == hipSuccess) {
+          if (stream) (void)hipStreamSynchronize(stream);
+          if (buf) (void)hipFree(buf);
+          if (stream) (void)hipStreamDestroy(stream);
+        }
+        HX_HIP(hipSetDevice(dev));
+      }
       buf = nullptr;
       cap = 0;
       stream = nullptr;
@@ -406,6 +416,9 @@ static int check_elt(EltOp op, const EltArgs& g) {
       if (!(g.in_mf == 1 || g.in_mf == 2 || g.in_mf == 4 || g.in_mf == 8))
         return fail(HEXL_AMD_ERR_INVALID_ARG, "input_mod_factor must be 1, 2, 4 or 8");
       if (g.q >= (1ull << 61)) return fail(HEXL_AMD_ERR_INVALID_ARG, "modulus must be < 2^61");
+      // eltwise-fma-mod.cpp:29-31 (HEXL_CHECK in debug builds): arg2 < input_mod_factor * q
+      if (g.scalar >= g.in_mf * g.q)
+        return fail(HEXL_AMD_ERR_INVALID_ARG, "arg2 must be < input_mod_factor * modulus");
       break;
     case ELT_REDUCE:
       if (!(g.in_mf == g.q || g.in_mf == 2 || g.in_mf == 4))
@@ -604,8 +617,6 @@ const hexl_amd_ntt* cached_plan(u64 n, u64 q, int device) {
   return p;
 }
 
-thread_local Staging g_workspace;  // device scratch of the composite operations
-
 u64 floor_2_64_over(u64 q) { return (u64)((((unsigned __int128)1) << 64) / q); }
 
 }  // namespace
@@ -638,6 +649,11 @@ static int check_key_switch(const uint64_t* result, const uint64_t* t_target, ui
         return fail(HEXL_AMD_ERR_INVALID_ARG,
                     "moduli[%llu] is not an NTT-friendly prime below 2^61 for degree %llu",
                     (unsigned long long)i, (unsigned long long)n);
+  // the factors go through EltwiseFMAMod(input_mod_factor = 8): key-switch-internal.cpp:190
+  for (uint64_t i = 0; i < D; ++i)
+    if (msf[i] >= 8 * moduli[i])
+      return fail(HEXL_AMD_ERR_INVALID_ARG, "modswitch_factors[%llu] must be < 8 * moduli[%llu]",
+                  (unsigned long long)i, (unsigned long long)i);
   return HEXL_AMD_OK;
 }
 
@@ -653,10 +669,13 @@ static int key_switch_device(u64* result, const u64* t_target_iter, u64 n, u64 D
       plan[i] = cached_plan(n, moduli[i], device);
       if (!plan[i]) return HEXL_AMD_ERR_HIP;  // message set by hexl_amd_ntt_create
     }
-  // workspace: t_target (D n) | ntt_buf (D n) | t_poly_prod (C R n)
+  // workspace: t_target (D n) | ntt_buf (D n) | t_poly_prod (C R n).  Keyed by the
+  // caller's stream: calls on one stream are serialised and share it, calls on
+  // different streams may overlap on the device and get separate buffers.
   const size_t words = (size_t)n * (2 * D + C * R);
-  if (int rc = g_workspace.ensure(device, words * sizeof(u64))) return rc;
-  u64* t_target = (u64*)g_workspace.buf;
+  void* ws = nullptr;
+  HX_HIP(stream_workspace(kWsKeySwitch, st, words * sizeof(u64), &ws));
+  u64* t_target = (u64*)ws;
   u64* ntt_buf = t_target + D * n;
   u64* prod = ntt_buf + D * n;
   hipError_t e;

@@ -169,8 +169,9 @@ typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 
 template <class Op, bool HAS_B>
 __global__ void __launch_bounds__(256)
-eltwise_vec2(u64* __restrict__ res, const u64* __restrict__ a, const u64* __restrict__ b,
-             u64 npairs, Op op) {
+eltwise_vec2(u64* res, const u64* a, const u64* b, u64 npairs, Op op) {
+  // (no __restrict__: the result may alias an operand -- in place is the common use;
+  // a thread loads its inputs before it stores)
   const u64x2* a2 = reinterpret_cast<const u64x2*>(a);
   const u64x2* b2 = reinterpret_cast<const u64x2*>(b);
   u64x2* r2 = reinterpret_cast<u64x2*>(res);

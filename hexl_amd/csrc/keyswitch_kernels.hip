@@ -25,7 +25,7 @@ __device__ __forceinline__ u64 full_reduce(u64 x, u64 q, u64 barrett) {
 // :77-89 operands of the products for RNS index i: slot s holds decomposition
 // modulus jmap[s], reduced to the key modulus where that one is smaller.
 __global__ void __launch_bounds__(256)
-ks_gather_kernel(u64* __restrict__ out, const u64* __restrict__ t_target, u64 n, KsGather g) {
+ks_gather_kernel(u64* out, const u64* t_target, u64 n, KsGather g) {
   const u32 s = blockIdx.y;
   const u64* src = t_target + (u64)g.jmap[s] * n;
   u64* dst = out + (u64)s * n;
@@ -40,8 +40,7 @@ ks_gather_kernel(u64* __restrict__ out, const u64* __restrict__ t_target, u64 n,
 // :94-130 multiply with the keys, accumulate in 128 bits, reduce once.
 // blockIdx.y = key component k.
 __global__ void __launch_bounds__(256)
-ks_mac_kernel(u64* __restrict__ prod, const u64* __restrict__ t_target_iter,
-              const u64* __restrict__ ntt_buf, u64 n, KsMac m) {
+ks_mac_kernel(u64* prod, const u64* t_target_iter, const u64* ntt_buf, u64 n, KsMac m) {
   const u32 k = blockIdx.y;
   const u64 key_off = (u64)k * m.key_component_stride + m.key_index_offset;
   u64* dst = prod + (u64)k * m.prod_component_stride + m.prod_offset;
@@ -69,7 +68,7 @@ ks_mac_kernel(u64* __restrict__ prod, const u64* __restrict__ t_target_iter,
 // :146-175 round the last RNS component (add q_k / 2, reduce mod q_k), bring it to
 // every decomposition modulus and add the correction; blockIdx.y = i.
 __global__ void __launch_bounds__(256)
-ks_round_kernel(u64* __restrict__ tbuf, const u64* __restrict__ t_last, u64 n, KsRound r) {
+ks_round_kernel(u64* tbuf, const u64* t_last, u64 n, KsRound r) {
   const KsRoundMod mi = r.mod[blockIdx.y];
   u64* dst = tbuf + (u64)blockIdx.y * n;
   const u64 stride = (u64)gridDim.x * 256;
@@ -83,8 +82,7 @@ ks_round_kernel(u64* __restrict__ tbuf, const u64* __restrict__ t_last, u64 n, K
 // :180-196 (ct mod q_i - ct mod q_k) * q_k^-1 mod q_i, accumulated into the result;
 // blockIdx.y = i.
 __global__ void __launch_bounds__(256)
-ks_finish_kernel(u64* __restrict__ result, const u64* __restrict__ prod,
-                 const u64* __restrict__ tbuf, u64 n, KsFinish f) {
+ks_finish_kernel(u64* result, const u64* prod, const u64* tbuf, u64 n, KsFinish f) {
   const KsFinishMod mi = f.mod[blockIdx.y];
   u64* data = result + (u64)blockIdx.y * n;
   const u64* p = prod + (u64)blockIdx.y * n;

@@ -35,6 +35,11 @@ BATCH = 4096
 PRIMES = [18014398510661633, 18014398512365569, 18014398514200577, 18014398514987009,
           18014398515511297, 18014398516559873, 18014398521016321, 18014398524424193]
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+TRAFFIC_PROFILE = "r2_hbm_traffic.json"
+# what keeps each kernel family below the HBM roofline (profiles/r2_pmc_summary.md)
+KERNEL_LIMITER = {"ntt_fwd_strided_pass": "hbm", "ntt_inv_strided_pass": "hbm",
+                  "ntt_fwd_tile_pass_bottom": "valu-issue", "ntt_inv_tile_pass_bottom": "valu-issue",
+                  "ntt_fwd_fused_pass": "valu-issue + scheduler", "ntt_inv_fused_pass": "valu-issue + scheduler"}
 PREWARM = 20            # untimed passes before the --warmup ones (see main)
 
 
@@ -98,6 +103,78 @@ def cpu_baseline(seconds_single=4.0, seconds_all=8.0):
     if simd:
         out["scalar_single_thread_value"] = run(scalar_fns, 1, 2.0)
     ho.lib.ho_ntt_destroy(plan)
+    return out
+
+
+def event_timed(torch, fn, iters):
+    """average seconds per call of fn, HIP events on the current (= launch) stream"""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def rate(bytes_algorithmic, seconds, **extra):
+    g = bytes_algorithmic / seconds / 1e9
+    return dict({"us": seconds * 1e6, "GBps_algorithmic": g, "frac_of_hbm_peak": g / HBM_PEAK_GBPS},
+                **extra)
+
+
+def timed_eltwise(hx, torch, name, n, batch, q):
+    a = torch.empty(batch * n, dtype=torch.int64, device="cuda")
+    b = torch.empty_like(a)
+    r = torch.empty_like(a)
+    hx.fill_splitmix(a, n, batch, 3, q)
+    hx.fill_splitmix(b, n, batch, 7, q)
+    t = event_timed(torch, lambda: hx.EltwiseMultMod(r, a, b, batch * n, q, 1), 5)
+    return dict(rate(24.0 * batch * n, t), op=name, elements=batch * n, ms=t * 1e3)
+
+
+def secondary_configs(hx, torch):
+    """BASELINE.json configs[1] and configs[4] (not the timed metric): per-call time with the
+    calls issued back to back on one stream (for the 8-us config-2 kernels that is the
+    launch-bound rate a caller sees)."""
+    out = {}
+    n, b, q = 4096, 256, 562949954093057  # configs[1]: N=4096, 50-bit prime, batch 256
+    x = torch.empty((b, n), dtype=torch.int64, device="cuda")
+    y = torch.empty_like(x)
+    hx.fill_splitmix(x, n, b, 1, q)
+    ntt = hx.NTT(n, q)
+    out["config2"] = {
+        "shape": f"N={n}, q={q} (50-bit), batch={b}",
+        "fwd": rate(16.0 * n * b, event_timed(torch, lambda: ntt.ComputeForward(y, x, 1, 1), 200)),
+        "inv": rate(16.0 * n * b, event_timed(torch, lambda: ntt.ComputeInverse(y, x, 1, 1), 200)),
+        "multmod": rate(24.0 * n * b,
+                        event_timed(torch, lambda: hx.EltwiseMultMod(y, x, x, n * b, q, 1), 200)),
+    }
+    n, b, q = 131072, 1024, 1152921504616808449  # configs[4]: N=131072, 61-bit prime, batch 1024
+    a = torch.empty(b * n, dtype=torch.int64, device="cuda")
+    c = torch.empty_like(a)
+    r = torch.empty_like(a)
+    hx.fill_splitmix(a, n, b, 21, 4 * q)
+    hx.fill_splitmix(c, n, b, 1021, 4 * q)
+    s = 3 * q + 12345
+    e = float(n) * b
+    ntt = hx.NTT(n, q)
+    cfg5 = {"shape": f"N={n}, q={q} (61-bit), batch={b}"}
+    cfg5["fma"] = rate(24 * e, event_timed(torch, lambda: hx.EltwiseFMAMod(r, a, s, c, b * n, q, 4), 5),
+                       op="EltwiseFMAMod(input_mod_factor=4, arg3 != null)")
+    cfg5["reduce"] = rate(16 * e, event_timed(torch, lambda: hx.EltwiseReduceMod(r, a, b * n, q, 4, 1), 5),
+                          op="EltwiseReduceMod(4 -> 1)")
+    cfg5["reduce_q"] = rate(16 * e, event_timed(torch, lambda: hx.EltwiseReduceMod(r, a, b * n, q, q, 1), 5),
+                            op="EltwiseReduceMod(q -> 1)")
+    cfg5["fused"] = rate(24 * e, event_timed(torch, lambda: hx.EltwiseReduceFMAMod(r, a, s % q, c, b * n, q, q), 5),
+                         op="fused ReduceMod(q -> 1) + FMAMod, one kernel")
+    hx.EltwiseReduceMod(a, a, b * n, q, 4, 1)
+    cfg5["ntt_fwd"] = rate(16 * e, event_timed(torch, lambda: ntt.ComputeForward(r, a, 1, 1), 5))
+    cfg5["ntt_inv"] = rate(16 * e, event_timed(torch, lambda: ntt.ComputeInverse(r, a, 1, 1), 5))
+    out["config5"] = cfg5
     return out
 
 
@@ -211,37 +288,27 @@ def main():
     # HBM bytes per launch of the dominant kernel from the committed PMC profile
     # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 read
     # correction: profiles/r1_pmc_summary.md); null if the profile does not cover it
-    traffic = None
+    traffic, traffic_source = None, None
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")))
+        prof = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)))
         if batch == BATCH:
             traffic = prof["by_bench_kernel_family"].get(dominant)
+            traffic_source = ("committed rocprofv3 --pmc profile of this command, not collected in "
+                              "this run: profiles/" + TRAFFIC_PROFILE)
     except (OSError, KeyError, ValueError):
         pass
 
-    # Secondary figure of the target (outside the timed region): EltwiseMultMod over the same
-    # batch, 24 algorithmic bytes per element, HIP-event timed.
+    # Secondary figures (outside the timed region, rank 0 at N=1 only): EltwiseMultMod over the
+    # headline batch and BASELINE.json configs[1] / configs[4], each as algorithmic GB/s and
+    # fraction of the 8 TB/s HBM peak (algorithmic bytes: SURVEY.md 8d / BASELINE.md 4).
     mult = None
+    secondary = None
     if rank == 0 and batch == BATCH:
-        b = torch.empty_like(data)
-        hx.fill_splitmix(b, N, batch, 7, q)
-        r = torch.empty_like(data)
-        n_el = batch * N
-        for _ in range(2):
-            hx.EltwiseMultMod(r, data, b, n_el, q, 1)
-        torch.cuda.synchronize()
-        hx.profile_start(16)
-        for _ in range(5):
-            hx.EltwiseMultMod(r, data, b, n_el, q, 1)
-        torch.cuda.synchronize()
-        ms = [t for name, t in hx.profile_stop() if name == "eltwise"]
-        if ms:
-            avg = sum(ms) / len(ms)
-            mult = {"op": "EltwiseMultMod(input_mod_factor=1)", "elements": n_el, "ms": avg,
-                    "GBps_algorithmic": 24.0 * n_el / (avg * 1e-3) / 1e9,
-                    "frac_of_hbm_peak": 24.0 * n_el / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-        del b, r
-
+        mult = timed_eltwise(hx, torch, "EltwiseMultMod(input_mod_factor=1)", N, batch, q)
+    if rank == 0 and world == 1 and batch == BATCH:
+        del data
+        torch.cuda.empty_cache()
+        secondary = secondary_configs(hx, torch)
     if rank == 0:
         out = {
             "metric": "Fwd+Inv NTTs/sec, N=65536 q~55b batch=4096",
@@ -260,14 +327,22 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": dominant, "achieved": achieved,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic,
+                "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_kernel_ms": kern_avg,
-                "note": ("per-kernel HIP-event timing on the launch stream inside the timed "
-                         "region; every kernel of the transform is listed in avg_kernel_ms")},
+                "per_kernel": {k: {"ms": v, "GBps_algorithmic": alg_bytes / (v * 1e-3) / 1e9,
+                                   "frac_of_hbm_peak": alg_bytes / (v * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                   "limiter": KERNEL_LIMITER.get(k, "hbm")}
+                               for k, v in kern_avg.items()},
+                "note": ("achieved = algorithmic bytes (16*N per transform, read + write once) of the "
+                         "dominant kernel's launch / its HIP-event duration on the launch stream inside "
+                         "the timed region; the bound of the path is HBM, `limiter` says what holds each "
+                         "kernel below it (the tile pass is VALU-issue limited: DESIGN.md 4-5)")},
         }
         if mult is not None:
             out["eltwise_mult_mod"] = mult
+        if secondary is not None:
+            out["secondary"] = secondary
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         elif world > 1:

@@ -458,7 +458,7 @@ PLAN_FUSED, PLAN_SPLIT, PLAN_TILED = 0, 1, 2
 def set_tuning(key, value):
     """Tuning / diagnostic knobs of the transform launch logic (include/hexl_amd.h):
     "plan" (PLAN_FUSED / PLAN_SPLIT / PLAN_TILED), "fused_window", "fused_min_batch",
-    "fused_wg_per_cu".  Results never depend on them."""
+    "fused_wg_per_cu", "fp64" (read at plan creation).  Results never depend on them."""
     _check(lib.hexl_amd_set_tuning(key.encode(), int(value)))
 
 

@@ -202,36 +202,57 @@ int hexl_amd_ntt_create(hexl_amd_ntt** out, uint64_t degree, uint64_t modulus,
     p->host[2][i] = nt::multiply_factor(R[i], 64, q);
     p->host[6][i] = nt::multiply_factor(IR[i], 64, q);
   }
-  // Device tables: heap-ordered (value, Shoup factor) pairs; the factor has 63
-  // fractional bits under the Lazy arithmetic policy, 64 otherwise.
-  const u64 shoup_bits = q < kSmallModulusBound ? 32 : q < kLazyModulusBound ? 63 : 64;
-  std::vector<ulonglong2> hf(n), hi(n);
+  // Device tables: heap-ordered (value, Shoup factor) pairs -- the factor has 32 / 63 / 64
+  // fractional bits under the Small / Lazy / Strict arithmetic policy -- or, under Fp64,
+  // one double per twiddle: the value balanced into (-q/2, q/2].
+  const int policy = choose_policy(q);
+  const u64 shoup_bits = policy == kPolicySmall ? 32 : policy == kPolicyLazy ? 63 : 64;
+  auto balanced = [q](u64 w) { return w > q / 2 ? -(double)(q - w) : (double)w; };
+  auto bits_of = [](double d) {
+    u64 b;
+    memcpy(&b, &d, sizeof b);
+    return b;
+  };
+  const size_t entry = policy == kPolicyFp64 ? sizeof(double) : sizeof(ulonglong2);
+  std::vector<u64> hf, hi;  // raw table words
+  hf.reserve(n * entry / 8);
+  hi.reserve(n * entry / 8);
   for (u64 i = 0; i < n; ++i) {
-    hf[i].x = R[i];
-    hf[i].y = nt::multiply_factor(R[i], shoup_bits, q);
-    hi[i].x = Rinv[i];
-    hi[i].y = nt::multiply_factor(Rinv[i], shoup_bits, q);
+    if (policy == kPolicyFp64) {
+      hf.push_back(bits_of(balanced(R[i])));
+      hi.push_back(bits_of(balanced(Rinv[i])));
+    } else {
+      hf.push_back(R[i]);
+      hf.push_back(nt::multiply_factor(R[i], shoup_bits, q));
+      hi.push_back(Rinv[i]);
+      hi.push_back(nt::multiply_factor(Rinv[i], shoup_bits, q));
+    }
   }
   InvLast il;
   il.n1 = nt::inverse_mod(n, q);
-  il.n1p = nt::multiply_factor(il.n1, shoup_bits, q);
   il.n1w = nt::multiply_mod(il.n1, Rinv[1], q);
-  il.n1wp = nt::multiply_factor(il.n1w, shoup_bits, q);
+  if (policy == kPolicyFp64) {
+    il.n1 = bits_of(balanced(il.n1));
+    il.n1w = bits_of(balanced(il.n1w));
+    il.n1p = il.n1wp = 0;
+  } else {
+    il.n1p = nt::multiply_factor(il.n1, shoup_bits, q);
+    il.n1wp = nt::multiply_factor(il.n1w, shoup_bits, q);
+  }
 
   DeviceScope scope(device);
   hipError_t e = scope.err;
-  if (e == hipSuccess) e = hipMalloc((void**)&p->d_fwd, n * sizeof(ulonglong2));
-  if (e == hipSuccess) e = hipMalloc((void**)&p->d_inv, n * sizeof(ulonglong2));
-  if (e == hipSuccess)
-    e = hipMemcpy(p->d_fwd, hf.data(), n * sizeof(ulonglong2), hipMemcpyHostToDevice);
-  if (e == hipSuccess)
-    e = hipMemcpy(p->d_inv, hi.data(), n * sizeof(ulonglong2), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->d_fwd, n * entry);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->d_inv, n * entry);
+  if (e == hipSuccess) e = hipMemcpy(p->d_fwd, hf.data(), n * entry, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p->d_inv, hi.data(), n * entry, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     if (p->d_fwd) (void)hipFree(p->d_fwd);
     if (p->d_inv) (void)hipFree(p->d_inv);
     delete p;
     return hip_fail(e, "uploading NTT tables");
   }
+  p->t.policy = policy;
   p->t.fwd = p->d_fwd;
   p->t.inv = p->d_inv;
   p->t.mod = make_mod_const(q);

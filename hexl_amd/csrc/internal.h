@@ -23,13 +23,24 @@ constexpr u64 kLazyModulusBound = 1ull << 56;
 // tables carry 32-bit Shoup factors.
 constexpr u64 kSmallModulusBound = 1ull << 30;
 
+// Moduli in [kSmallModulusBound, kFp64ModulusBound) use the Fp64 policy (exact integers in
+// doubles, one-word balanced twiddles).
+constexpr u64 kFp64ModulusBound = 1ull << 50;
+
+enum ArithPolicy : int { kPolicySmall = 0, kPolicyFp64 = 1, kPolicyLazy = 2, kPolicyStrict = 3 };
+int choose_policy(u64 q);  // ntt_kernels.hip
+
 // Device-resident state of one NTT plan.
 struct NttTables {
-  const ulonglong2* fwd;  // heap-ordered (R[n], floor(R[n] 2^s / q)), s = 63 (Lazy) or 64
-  const ulonglong2* inv;  // heap-ordered (R[n]^-1, precon)
+  // heap-ordered twiddles.  Integer policies: (R[n], floor(R[n] 2^s / q)) pairs, s = 32
+  // (Small), 63 (Lazy) or 64 (Strict).  Fp64: an array of doubles, R[n] balanced into
+  // (-q/2, q/2] (the pointer type is nominal).
+  const ulonglong2* fwd;
+  const ulonglong2* inv;  // the same for R[n]^-1
   ModConst mod;
   u32 log_n;
-  InvLast inv_last;
+  int policy;  // ArithPolicy the tables were built for
+  InvLast inv_last;  // Fp64: n1 / n1w hold the bit patterns of the balanced doubles
 };
 
 // Optional per-kernel timing (bench support): when a sink is active on the

@@ -123,13 +123,56 @@ __device__ __forceinline__ void store_global(u64* uniform_base, u32 byte_off, u6
 // Register subtrees
 // ---------------------------------------------------------------------------
 
+// A twiddle as it sits in the device table: (W, Shoup factor) for the integer
+// policies, ONE double (balanced W) for Fp64.
+template <class A>
+struct TwOf {
+  typedef ulonglong2 T;
+};
+template <>
+struct TwOf<Fp64> {
+  typedef double T;
+};
+template <class A>
+using TwT = typename TwOf<A>::T;
+
+template <class A>
+__device__ __forceinline__ void bf_fwd(u64& x, u64& y, const TwT<A>& w, const ModConst& m) {
+  if constexpr (A::kFp)
+    fwd_butterfly_fp(x, y, w, m);
+  else
+    fwd_butterfly<A>(x, y, w.x, w.y, m);
+}
+template <class A, bool BOUND>
+__device__ __forceinline__ void bf_inv(u64& x, u64& y, const TwT<A>& w, const ModConst& m, int k) {
+  if constexpr (A::kFp)
+    inv_butterfly_fp(x, y, w, m);
+  else
+    inv_butterfly<A, BOUND>(x, y, w.x, w.y, m, k);
+}
+template <class A>
+__device__ __forceinline__ void bf_inv_last(u64& x, u64& y, const InvLast& il, const ModConst& m,
+                                            int k) {
+  if constexpr (A::kFp)
+    inv_butterfly_last_fp(x, y, fp_bits_to_double(il.n1), fp_bits_to_double(il.n1w), m);
+  else
+    inv_butterfly_last<A>(x, y, il.n1, il.n1p, il.n1w, il.n1wp, m, k);
+}
+// Fp64: full reduction of all E elements (end of a run of stages); nothing otherwise.
+template <class A, int E>
+__device__ __forceinline__ void fp_bound_all(u64* x, const ModConst& m) {
+  if constexpr (A::kFp) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) x[e] = fp_bound<A>(x[e], m);
+  }
+}
+
 // The 2^R - 1 twiddles of the subtree rooted at heap node `node`, fetched
 // before the first butterfly so that their latencies overlap (left to itself
 // the compiler issues one load + one full wait per stage).  wv[2^v + g] is the
 // twiddle of group g at depth v.
-template <int R>
-__device__ __forceinline__ void load_twiddles(ulonglong2* wv, const ulonglong2* __restrict__ tw,
-                                              u32 node) {
+template <int R, class T>
+__device__ __forceinline__ void load_twiddles(T* wv, const T* __restrict__ tw, u32 node) {
 #pragma unroll
   for (int v = 0; v < R; ++v)
 #pragma unroll
@@ -138,16 +181,20 @@ __device__ __forceinline__ void load_twiddles(ulonglong2* wv, const ulonglong2* 
 
 // R forward stages on x[0 .. 2^R): stage v pairs elements 2^(R-1-v) apart.
 template <int R, class A>
-__device__ __forceinline__ void fwd_subtree(u64* x, const ulonglong2* wv, const ModConst& m) {
+__device__ __forceinline__ void fwd_subtree(u64* x, const TwT<A>* wv, const ModConst& m) {
+  static_assert(R <= kFpFwdRun, "Fp64 forward run too long");
 #pragma unroll
   for (int v = 0; v < R; ++v) {
     const int half = 1 << (R - 1 - v);
 #pragma unroll
     for (int g = 0; g < (1 << v); ++g) {
-      const ulonglong2 w = wv[(1 << v) + g];
+      const TwT<A> w = wv[(1 << v) + g];
 #pragma unroll
       for (int j = 0; j < half; ++j)
-        fwd_butterfly<A>(x[g * 2 * half + j], x[g * 2 * half + j + half], w.x, w.y, m);
+        bf_fwd<A>(x[g * 2 * half + j], x[g * 2 * half + j + half], w, m);
+      // Fp64, deep subtrees: keep the scheduler from interleaving every product of a
+      // stage (their temporaries would all be live at once and spill).
+      if (A::kFp && R >= 4) __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
@@ -179,8 +226,10 @@ struct InvLadder<R, (1 << R), A> {
 // restored at exit (not needed after LAST, whose outputs are both lazy
 // products).  A lazy run is at most 4 stages deep (8q * 2^4 must stay below
 // 2^63 for q < 2^56); a 5-stage subtree bounds the sums of its first stage.
+// Fp64: the sums double, so every kFpInvRun stages all elements are fully reduced,
+// and again at exit (not after LAST: the finish does it).
 template <int R, class A, bool LAST>
-__device__ __forceinline__ void inv_subtree(u64* x, const ulonglong2* wv, const ModConst& m,
+__device__ __forceinline__ void inv_subtree(u64* x, const TwT<A>* wv, const ModConst& m,
                                             const InvLast& il) {
   constexpr int kBounded = (A::kLazy && R > 4) ? R - 4 : 0;
   static_assert(R <= 5, "lazy inverse run too deep");
@@ -193,26 +242,25 @@ __device__ __forceinline__ void inv_subtree(u64* x, const ulonglong2* wv, const 
     for (int g = 0; g < (1 << v); ++g) {
       if (LAST && v == 0) {
 #pragma unroll
-        for (int j = 0; j < half; ++j)
-          inv_butterfly_last<A>(x[j], x[j + half], il.n1, il.n1p, il.n1w, il.n1wp, m, k);
+        for (int j = 0; j < half; ++j) bf_inv_last<A>(x[j], x[j + half], il, m, k);
       } else {
-        const ulonglong2 w = wv[(1 << v) + g];
+        const TwT<A> w = wv[(1 << v) + g];
 #pragma unroll
         for (int j = 0; j < half; ++j) {
           if (t < kBounded)
-            inv_butterfly<A, true>(x[g * 2 * half + j], x[g * 2 * half + j + half], w.x, w.y, m,
-                                   0);
+            bf_inv<A, true>(x[g * 2 * half + j], x[g * 2 * half + j + half], w, m, 0);
           else
-            inv_butterfly<A, false>(x[g * 2 * half + j], x[g * 2 * half + j + half], w.x, w.y, m,
-                                    k);
+            bf_inv<A, false>(x[g * 2 * half + j], x[g * 2 * half + j + half], w, m, k);
         }
       }
       // Deep subtrees: stop the scheduler from interleaving every butterfly of a
       // stage (it would keep all their temporaries live at once and spill).
       if (R >= 4) __builtin_amdgcn_sched_barrier(0);
     }
+    if (A::kFp && (t + 1) % kFpInvRun == 0 && v > 0) fp_bound_all<A, (1 << R)>(x, m);
   }
   if (A::kLazy && !LAST) InvLadder<R, 0, A>::run(x, m);
+  if (!LAST) fp_bound_all<A, (1 << R)>(x, m);
 }
 
 // One level of a subtree on its own, groups [G0, G1): used by the 5-stage strided
@@ -220,20 +268,23 @@ __device__ __forceinline__ void inv_subtree(u64* x, const ulonglong2* wv, const 
 // requested one batch ahead of its use) because all of them at once do not fit
 // the SGPR file.
 template <int R, int V, int G0, int G1, class A>
-__device__ __forceinline__ void fwd_level(u64* x, const ulonglong2* wl, const ModConst& m) {
+__device__ __forceinline__ void fwd_level(u64* x, const TwT<A>* wl, const ModConst& m) {
   constexpr int half = 1 << (R - 1 - V);
 #pragma unroll
-  for (int g = G0; g < G1; ++g)
+  for (int g = G0; g < G1; ++g) {
 #pragma unroll
-    for (int j = 0; j < half; ++j)
-      fwd_butterfly<A>(x[g * 2 * half + j], x[g * 2 * half + j + half], wl[g - G0].x, wl[g - G0].y,
-                       m);
+    for (int j = 0; j < half; ++j) {
+      bf_fwd<A>(x[g * 2 * half + j], x[g * 2 * half + j + half], wl[g - G0], m);
+      if (A::kFp && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // see fwd_subtree
+    }
+    if (A::kFp) __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 // Inverse level V at lazy depth K; BOUND as in inv_butterfly; LAST folds N^-1 in
 // (then V == 0).
 template <int R, int V, int G0, int G1, class A, bool BOUND, bool LAST>
-__device__ __forceinline__ void inv_level(u64* x, const ulonglong2* wl, const ModConst& m,
+__device__ __forceinline__ void inv_level(u64* x, const TwT<A>* wl, const ModConst& m,
                                           const InvLast& il, int k) {
   constexpr int half = 1 << (R - 1 - V);
 #pragma unroll
@@ -243,24 +294,23 @@ __device__ __forceinline__ void inv_level(u64* x, const ulonglong2* wl, const Mo
       u64& a = x[g * 2 * half + j];
       u64& b = x[g * 2 * half + j + half];
       if (LAST)
-        inv_butterfly_last<A>(a, b, il.n1, il.n1p, il.n1w, il.n1wp, m, k);
+        bf_inv_last<A>(a, b, il, m, k);
       else
-        inv_butterfly<A, BOUND>(a, b, wl[g - G0].x, wl[g - G0].y, m, k);
+        bf_inv<A, BOUND>(a, b, wl[g - G0], m, k);
     }
 }
 
-template <int COUNT>
-__device__ __forceinline__ void load_twiddle_run(ulonglong2* w, const ulonglong2* __restrict__ tw,
-                                                 u32 first) {
+template <int COUNT, class T>
+__device__ __forceinline__ void load_twiddle_run(T* w, const T* __restrict__ tw, u32 first) {
 #pragma unroll
   for (int i = 0; i < COUNT; ++i) w[i] = tw[first + i];
 }
 
 // The 5-stage subtrees of the strided pass, twiddles streamed (see fwd_level).
 template <class A>
-__device__ __forceinline__ void fwd_subtree5_streamed(u64* x, const ulonglong2* __restrict__ tw,
+__device__ __forceinline__ void fwd_subtree5_streamed(u64* x, const TwT<A>* __restrict__ tw,
                                                       u32 node, const ModConst& m) {
-  ulonglong2 w0, w1[2], w2[4], w3[8], w4a[8], w4b[8];
+  TwT<A> w0, w1[2], w2[4], w3[8], w4a[8], w4b[8];
   load_twiddle_run<1>(&w0, tw, node);
   load_twiddle_run<2>(w1, tw, node << 1);
   load_twiddle_run<4>(w2, tw, node << 2);
@@ -276,13 +326,14 @@ __device__ __forceinline__ void fwd_subtree5_streamed(u64* x, const ulonglong2* 
 }
 
 template <class A, bool LAST>
-__device__ __forceinline__ void inv_subtree5_streamed(u64* x, const ulonglong2* __restrict__ tw,
+__device__ __forceinline__ void inv_subtree5_streamed(u64* x, const TwT<A>* __restrict__ tw,
                                                       u32 node, const ModConst& m,
                                                       const InvLast& il) {
   // Lazy: the first stage bounds its sums (a lazy run is at most 4 stages deep),
-  // the remaining four run at depths 0..3.
+  // the remaining four run at depths 0..3.  Fp64: full reduction after the third
+  // stage and at exit.
   constexpr bool kB = A::kLazy;
-  ulonglong2 w0, w1[2], w2[4], w3[8], w4a[8], w4b[8];
+  TwT<A> w0, w1[2], w2[4], w3[8], w4a[8], w4b[8];
   load_twiddle_run<8>(w4a, tw, node << 4);
   load_twiddle_run<8>(w4b, tw, (node << 4) + 8);
   inv_level<5, 4, 0, 8, A, kB, false>(x, w4a, m, il, 0);
@@ -293,9 +344,11 @@ __device__ __forceinline__ void inv_subtree5_streamed(u64* x, const ulonglong2* 
   load_twiddle_run<1>(&w0, tw, node);
   inv_level<5, 3, 0, 8, A, false, false>(x, w3, m, il, 0);
   inv_level<5, 2, 0, 4, A, false, false>(x, w2, m, il, 1);
+  fp_bound_all<A, 32>(x, m);
   inv_level<5, 1, 0, 2, A, false, false>(x, w1, m, il, 2);
   inv_level<5, 0, 0, 1, A, false, LAST>(x, &w0, m, il, 3);
   if (A::kLazy && !LAST) InvLadder<5, 0, A>::run(x, m);
+  if (!LAST) fp_bound_all<A, 32>(x, m);
 }
 
 // ---------------------------------------------------------------------------
@@ -336,8 +389,9 @@ __device__ __forceinline__ void strided_body(u64* out, const u64* in,
   const u64 base = (b << log_n) + ((u64)h << (log_s + R)) + c0;
   const u64 vbase = base + lane;  // (SGPR base + 32-bit lane offset measured 3% slower here)
   const u32 node = (1u << a0) + h;
-  ulonglong2 wv[E];
-  if constexpr (R < 5) load_twiddles<R>(wv, tw, node);
+  const TwT<A>* __restrict__ twa = reinterpret_cast<const TwT<A>*>(tw);
+  TwT<A> wv[E];
+  if constexpr (R < 5) load_twiddles<R>(wv, twa, node);
 
   u64 x[E];
   // loads go out at raised priority (forward: 0.70 -> 0.68 ms; the inverse pass
@@ -348,15 +402,19 @@ __device__ __forceinline__ void strided_body(u64* out, const u64* in,
   if (FWD) __builtin_amdgcn_s_setprio(0);
   if (flags & kFirstPass) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) x[e] = to_internal<A>(x[e]);
+    for (int e = 0; e < E; ++e) x[e] = to_internal<A>(x[e], m);
   }
 
   if (FWD) {
     if constexpr (R < 5)
       fwd_subtree<R, A>(x, wv, m);
     else
-      fwd_subtree5_streamed<A>(x, tw, node, m);
-    if (finish) {
+      fwd_subtree5_streamed<A>(x, twa, node, m);
+    if constexpr (A::kFp) {
+      // every pass hands over fully reduced values; the last one canonical residues
+#pragma unroll
+      for (int e = 0; e < E; ++e) x[e] = fp_pass_end(fp_bits_to_double(x[e]), m, finish != 0);
+    } else if (finish) {
 #pragma unroll
       for (int e = 0; e < E; ++e) x[e] = fwd_finish<A>(x[e], m, finish == 2);
     }
@@ -364,7 +422,7 @@ __device__ __forceinline__ void strided_body(u64* out, const u64* in,
     if constexpr (R < 5)
       inv_subtree<R, A, LAST>(x, wv, m, il);
     else
-      inv_subtree5_streamed<A, LAST>(x, tw, node, m, il);
+      inv_subtree5_streamed<A, LAST>(x, twa, node, m, il);
     if (finish) {
 #pragma unroll
       for (int e = 0; e < E; ++e) x[e] = inv_finish<A>(x[e], m, finish == 2);
@@ -434,6 +492,21 @@ struct Rounds {
   // Forward executes rounds 0..NR-1, inverse NR-1..0.
   static constexpr bool pre_fwd(int j) { return j >= 1 && j < NR && !vec(j); }
   static constexpr bool pre_inv(int j) { return j >= 0 && j <= NR - 2 && !vec(j); }
+  // Fp64 forward: a pass starts from fully reduced values; all elements are reduced
+  // again after round j when running round j + 1 too would make the run longer than
+  // kFpFwdRun stages (modarith.h).  fwd_run(j) = stages since the last reduction at
+  // the end of round j.
+  static constexpr int fwd_run(int j) {
+    int c = 0;
+    for (int i = 0; i <= j; ++i) {
+      c += r(i);
+      if (i < j && c + r(i + 1) > kFpFwdRun) c = 0;
+    }
+    return c;
+  }
+  static constexpr bool fp_reduce_after(int j) {
+    return j + 1 < NR && fwd_run(j) + r(j + 1) > kFpFwdRun;
+  }
 };
 
 // Tile index of element e of virtual thread vt in a round with r stages whose
@@ -477,9 +550,9 @@ __device__ __forceinline__ u64 tile_uniform_offset(const TileGeom& g, u32 dp) {
 // Twiddles of round j for every sub-run this thread owns in that round, all
 // requested before the round's first butterfly.  Wave-uniform twiddles (gap >= 64)
 // come through scalar loads (no VGPR cost), the others through per-lane loads.
-template <int S, int CB, int TL, int j>
-__device__ __forceinline__ void round_twiddles(ulonglong2* wv, const ulonglong2* __restrict__ tw,
-                                               u32 tid, const TileGeom& g) {
+template <int S, int CB, int TL, int j, class T>
+__device__ __forceinline__ void round_twiddles(T* wv, const T* __restrict__ tw, u32 tid,
+                                               const TileGeom& g) {
   using RD = Rounds<S, CB>;
   constexpr int r = RD::r(j), w = RD::w(j), u = RD::u(j);
   constexpr int SS = kE >> r;
@@ -497,12 +570,12 @@ __device__ __forceinline__ void round_twiddles(ulonglong2* wv, const ulonglong2*
 }
 
 template <int S, int CB, int j, class A, bool FWD, bool LAST>
-__device__ __forceinline__ void round_compute(u64* x, const ulonglong2* wv, const ModConst& m,
+__device__ __forceinline__ void round_compute(u64* x, const TwT<A>* wv, const ModConst& m,
                                               const InvLast& il) {
   constexpr int r = Rounds<S, CB>::r(j);
   constexpr int SS = kE >> r;
 #ifdef HX_EXP_NOCOMPUTE  // developer experiment: data movement only
-  x[0] += wv[1].x;
+  if constexpr (!A::kFp) x[0] += wv[1].x;
   return;
 #endif
 #pragma unroll
@@ -512,6 +585,7 @@ __device__ __forceinline__ void round_compute(u64* x, const ulonglong2* wv, cons
     else
       inv_subtree<r, A, LAST>(x + (s << r), wv + (s << r), m, il);
   }
+  if (FWD && Rounds<S, CB>::fp_reduce_after(j)) fp_bound_all<A, kE>(x, m);
 }
 
 // LDS byte address of a slot.  lds_slot is linear over XOR and the fields of a
@@ -567,13 +641,13 @@ __device__ __forceinline__ void handover() {
 // forward rounds J .. NR-1: LDS -> registers -> subtree -> same LDS slots.
 // `pre` holds the twiddles of round J when Rounds::pre_fwd(J).
 template <int S, int CB, int TL, int J, class A>
-__device__ __forceinline__ void fwd_mid_rounds(u64* x, u64* lds, const ulonglong2* tw, u32 tid,
+__device__ __forceinline__ void fwd_mid_rounds(u64* x, u64* lds, const TwT<A>* tw, u32 tid,
                                                const TileGeom& g, const ModConst& m,
-                                               const InvLast& il, const ulonglong2* pre) {
+                                               const InvLast& il, const TwT<A>* pre) {
   using RD = Rounds<S, CB>;
   if constexpr (J < RD::NR) {
-    ulonglong2 wv[kE], wn[kE];
-    const ulonglong2* w = pre;
+    TwT<A> wv[kE], wn[kE];
+    const TwT<A>* w = pre;
     if constexpr (!RD::pre_fwd(J)) {
       round_twiddles<S, CB, TL, J>(wv, tw, tid, g);
       w = wv;
@@ -592,14 +666,14 @@ __device__ __forceinline__ void fwd_mid_rounds(u64* x, u64* lds, const ulonglong
 // J == NR-1 or Rounds::pre_inv(J); `pre0` receives those of round 0 when
 // Rounds::pre_inv(0).
 template <int S, int CB, int TL, int J, class A>
-__device__ __forceinline__ void inv_mid_rounds(u64* x, u64* lds, const ulonglong2* tw, u32 tid,
+__device__ __forceinline__ void inv_mid_rounds(u64* x, u64* lds, const TwT<A>* tw, u32 tid,
                                                const TileGeom& g, const ModConst& m,
-                                               const InvLast& il, const ulonglong2* pre,
-                                               ulonglong2* pre0) {
+                                               const InvLast& il, const TwT<A>* pre,
+                                               TwT<A>* pre0) {
   using RD = Rounds<S, CB>;
   if constexpr (J >= 1) {
-    ulonglong2 wv[kE], wn[kE];
-    const ulonglong2* w = pre;
+    TwT<A> wv[kE], wn[kE];
+    const TwT<A>* w = pre;
     if constexpr (J != RD::NR - 1 && !RD::pre_inv(J)) {
       round_twiddles<S, CB, TL, J>(wv, tw, tid, g);
       w = wv;
@@ -656,8 +730,8 @@ __device__ __forceinline__ constexpr u32 xfer_dp(int i) {
 // GUARD: the batch may end inside the tile (only possible for CB == 0 and a batch
 // smaller than / not a multiple of the tile); otherwise every access is in range.
 template <bool ROUND0, int S, int CB, int TL, bool GUARD, class A, int LDK>
-__device__ __forceinline__ void fetch_tile(u64* x, const u64* in, u32 tid,
-                                           const TileGeom& g, u64 total, bool first) {
+__device__ __forceinline__ void fetch_tile(u64* x, const u64* in, u32 tid, const TileGeom& g,
+                                           u64 total, bool first, const ModConst& m) {
 #pragma unroll
   for (int i = 0; i < kE; ++i) {
     const u32 p0 = xfer_p0<ROUND0, S, CB, TL>(tid, i);
@@ -674,7 +748,7 @@ __device__ __forceinline__ void fetch_tile(u64* x, const u64* in, u32 tid,
   }
   if (first) {
 #pragma unroll
-    for (int i = 0; i < kE; ++i) x[i] = to_internal<A>(x[i]);
+    for (int i = 0; i < kE; ++i) x[i] = to_internal<A>(x[i], m);
   }
 }
 
@@ -713,11 +787,12 @@ constexpr int min_waves() { return (S >= 10 || CB > 0) ? 8 : 6; }
 // pointers are not __restrict__: transforms run in place (out == in).
 template <bool FWD, int S, int CB, int TL, bool GUARD, class A, bool LAST, int LDK, int STK>
 __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
-                                          const ulonglong2* __restrict__ tw, const ModConst& m,
+                                          const ulonglong2* __restrict__ tw_raw, const ModConst& m,
                                           u32 log_n, u32 flags, u64 total, const InvLast& il,
                                           u32 bid) {
   using RD = Rounds<S, CB>;
   constexpr int NR = RD::NR;
+  const TwT<A>* __restrict__ tw = reinterpret_cast<const TwT<A>*>(tw_raw);
   const u32 finish = flags & kFinishMask;
   const bool first = (flags & kFirstPass) != 0;
   const u32 tid = threadIdx.x;
@@ -731,11 +806,11 @@ __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
   HX_STAMP(0);
 
   if (FWD) {
-    ulonglong2 wn[kE];  // twiddles of round 1 when requested ahead
+    TwT<A> wn[kE];  // twiddles of round 1 when requested ahead
     {  // round 0 straight from global memory; its twiddles are requested first
-      ulonglong2 wv[kE];
+      TwT<A> wv[kE];
       round_twiddles<S, CB, TL, 0>(wv, tw, tid, g);
-      fetch_tile<true, S, CB, TL, GUARD, A, LDK>(x, in, tid, g, total, first);  // round-0 set
+      fetch_tile<true, S, CB, TL, GUARD, A, LDK>(x, in, tid, g, total, first, m);  // round-0 set
       __builtin_amdgcn_s_setprio(0);
       if constexpr (RD::pre_fwd(1)) round_twiddles<S, CB, TL, 1>(wn, tw, tid, g);
       HX_PROFILE_WAIT_VMEM();
@@ -754,7 +829,10 @@ __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
 #pragma unroll
       for (int i = 0; i < kE; ++i) {
         u64 v = lds_at(lds, a0 ^ (lds_slot(xfer_dp<false, S, CB>(i)) << 3));
-        if (finish) v = fwd_finish<A>(v, m, finish == 2);
+        if (finish)
+          v = fwd_finish<A>(v, m, finish == 2);
+        else
+          v = fp_bound<A>(v, m);  // Fp64: every pass hands over fully reduced values
         store_elem<false, S, CB, TL, GUARD, STK>(out, tid, i, v, g, total);
       }
     }
@@ -764,9 +842,9 @@ __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
   } else {
     // copy-in of the run this wave owns in the deepest round; the twiddles of that
     // round are requested first
-    ulonglong2 wtop[kE], w0[kE];
+    TwT<A> wtop[kE], w0[kE];
     if constexpr (NR > 1) round_twiddles<S, CB, TL, NR - 1>(wtop, tw, tid, g);
-    fetch_tile<false, S, CB, TL, GUARD, A, LDK>(x, in, tid, g, total, first);
+    fetch_tile<false, S, CB, TL, GUARD, A, LDK>(x, in, tid, g, total, first, m);
     __builtin_amdgcn_s_setprio(0);
     {
       const u32 a0 = lds_slot(xfer_p0<false, S, CB, TL>(tid, 0)) << 3;
@@ -1197,7 +1275,7 @@ static u32 env_u32(const char* name, u32 dflt) {
 // Process-wide tuning state: defaults from the environment, changeable at run time
 // through hexl_amd_set_tuning (tests compare the plans in one process).
 struct Tuning {
-  std::atomic<u32> plan, fused_window, fused_min_batch, fused_wg_per_cu;
+  std::atomic<u32> plan, fused_window, fused_min_batch, fused_wg_per_cu, fp64;
   Tuning() {
     const char* e = getenv("HEXL_AMD_PLAN");
     plan = (e && strcmp(e, "tiled") == 0) ? kPlanTiled : (e && strcmp(e, "fused") == 0) ? kPlanFused
@@ -1208,6 +1286,8 @@ struct Tuning {
     fused_window = env_u32("HEXL_AMD_FUSED_WINDOW", 10);
     fused_min_batch = env_u32("HEXL_AMD_FUSED_MIN_BATCH", 64);
     fused_wg_per_cu = env_u32("HEXL_AMD_FUSED_WG_PER_CU", 0);
+    const char* f = getenv("HEXL_AMD_FP64");
+    fp64 = (f && f[0] == '0') ? 0 : 1;
   }
 };
 static Tuning& tuning() {
@@ -1220,6 +1300,7 @@ int set_tuning(const char* key, u64 value) {
   else if (strcmp(key, "fused_window") == 0 && value < (1u << 16)) t.fused_window = (u32)value;
   else if (strcmp(key, "fused_min_batch") == 0 && value >= 1) t.fused_min_batch = (u32)value;
   else if (strcmp(key, "fused_wg_per_cu") == 0) t.fused_wg_per_cu = (u32)value;
+  else if (strcmp(key, "fp64") == 0 && value <= 1) t.fp64 = (u32)value;
   else return -1;
   return 0;
 }
@@ -1423,21 +1504,33 @@ static hipError_t transform_impl(const NttTables& t, u64* result, const u64* ope
 hipError_t ntt_forward_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
                               u64 out_mf, hipStream_t st) {
   if (batch == 0) return hipSuccess;
-  if (t.mod.q < kSmallModulusBound)
-    return transform_impl<true, Small>(t, result, operand, batch, out_mf, st);
-  if (t.mod.q < kLazyModulusBound)
-    return transform_impl<true, Lazy>(t, result, operand, batch, out_mf, st);
-  return transform_impl<true, Strict>(t, result, operand, batch, out_mf, st);
+  switch (t.policy) {
+    case kPolicySmall: return transform_impl<true, Small>(t, result, operand, batch, out_mf, st);
+    case kPolicyFp64: return transform_impl<true, Fp64>(t, result, operand, batch, out_mf, st);
+    case kPolicyLazy: return transform_impl<true, Lazy>(t, result, operand, batch, out_mf, st);
+    default: return transform_impl<true, Strict>(t, result, operand, batch, out_mf, st);
+  }
 }
 
 hipError_t ntt_inverse_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
                               u64 out_mf, hipStream_t st) {
   if (batch == 0) return hipSuccess;
-  if (t.mod.q < kSmallModulusBound)
-    return transform_impl<false, Small>(t, result, operand, batch, out_mf, st);
-  if (t.mod.q < kLazyModulusBound)
-    return transform_impl<false, Lazy>(t, result, operand, batch, out_mf, st);
-  return transform_impl<false, Strict>(t, result, operand, batch, out_mf, st);
+  switch (t.policy) {
+    case kPolicySmall: return transform_impl<false, Small>(t, result, operand, batch, out_mf, st);
+    case kPolicyFp64: return transform_impl<false, Fp64>(t, result, operand, batch, out_mf, st);
+    case kPolicyLazy: return transform_impl<false, Lazy>(t, result, operand, batch, out_mf, st);
+    default: return transform_impl<false, Strict>(t, result, operand, batch, out_mf, st);
+  }
+}
+
+// The arithmetic policy a plan for modulus q is built for (its tables depend on it).
+// HEXL_AMD_FP64=0 (or set_tuning("fp64", 0) before the plan is created) keeps 31..50-bit
+// moduli on the integer Lazy policy (A/B runs).
+int choose_policy(u64 q) {
+  if (q < kSmallModulusBound) return kPolicySmall;
+  if (q < kFp64ModulusBound && tuning().fp64.load()) return kPolicyFp64;
+  if (q < kLazyModulusBound) return kPolicyLazy;
+  return kPolicyStrict;
 }
 
 }  // namespace hexl_amd

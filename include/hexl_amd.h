@@ -311,7 +311,10 @@ int hexl_amd_profile_get(int i, const char** name, float* ms);
  *                      LDS-tiled launches)
  *   "fused_window"     polynomials one XCD keeps in flight (>= 1)
  *   "fused_min_batch"  smallest batch the fused launch is used for (>= 1)
- *   "fused_wg_per_cu"  persistent workgroups per CU (0 = occupancy query) */
+ *   "fused_wg_per_cu"  persistent workgroups per CU (0 = occupancy query)
+ *   "fp64"             1 (default) = plans for 2^30 <= q < 2^50 use the Fp64 arithmetic
+ *                      policy (exact integers in doubles), 0 = the integer Lazy policy;
+ *                      read when a plan is created */
 int hexl_amd_set_tuning(const char* key, uint64_t value);
 
 #ifdef __cplusplus

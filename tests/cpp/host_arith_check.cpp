@@ -71,7 +71,7 @@ static void check(u64 n, u64 q, const std::vector<int>& inv_runs, u64 in_mf_f, u
     in[1] = 0;
     in[n - 1] = in_mf_f * q - 1;
     ho_ntt_forward_radix2(ref.data(), in.data(), n, q, R.data(), Rp.data(), in_mf_f, 1);
-    for (u64 i = 0; i < n; ++i) x[i] = to_internal<A>(in[i]);
+    for (u64 i = 0; i < n; ++i) x[i] = to_internal<A>(in[i], m);
     for (int s = 0; s < L; ++s) {
       const u64 mgroups = 1ull << s, t = n >> (s + 1);
       for (u64 i = 0; i < mgroups; ++i)
@@ -103,7 +103,7 @@ static void check(u64 n, u64 q, const std::vector<int>& inv_runs, u64 in_mf_f, u
     in[2] = 0;
     ho_ntt_inverse_radix2(ref.data(), in.data(), n, q, Ri_stage.data(), Rip_stage.data(), in_mf_i,
                           1);
-    for (u64 i = 0; i < n; ++i) x[i] = to_internal<A>(in[i]);
+    for (u64 i = 0; i < n; ++i) x[i] = to_internal<A>(in[i], m);
     std::vector<int> depth(n, 0);  // lazy stages since the element was last bounded
     const u64 n1 = ho_inverse_mod(n, q), n1w = ho_multiply_mod(n1, V[1], q);
     const u64 n1p = ho_multiply_factor(n1, shoup, q), n1wp = ho_multiply_factor(n1w, shoup, q);
@@ -159,6 +159,137 @@ static void check(u64 n, u64 q, const std::vector<int>& inv_runs, u64 in_mf_f, u
       else
         EXPECT(r < 2 * q && r % q == ref[i], "inv lazy mismatch at %llu", (unsigned long long)i);
     }
+  }
+}
+
+// Fp64 policy (2^30 <= q < 2^50): exact integers in doubles, balanced twiddles.  The
+// forward network is cut into runs of <= kFpFwdRun stages and the inverse into runs of
+// <= kFpInvRun, every element fully reduced at each run end -- as the kernels do.  Checks
+// every intermediate against 2^53 and against the bound the analysis in modarith.h
+// promises, and the outputs against the oracle bit for bit.
+#include <cmath>
+static void check_fp(u64 n, u64 q, const std::vector<int>& fwd_runs,
+                     const std::vector<int>& inv_runs, u64 in_mf_f, u64 in_mf_i) {
+  int L = 0;
+  while ((1ull << L) < n) ++L;
+  std::vector<u64> R(n), Rp(n), Ri_stage(n), Rip_stage(n);
+  ho_ntt_tables(n, q, ho_minimal_primitive_root(2 * n, q), R.data(), Rp.data(), Ri_stage.data(),
+                Rip_stage.data());
+  auto balanced = [q](u64 w) { return w > q / 2 ? -(double)(q - w) : (double)w; };
+  std::vector<double> W(n), V(n);
+  for (u64 i = 1; i < n; ++i) {
+    W[i] = balanced(R[i]);
+    V[i] = balanced(ho_inverse_mod(R[i], q));
+  }
+  const ModConst m = make_mod_const(q);
+  ++g_cases;
+  const double two53 = 9007199254740992.0, qd = (double)q;
+  std::vector<u64> in(n), ref(n), x(n);
+  // ---------------- forward
+  for (auto& v : in) v = rnd() % (in_mf_f * q);
+  in[0] = in_mf_f * q - 1;
+  in[1] = 0;
+  in[n - 1] = in_mf_f * q - 1;
+  ho_ntt_forward_radix2(ref.data(), in.data(), n, q, R.data(), Rp.data(), in_mf_f, 1);
+  for (u64 i = 0; i < n; ++i) {
+    x[i] = to_internal<Fp64>(in[i], m);
+    EXPECT(std::fabs(fp_bits_to_double(x[i])) <= 0.5000001 * qd, "fp entry bound");
+  }
+  int s = 0;
+  for (size_t ri = 0; ri < fwd_runs.size() && s < L; ++ri) {
+    double bound = 0.5000001;  // in units of q
+    for (int tt = 0; tt < fwd_runs[ri] && s < L; ++tt, ++s) {
+      EXPECT(tt < kFpFwdRun, "forward run longer than kFpFwdRun");
+      bound = 1.1875 * bound + 0.5;
+      const u64 mgroups = 1ull << s, t = n >> (s + 1);
+      for (u64 i = 0; i < mgroups; ++i)
+        for (u64 j = 0; j < t; ++j) {
+          u64& a = x[2 * i * t + j];
+          u64& b = x[2 * i * t + j + t];
+          fwd_butterfly_fp(a, b, W[mgroups + i], m);
+          const double av = std::fabs(fp_bits_to_double(a)), bv = std::fabs(fp_bits_to_double(b));
+          EXPECT(av < two53 && bv < two53, "fp fwd 2^53: stage %d", s);
+          EXPECT(av <= bound * qd && bv <= bound * qd, "fp fwd bound: stage %d run pos %d", s, tt);
+        }
+    }
+    if (s < L)
+      for (u64 i = 0; i < n; ++i) x[i] = fp_bound<Fp64>(x[i], m);
+  }
+  EXPECT(s == L, "forward runs do not cover the network");
+  for (u64 i = 0; i < n; ++i) {
+    EXPECT(fwd_finish<Fp64>(x[i], m, true) == ref[i], "fp fwd mismatch at %llu",
+           (unsigned long long)i);
+    EXPECT(fp_pass_end(fp_bits_to_double(x[i]), m, true) == ref[i], "fp pass end (canonical)");
+    const double r = fp_bits_to_double(fp_pass_end(fp_bits_to_double(x[i]), m, false));
+    EXPECT(std::fabs(r) <= 0.5000001 * qd, "fp pass end (reduced)");
+  }
+  // ---------------- inverse
+  for (auto& v : in) v = rnd() % (in_mf_i * q);
+  in[0] = in_mf_i * q - 1;
+  in[1] = in_mf_i * q - 1;
+  in[2] = 0;
+  ho_ntt_inverse_radix2(ref.data(), in.data(), n, q, Ri_stage.data(), Rip_stage.data(), in_mf_i, 1);
+  for (u64 i = 0; i < n; ++i) x[i] = to_internal<Fp64>(in[i], m);
+  const u64 n1 = ho_inverse_mod(n, q);
+  const double n1d = balanced(n1), n1wd = balanced(ho_multiply_mod(n1, ho_inverse_mod(R[1], q), q));
+  int stage = L - 1;
+  for (size_t ri = 0; ri < inv_runs.size() && stage >= 0; ++ri) {
+    for (int tt = 0; tt < inv_runs[ri] && stage >= 0; ++tt, --stage) {
+      EXPECT(tt < kFpInvRun, "inverse run longer than kFpInvRun");
+      const u64 mgroups = 1ull << stage, t = n >> (stage + 1);
+      for (u64 i = 0; i < mgroups; ++i)
+        for (u64 j = 0; j < t; ++j) {
+          const u64 ia = 2 * i * t + j, ib = ia + t;
+          if (stage == 0)
+            inv_butterfly_last_fp(x[ia], x[ib], n1d, n1wd, m);
+          else
+            inv_butterfly_fp(x[ia], x[ib], V[mgroups + i], m);
+          const double av = std::fabs(fp_bits_to_double(x[ia])),
+                       bv = std::fabs(fp_bits_to_double(x[ib]));
+          EXPECT(av <= 4.0001 * qd && bv <= 4.0001 * qd, "fp inv bound: stage %d", stage);
+        }
+    }
+    if (stage >= 0)
+      for (u64 i = 0; i < n; ++i) x[i] = fp_bound<Fp64>(x[i], m);
+  }
+  EXPECT(stage == -1, "inverse runs do not cover the network");
+  for (u64 i = 0; i < n; ++i)
+    EXPECT(inv_finish<Fp64>(x[i], m, true) == ref[i], "fp inv mismatch at %llu",
+           (unsigned long long)i);
+}
+
+// The Fp64 product and reductions on their own at the edges of their domain.
+static void check_fp_product(u64 q) {
+  const ModConst m = make_mod_const(q);
+  const double qd = (double)q;
+  for (int it = 0; it < 400000; ++it) {
+    // |y| up to just below 8q (the largest input a kFpFwdRun-stage run feeds a product)
+    u64 mag;
+    switch (it & 7) {
+      case 0: mag = 8 * q - 1 - rnd() % 8; break;
+      case 1: mag = rnd() % 8; break;
+      case 2: mag = (rnd() % 8) * q + (rnd() % 4); break;
+      case 3: mag = (1 + rnd() % 8) * q - 1 - (rnd() % 4); break;
+      default: mag = rnd() % (8 * q); break;
+    }
+    const bool neg = (it >> 3) & 1;
+    u64 W;
+    switch ((it >> 4) & 3) {
+      case 0: W = q - 1 - rnd() % 4; break;
+      case 1: W = 1 + rnd() % 4; break;
+      case 2: W = q / 2 + (rnd() % 5) - 2; break;
+      default: W = rnd() % q; break;
+    }
+    const double Wb = W > q / 2 ? -(double)(q - W) : (double)W;
+    const double y = neg ? -(double)mag : (double)mag;
+    const double t = fp_mul(y, Wb, m);
+    // exact residue: (+-mag) * W mod q
+    u64 want = (u64)(((unsigned __int128)(mag % q) * W) % q);
+    if (neg && want) want = q - want;
+    EXPECT(t == std::floor(t) && std::fabs(t) <= (0.5 + 0.1875 * 8) * qd, "fp product range");
+    EXPECT(fp_canonical(t, m) == want, "fp product residue");
+    EXPECT(fp_canonical(y, m) == (neg && mag % q ? q - mag % q : mag % q), "fp canonical");
+    if (mag < (1ull << 52)) EXPECT(fp_from_u64(mag) == (double)mag, "fp_from_u64");
   }
 }
 
@@ -258,6 +389,30 @@ int main() {
     for (size_t pi = 0; pi < got; ++pi) check<Strict>(4096, primes[pi], run_sets[0], 4, 2);
     const size_t got2 = ho_generate_primes(primes, 1, 61, 1, 4096);
     for (size_t pi = 0; pi < got2; ++pi) check<Strict>(4096, primes[pi], run_sets[0], 4, 2);
+  }
+  // Fp64 policy: moduli from 2^30 up to just below 2^50, including the survey's 50-bit
+  // prime of BASELINE configs[1]; run layouts of the kernels (tile rounds 2|3|3|3 with one
+  // mid-pass reduction, strided 4 / 5, the longest legal runs)
+  {
+    // (runs past the end of a network are ignored)
+    const std::vector<std::vector<int>> fwd_sets = {{5, 5, 6, 7}, {4, 5, 6, 5}, {7, 7, 6}, {3, 3, 3, 3, 3, 3, 3},
+                                                    {5, 7, 5, 3}, {1, 7, 7, 5}};
+    const std::vector<std::vector<int>> inv_sets = {{3, 3, 3, 3, 3, 3, 2}, {2, 3, 3, 3, 3, 3, 3},
+                                                    {3, 3, 3, 3, 3, 2, 3}, {1, 3, 3, 3, 3, 3, 3, 1}};
+    const Case fp_cases[] = {{16, 30}, {1024, 35}, {4096, 49}, {4096, 45}, {65536, 49}, {131072, 49}};
+    for (const Case& c : fp_cases) {
+      size_t got = ho_generate_primes(primes, 2, c.bits, 1, c.n);
+      got += ho_generate_primes(primes + got, 2, c.bits, 0, c.n);  // walking down from 2^(bits+1)
+      for (size_t pi = 0; pi < got; ++pi) {
+        check_fp_product(primes[pi]);
+        for (size_t k = 0; k < fwd_sets.size(); ++k) {
+          check_fp(c.n, primes[pi], fwd_sets[k], inv_sets[k % inv_sets.size()], 4, 2);
+          check_fp(c.n, primes[pi], fwd_sets[k], inv_sets[(k + 1) % inv_sets.size()], 1, 1);
+        }
+      }
+    }
+    check_fp_product(562949954093057ull);
+    check_fp(4096, 562949954093057ull, {3, 3, 6}, {3, 3, 3, 3}, 1, 1);
   }
   if (g_fail) {
     fprintf(stderr, "host_arith_check: %d failures\n", g_fail);

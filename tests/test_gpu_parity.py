@@ -348,13 +348,17 @@ def test_ntt_config4_full_size_one_gpu(hx, ho):
 
 @pytest.mark.parametrize("n,bits,small_end", [(1 << 20, 55, False), (1 << 20, 29, False),
                                              (1 << 16, 29, False), (1 << 16, 30, True),
+                                             (1 << 16, 49, False), (1 << 20, 49, False),
+                                             (1 << 12, 49, False), (1 << 16, 50, True),
                                              (1 << 16, 55, False), (1 << 16, 56, True),
                                              (1 << 17, 61, False), (1 << 20, 61, False)])
 def test_ntt_policy_boundaries(hx, ho, n, bits, small_end):
-    """Moduli at the edges of the three arithmetic policies: just below 2^30 (Small) and
-    just above it (Lazy), just below 2^56 (Lazy: with input_mod_factor 4 at N = 2^20 the
-    doubled values reach (8 + 6*20) q = 128 q, just under 2^63) and just above it (Strict),
-    just below 2^62 (the largest moduli the API admits).  All (in, out) factors."""
+    """Moduli at the edges of the four arithmetic policies: just below 2^30 (Small) and
+    just above it (Fp64), just below 2^50 (Fp64: exact integers in doubles, 7-stage
+    forward runs reach 7.9 q < 2^53) and just above it (Lazy), just below 2^56 (Lazy:
+    with input_mod_factor 4 at N = 2^20 the doubled values reach (8 + 6*20) q = 128 q,
+    just under 2^63) and just above it (Strict), just below 2^62 (the largest moduli the
+    API admits).  All (in, out) factors."""
     q = ho.generate_primes(1, bits, small_end, n)[0]
     lo, hi = 1 << bits, 1 << (bits + 1)
     assert lo < q < hi and ((q - lo) < (hi - lo) // 8 if small_end else (hi - q) < (hi - lo) // 8)
@@ -382,8 +386,40 @@ def test_ntt_policy_boundaries(hx, ho, n, bits, small_end):
             assert (got == ref).all()
 
 
+@pytest.mark.parametrize("n,batch", [(4096, 256), (65536, 64), (1 << 17, 3), (1 << 13, 5)])
+def test_ntt_fp64_policy_matches_integer_policy(hx, n, batch):
+    """q < 2^50 (the reference's IFMA / FP64-class moduli): the Fp64 arithmetic policy
+    (doubles, balanced twiddles) against the integer Lazy policy on the same inputs, bit
+    for bit -- plans built with the policy switched on and off."""
+    import torch
+    q = 562949954093057 if n == 4096 else hx.GeneratePrimes(1, 49, False, n)[0]
+    try:
+        hx.set_tuning("fp64", 0)
+        lazy = hx.NTT(n, q)
+        hx.set_tuning("fp64", 1)
+        fp = hx.NTT(n, q)
+    finally:
+        hx.set_tuning("fp64", 1)
+    for in_mf in (1, 4):
+        x = torch.empty((batch, n), dtype=torch.int64, device="cuda")
+        hx.fill_splitmix(x, n, batch, 77, in_mf * q)
+        a, b = torch.empty_like(x), torch.empty_like(x)
+        lazy.ComputeForward(a, x, in_mf, 1)
+        fp.ComputeForward(b, x, in_mf, 1)
+        assert torch.equal(a, b)
+        fp.ComputeForward(b, x, in_mf, 4)
+        assert int(b.min()) >= 0 and int(b.max()) < 4 * q and torch.equal(b % q, a)
+    for in_mf in (1, 2):
+        hx.fill_splitmix(x, n, batch, 78, in_mf * q)
+        lazy.ComputeInverse(a, x, in_mf, 1)
+        fp.ComputeInverse(b, x, in_mf, 1)
+        assert torch.equal(a, b)
+        fp.ComputeInverse(x, x, in_mf, 2)  # in place, lazy output range
+        assert int(x.min()) >= 0 and int(x.max()) < 2 * q and torch.equal(x % q, a)
+
+
 @pytest.mark.parametrize("logn", [15, 16])
-@pytest.mark.parametrize("bits", [28, 54, 60])
+@pytest.mark.parametrize("bits", [28, 45, 54, 60])
 def test_ntt_fused_plan_matches_split_plan(hx, logn, bits):
     """The one-launch plan (fused_pass: persistent workgroups, per-XCD tickets, the
     intermediate handed from the strided phase to the tile phase through the XCD's L2)

@@ -113,6 +113,7 @@ struct hexl_amd_ntt {
   mutable std::once_flag once[7];
   ulonglong2* d_fwd = nullptr;
   ulonglong2* d_inv = nullptr;
+  PlanDev* d_self = nullptr;  // device copy of the kernel parameters (multi-plan launches)
   NttTables t{};
 };
 
@@ -258,6 +259,19 @@ int hexl_amd_ntt_create(hexl_amd_ntt** out, uint64_t degree, uint64_t modulus,
   p->t.mod = make_mod_const(q);
   p->t.log_n = p->log_n;
   p->t.inv_last = il;
+  {
+    PlanDev pd{p->d_fwd, p->d_inv, p->t.mod, il};
+    e = hipMalloc((void**)&p->d_self, sizeof(PlanDev));
+    if (e == hipSuccess) e = hipMemcpy(p->d_self, &pd, sizeof pd, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      (void)hipFree(p->d_fwd);
+      (void)hipFree(p->d_inv);
+      if (p->d_self) (void)hipFree(p->d_self);
+      delete p;
+      return hip_fail(e, "uploading NTT plan parameters");
+    }
+    p->t.dev = p->d_self;
+  }
   *out = p;
   return HEXL_AMD_OK;
 }
@@ -268,6 +282,7 @@ int hexl_amd_ntt_destroy(hexl_amd_ntt* p) {
     DeviceScope scope(p->device);
     if (p->d_fwd) (void)hipFree(p->d_fwd);
     if (p->d_inv) (void)hipFree(p->d_inv);
+    if (p->d_self) (void)hipFree(p->d_self);
   }
   delete p;
   return HEXL_AMD_OK;
@@ -352,6 +367,33 @@ static int ntt_run_rns(const hexl_amd_ntt* const* plans, uint64_t num_plans, uin
                                (unsigned long long)k);
     if (plans[k]->n != plans[0]->n || plans[k]->device != plans[0]->device)
       return fail(HEXL_AMD_ERR_INVALID_ARG, "plans must share degree and device");
+  }
+  if (num_plans == 0 || batch_per_plan == 0) return HEXL_AMD_OK;
+  if (int rc = check_ntt_args(plans[0], result, operand, forward, in_mf, out_mf)) return rc;
+  // One launch sequence over all moduli where the shapes allow it (degree >= 4096,
+  // one arithmetic policy), in groups of kMaxMultiPlans; otherwise plan by plan.
+  {
+    DeviceScope scope(plans[0]->device);
+    if (scope.err != hipSuccess) return hip_fail(scope.err, "hipSetDevice");
+    bool multi_ok = num_plans > 1;
+    uint64_t k = 0;
+    while (multi_ok && k < num_plans) {
+      const uint64_t cnt = num_plans - k < (uint64_t)kMaxMultiPlans ? num_plans - k
+                                                                     : (uint64_t)kMaxMultiPlans;
+      const NttTables* tabs[kMaxMultiPlans];
+      for (uint64_t j = 0; j < cnt; ++j) tabs[j] = &plans[k + j]->t;
+      const uint64_t off = k * batch_per_plan * plans[0]->n;
+      hipError_t e = ntt_multi_launch(forward, tabs, (u32)cnt, batch_per_plan, result + off,
+                                      operand + off, out_mf, (hipStream_t)stream);
+      if (e == hipErrorNotSupported) {
+        if (k != 0) return hip_fail(e, "multi-plan NTT launch");  // cannot happen: same shapes
+        multi_ok = false;
+        break;
+      }
+      if (e != hipSuccess) return hip_fail(e, "multi-plan NTT launch");
+      k += cnt;
+    }
+    if (multi_ok) return HEXL_AMD_OK;
   }
   for (uint64_t k = 0; k < num_plans; ++k) {
     const uint64_t off = k * batch_per_plan * plans[k]->n;

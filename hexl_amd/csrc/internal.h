@@ -41,6 +41,7 @@ struct NttTables {
   u32 log_n;
   int policy;  // ArithPolicy the tables were built for
   InvLast inv_last;  // Fp64: n1 / n1w hold the bit patterns of the balanced doubles
+  const struct PlanDev* dev;  // device copy of (fwd, inv, mod, inv_last)
 };
 
 // Optional per-kernel timing (bench support): when a sink is active on the
@@ -72,6 +73,25 @@ struct ScopedKernelTimer {
     if (r) (void)hipEventRecord(r->stop, st);
   }
 };
+
+// Device-resident copy of a plan's kernel parameters: what the multi-plan launches
+// (one launch over polynomials of several moduli) read per workgroup instead of
+// kernel arguments.
+struct PlanDev {
+  const ulonglong2* fwd;
+  const ulonglong2* inv;
+  ModConst mod;
+  InvLast il;
+};
+constexpr int kMaxMultiPlans = 32;
+
+// One transform over num_plans * polys_per_plan polynomials, polynomial b using plan
+// b / polys_per_plan (tabs[k]->dev must be set; all plans: same degree >= 4096, same
+// arithmetic policy, num_plans <= kMaxMultiPlans -- hipErrorNotSupported otherwise, and
+// the caller loops over the plans instead).
+hipError_t ntt_multi_launch(bool forward, const struct NttTables* const* tabs, u32 num_plans,
+                            u64 polys_per_plan, u64* result, const u64* operand, u64 out_mf,
+                            hipStream_t st);
 
 hipError_t ntt_forward_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
                               u64 out_mf, hipStream_t st);

@@ -448,6 +448,33 @@ strided_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModCons
   strided_body<FWD, R, A, LAST, kStream, kStream>(out, in, tw, m, log_n, a0, flags, bid, il);
 }
 
+// Polynomials of several moduli in one launch (RNS limbs, the per-modulus
+// transforms of KeySwitch): the workgroup's polynomial selects the plan, whose
+// parameters are read from its device-resident copy instead of kernel arguments.
+struct PlanPtrs {
+  const PlanDev* p[kMaxMultiPlans];
+};
+struct MultiCtx {
+  PlanPtrs ptrs;
+  u32 polys_per_plan;
+};
+
+template <bool FWD, int R, class A, bool LAST>
+__global__ void __launch_bounds__(256, (strided_min_waves<R>()))
+strided_pass_multi(u64* out, const u64* in, PlanPtrs ptrs, u32 polys_per_plan, u32 log_n, u32 a0,
+                   u32 flags, u64 items) {
+  u32 bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  if ((u64)bid * 256 + threadIdx.x >= items) return;
+  // a workgroup's 4 waves lie in one polynomial (>= 256 columns per polynomial: N >= 2^13)
+  const u32 poly = (bid * 4u) >> (log_n - R - 6);
+  const PlanDev* __restrict__ pd = ptrs.p[poly / polys_per_plan];
+  const ModConst m = pd->mod;
+  const InvLast il = pd->il;
+  strided_body<FWD, R, A, LAST, kStream, kStream>(out, in, FWD ? pd->fwd : pd->inv, m, log_n, a0,
+                                                  flags, bid, il);
+}
+
 // ---------------------------------------------------------------------------
 // tile_pass: S stages on a 2^TL-element tile staged through LDS
 // ---------------------------------------------------------------------------
@@ -878,6 +905,21 @@ tile_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst m
       lds, out, in, tw, m, log_n, flags, total, il, blockIdx.x);
 }
 
+// Bottom pass over polynomials of several moduli (see strided_pass_multi); N >= 2^TL, so
+// a tile lies in one polynomial and no tile is ragged.
+template <bool FWD, int S, int TL, class A, bool LAST>
+__global__ void __launch_bounds__(1 << (TL - kRE), (min_waves<S, 0>()))
+tile_pass_multi(u64* out, const u64* in, PlanPtrs ptrs, u32 polys_per_plan, u32 log_n, u32 flags,
+                u64 total) {
+  __shared__ u64 lds[1 << TL];
+  const u32 poly = (u32)(((u64)blockIdx.x << TL) >> log_n);
+  const PlanDev* __restrict__ pd = ptrs.p[poly / polys_per_plan];
+  const ModConst m = pd->mod;
+  const InvLast il = pd->il;
+  tile_body<FWD, S, 0, TL, false, A, LAST, FWD ? kStream : kPlain, FWD ? kStream : kPlain>(
+      lds, out, in, FWD ? pd->fwd : pd->inv, m, log_n, flags, total, il, blockIdx.x);
+}
+
 // (Round-1 experiment, removed: `tile_stream`, a persistent variant of the bottom pass
 // with two LDS tile buffers per workgroup, the next tile prefetched by
 // `global_load ... lds` DMA (no VGPRs, permutation applied on the global side) and the
@@ -1137,14 +1179,24 @@ fused_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst 
 template <bool FWD, class A>
 static hipError_t launch_strided(int R, u64* out, const u64* in, const ulonglong2* tw,
                                  const ModConst& m, u32 log_n, u32 a0, u32 finish, u64 batch,
-                                 const InvLast& il, hipStream_t st) {
+                                 const InvLast& il, hipStream_t st, const MultiCtx* mc = nullptr) {
   const u64 items = batch << (log_n - R);
   const unsigned grid = (unsigned)((items + 255) / 256);
   if (log_n < a0 + (u32)R + 6) return hipErrorInvalidValue;  // needs >= 64 columns per subtree
   ScopedKernelTimer timer(FWD ? "ntt_fwd_strided_pass" : "ntt_inv_strided_pass", st);
 #define HX_LAUNCH_S(RR)                                                                   \
   case RR:                                                                                \
-    if (!FWD && a0 == 0)                                                                  \
+    if (mc) {                                                                             \
+      if (log_n < (u32)RR + 8) return hipErrorNotSupported;                               \
+      if (!FWD && a0 == 0)                                                                \
+        hipLaunchKernelGGL((strided_pass_multi<FWD, RR, A, !FWD>), dim3(grid), dim3(256), \
+                           0, st, out, in, mc->ptrs, mc->polys_per_plan, log_n, a0,      \
+                           finish, items);                                                \
+      else                                                                                \
+        hipLaunchKernelGGL((strided_pass_multi<FWD, RR, A, false>), dim3(grid), dim3(256), \
+                           0, st, out, in, mc->ptrs, mc->polys_per_plan, log_n, a0,      \
+                           finish, items);                                                \
+    } else if (!FWD && a0 == 0)                                                           \
       hipLaunchKernelGGL((strided_pass<FWD, RR, A, !FWD>), dim3(grid), dim3(256), 0, st, \
                          out, in, tw, m, log_n, a0, finish, items, il);                   \
     else                                                                                  \
@@ -1168,11 +1220,37 @@ static hipError_t launch_strided(int R, u64* out, const u64* in, const ulonglong
 template <bool FWD, int TL, class A>
 static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2* tw,
                                 const ModConst& m, u32 log_n, u32 finish, u64 batch,
-                                const InvLast& il, hipStream_t st) {
+                                const InvLast& il, hipStream_t st, const MultiCtx* mc = nullptr) {
   const u64 total = batch << log_n;
   const unsigned grid = (unsigned)((total + (1u << TL) - 1) >> TL);
   const bool guard = (total & ((1u << TL) - 1)) != 0;  // the batch ends inside the last tile
   ScopedKernelTimer timer(FWD ? "ntt_fwd_tile_pass_bottom" : "ntt_inv_tile_pass_bottom", st);
+  if (mc) {  // several moduli: the shapes N >= 4096 use
+    if constexpr (TL >= 11) {
+      if (log_n < (u32)TL || (S != 11 && S != 12) || S > TL) return hipErrorNotSupported;
+      const bool last = !FWD && (u32)S == log_n;
+#define HX_LAUNCH_BM(T, LST)                                                                \
+  hipLaunchKernelGGL((tile_pass_multi<FWD, T, TL, A, LST>), dim3(grid), dim3(1 << (TL - kRE)), \
+                     0, st, out, in, mc->ptrs, mc->polys_per_plan, log_n, finish, total)
+      if (S == 11) {
+        if constexpr (TL == 11) {
+          if (last) HX_LAUNCH_BM(11, !FWD); else HX_LAUNCH_BM(11, false);
+        } else {
+          return hipErrorNotSupported;
+        }
+      } else {
+        if constexpr (TL == 12) {
+          if (last) HX_LAUNCH_BM(12, !FWD); else HX_LAUNCH_BM(12, false);
+        } else {
+          return hipErrorNotSupported;
+        }
+      }
+#undef HX_LAUNCH_BM
+      return hipGetLastError();
+    } else {
+      return hipErrorNotSupported;
+    }
+  }
 #define HX_LAUNCH_B2(T, G, LST)                                                           \
   hipLaunchKernelGGL((tile_pass<FWD, T, 0, TL, G, A, LST>), dim3(grid), dim3(1 << (TL - kRE)), \
                      0, st, out, in, tw, m, log_n, finish, total, il)
@@ -1363,10 +1441,13 @@ static hipError_t launch_top_tl(int tl, int S, u64* out, const u64* in, const ul
 template <bool FWD, class A>
 static hipError_t launch_bottom_tl(int tl, int S, u64* out, const u64* in, const ulonglong2* tw,
                                    const ModConst& m, u32 log_n, u32 finish, u64 batch,
-                                   const InvLast& il, hipStream_t st) {
-  if (tl == 10) return launch_bottom<FWD, 10, A>(S, out, in, tw, m, log_n, finish, batch, il, st);
-  if (tl == 11) return launch_bottom<FWD, 11, A>(S, out, in, tw, m, log_n, finish, batch, il, st);
-  return launch_bottom<FWD, 12, A>(S, out, in, tw, m, log_n, finish, batch, il, st);
+                                   const InvLast& il, hipStream_t st,
+                                   const MultiCtx* mc = nullptr) {
+  if (tl == 10)
+    return launch_bottom<FWD, 10, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc);
+  if (tl == 11)
+    return launch_bottom<FWD, 11, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc);
+  return launch_bottom<FWD, 12, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc);
 }
 
 // Resident workgroups of a fused_pass instantiation on the current device
@@ -1438,12 +1519,14 @@ static hipError_t launch_fused(int R, const NttTables& t, u64* result, const u64
 // One transform of `batch` polynomials on stream `st`.
 template <class A>
 static hipError_t forward_seq(const NttTables& t, const Plan& p, u64* result, const u64* operand,
-                              u64 batch, u64 out_mf, hipStream_t st) {
+                              u64 batch, u64 out_mf, hipStream_t st,
+                              const MultiCtx* mc = nullptr) {
   const u64* src = operand;
   InvLast il{};
   hipError_t e;
   u32 first = kFirstPass;  // consumed by whichever pass runs first
   if (p.top_tile) {
+    if (mc) return hipErrorNotSupported;
     e = launch_top_tl<true, A>(p.tl, p.top_tile, result, src, t.fwd, t.mod,
                                t.log_n, first, batch, il, st);
     if (e != hipSuccess) return e;
@@ -1453,7 +1536,7 @@ static hipError_t forward_seq(const NttTables& t, const Plan& p, u64* result, co
   u32 a0 = 0;
   for (int i = 0; i < p.n_strided; ++i) {
     e = launch_strided<true, A>(p.strided[i], result, src, t.fwd, t.mod, t.log_n, a0, first,
-                                batch, il, st);
+                                batch, il, st, mc);
     if (e != hipSuccess) return e;
     a0 += p.strided[i];
     src = result;
@@ -1461,22 +1544,25 @@ static hipError_t forward_seq(const NttTables& t, const Plan& p, u64* result, co
   }
   const u32 fin = out_mf == 1 ? 2 : 1;
   return launch_bottom_tl<true, A>(p.tl, p.bottom, result, src, t.fwd, t.mod, t.log_n, fin | first,
-                                   batch, il, st);
+                                   batch, il, st, mc);
 }
 
 template <class A>
 static hipError_t inverse_seq(const NttTables& t, const Plan& p, u64* result, const u64* operand,
-                              u64 batch, u64 out_mf, hipStream_t st) {
+                              u64 batch, u64 out_mf, hipStream_t st,
+                              const MultiCtx* mc = nullptr) {
   const u32 fin = out_mf == 1 ? 2 : 1;
   const bool only = !p.top_tile && p.n_strided == 0;
+  if (mc && p.top_tile) return hipErrorNotSupported;
   hipError_t e = launch_bottom_tl<false, A>(p.tl, p.bottom, result, operand, t.inv, t.mod, t.log_n,
-                                            kFirstPass | (only ? fin : 0), batch, t.inv_last, st);
+                                            kFirstPass | (only ? fin : 0), batch, t.inv_last, st,
+                                            mc);
   if (e != hipSuccess) return e;
   u32 a0 = t.log_n - (u32)p.bottom;
   for (int i = p.n_strided - 1; i >= 0; --i) {
     a0 -= p.strided[i];
     e = launch_strided<false, A>(p.strided[i], result, result, t.inv, t.mod, t.log_n, a0,
-                                 i == 0 ? fin : 0, batch, t.inv_last, st);
+                                 i == 0 ? fin : 0, batch, t.inv_last, st, mc);
     if (e != hipSuccess) return e;
   }
   if (p.top_tile)
@@ -1520,6 +1606,38 @@ hipError_t ntt_inverse_launch(const NttTables& t, u64* result, const u64* operan
     case kPolicyFp64: return transform_impl<false, Fp64>(t, result, operand, batch, out_mf, st);
     case kPolicyLazy: return transform_impl<false, Lazy>(t, result, operand, batch, out_mf, st);
     default: return transform_impl<false, Strict>(t, result, operand, batch, out_mf, st);
+  }
+}
+
+template <class A>
+static hipError_t multi_impl(bool forward, const NttTables& t0, const MultiCtx& mc, u64 polys,
+                             u64* result, const u64* operand, u64 out_mf, hipStream_t st) {
+  Plan p = make_plan((int)t0.log_n);
+  if (plan_mode() == kPlanTiled) return hipErrorNotSupported;
+  return forward ? forward_seq<A>(t0, p, result, operand, polys, out_mf, st, &mc)
+                 : inverse_seq<A>(t0, p, result, operand, polys, out_mf, st, &mc);
+}
+
+hipError_t ntt_multi_launch(bool forward, const NttTables* const* tabs, u32 num_plans,
+                            u64 polys_per_plan, u64* result, const u64* operand, u64 out_mf,
+                            hipStream_t st) {
+  if (num_plans == 0 || polys_per_plan == 0) return hipSuccess;
+  if (num_plans > (u32)kMaxMultiPlans || polys_per_plan >= (1ull << 31)) return hipErrorNotSupported;
+  const NttTables& t0 = *tabs[0];
+  if (t0.log_n < 12 || t0.log_n > 17) return hipErrorNotSupported;  // one strided + one bottom pass
+  MultiCtx mc{};
+  for (u32 k = 0; k < num_plans; ++k) {
+    if (tabs[k]->log_n != t0.log_n || tabs[k]->policy != t0.policy || !tabs[k]->dev)
+      return hipErrorNotSupported;
+    mc.ptrs.p[k] = tabs[k]->dev;
+  }
+  mc.polys_per_plan = (u32)polys_per_plan;
+  const u64 polys = (u64)num_plans * polys_per_plan;
+  switch (t0.policy) {
+    case kPolicySmall: return multi_impl<Small>(forward, t0, mc, polys, result, operand, out_mf, st);
+    case kPolicyFp64: return multi_impl<Fp64>(forward, t0, mc, polys, result, operand, out_mf, st);
+    case kPolicyLazy: return multi_impl<Lazy>(forward, t0, mc, polys, result, operand, out_mf, st);
+    default: return multi_impl<Strict>(forward, t0, mc, polys, result, operand, out_mf, st);
   }
 }
 

@@ -274,6 +274,36 @@ def test_ntt_rns(hx, ho):
     assert (host(hx, out) == x).all()
 
 
+@pytest.mark.parametrize("n,bits_list,B", [
+    (4096, [54, 54, 54], 3),          # one launch sequence over the three moduli
+    (8192, [45, 45, 45, 45], 1),      # Fp64 policy, one polynomial per modulus
+    (1 << 17, [60, 60], 2),           # Strict policy, 5 + 12 stages
+    (2048, [54, 54], 3),              # below the multi-plan shapes: plan by plan
+    (16384, [28, 54, 45, 60], 2),     # mixed arithmetic policies: plan by plan
+    (4096, [54] * 33, 1),             # more moduli than one launch takes (32): two groups
+])
+def test_ntt_rns_shapes(hx, ho, n, bits_list, B):
+    """The RNS entry point (polynomials [k*B, (k+1)*B) use plans[k]) over the shapes that do
+    and do not go through the multi-plan launches, against the oracle."""
+    import torch
+    primes = []
+    for bits in sorted(set(bits_list)):
+        found = ho.generate_primes(bits_list.count(bits), bits, True, n)
+        primes += found
+    primes = [primes.pop(0) for _ in bits_list]  # any order will do; all distinct
+    plans = [hx.NTT(n, p) for p in primes]
+    x = np.stack([np.stack([ho.fill_splitmix(n, 100 * k + b, p) for b in range(B)])
+                  for k, p in enumerate(primes)])
+    d = dev(hx, x)
+    out = torch.empty_like(d)
+    hx.ComputeForwardRNS(plans, out, d, 1, 1)
+    got = host(hx, out)
+    for k, p in enumerate(primes):
+        assert (got[k] == ho.NTT(n, p).forward(x[k], 1, 1)).all(), (k, p)
+    hx.ComputeInverseRNS(plans, out, out, 1, 1)
+    assert (host(hx, out) == x).all()
+
+
 DEFN = json.load(open(os.path.join(os.path.dirname(__file__), "golden",
                                    "ntt_definition_fixtures.json")))
 

@@ -29,6 +29,7 @@ _LIB_PATH = os.environ.get("HEXL_AMD_LIB") or os.path.join(_HERE, "lib", "libhex
 __all__ = [
     "NTT", "EltwiseAddMod", "EltwiseSubMod", "EltwiseMultMod", "EltwiseFMAMod",
     "EltwiseReduceMod", "EltwiseReduceFMAMod", "EltwiseCmpAdd", "EltwiseCmpSubMod", "CMPINT", "DyadicMultiply", "KeySwitch",
+    "KeySwitchBatch",
     "HexlAmdError", "lib", "LIB_PATH",
     "MinimalPrimitiveRoot", "GeneratePrimes", "IsPrime", "InverseMod", "MultiplyMod",
     "PowMod", "IsPrimitiveRoot", "ReverseBits", "MultiplyFactor", "fill_splitmix",
@@ -84,6 +85,8 @@ def _load():
     sig("hexl_amd_dyadic_multiply_host", ci, p64, p64, p64, u64, C.POINTER(u64), u64)
     sig("hexl_amd_key_switch", ci, p64, p64, u64, u64, u64, u64, u64, C.POINTER(u64),
         C.POINTER(vp), C.POINTER(u64), vp)
+    sig("hexl_amd_key_switch_batch", ci, p64, p64, u64, u64, u64, u64, u64, u64, C.POINTER(u64),
+        C.POINTER(vp), C.POINTER(u64), vp)
     sig("hexl_amd_key_switch_host", ci, p64, p64, u64, u64, u64, u64, u64, C.POINTER(u64),
         C.POINTER(vp), C.POINTER(u64))
     sig("hexl_amd_eltwise_cmp_add", ci, p64, p64, u64, ci, u64, u64, vp)
@@ -124,7 +127,7 @@ C_ABI_SYMBOLS = [
     "hexl_amd_eltwise_reduce_mod", "hexl_amd_eltwise_reduce_fma_mod", "hexl_amd_eltwise_host",
     "hexl_amd_eltwise_cmp_add", "hexl_amd_eltwise_cmp_sub_mod", "hexl_amd_eltwise_cmp_host",
     "hexl_amd_dyadic_multiply", "hexl_amd_dyadic_multiply_host",
-    "hexl_amd_key_switch", "hexl_amd_key_switch_host",
+    "hexl_amd_key_switch", "hexl_amd_key_switch_batch", "hexl_amd_key_switch_host",
     "hexl_amd_multiply_factor", "hexl_amd_inverse_mod", "hexl_amd_multiply_mod",
     "hexl_amd_pow_mod", "hexl_amd_is_primitive_root", "hexl_amd_generate_primitive_root",
     "hexl_amd_minimal_primitive_root", "hexl_amd_reverse_bits", "hexl_amd_is_prime",
@@ -410,6 +413,24 @@ def KeySwitch(result, t_target_iter, n, decomp_modulus_size, key_modulus_size, r
                                    _ptr(t_target_iter, decomp_modulus_size * n), n, decomp_modulus_size,
                                    key_modulus_size, rns_modulus_size, key_component_count, mod,
                                    keys, msf, _stream()))
+
+
+def KeySwitchBatch(result, t_target_iter, num_targets, n, decomp_modulus_size, key_modulus_size,
+                   rns_modulus_size, key_component_count, moduli, k_switch_keys, modswitch_factors):
+    """num_targets ciphertexts with the same keys and moduli in one call (twelve launches
+    whatever the sizes): targets and results back to back in the layouts of KeySwitch."""
+    mod = (C.c_uint64 * len(moduli))(*[int(m) for m in moduli])
+    msf = (C.c_uint64 * len(modswitch_factors))(*[int(m) for m in modswitch_factors])
+    if (len(moduli) < key_modulus_size or len(modswitch_factors) < decomp_modulus_size or
+            len(k_switch_keys) < decomp_modulus_size):
+        raise HexlAmdError("moduli / modswitch_factors / k_switch_keys are shorter than the sizes say")
+    key_words = key_component_count * key_modulus_size * n
+    keys = (C.c_void_p * len(k_switch_keys))(*[_ptr(k, key_words).value for k in k_switch_keys])
+    _check(lib.hexl_amd_key_switch_batch(
+        _ptr(result, num_targets * key_component_count * decomp_modulus_size * n),
+        _ptr(t_target_iter, num_targets * decomp_modulus_size * n), num_targets, n,
+        decomp_modulus_size, key_modulus_size, rns_modulus_size, key_component_count, mod, keys,
+        msf, _stream()))
 
 
 class CMPINT:

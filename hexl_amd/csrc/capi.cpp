@@ -370,23 +370,31 @@ static int ntt_run_rns(const hexl_amd_ntt* const* plans, uint64_t num_plans, uin
   }
   if (num_plans == 0 || batch_per_plan == 0) return HEXL_AMD_OK;
   if (int rc = check_ntt_args(plans[0], result, operand, forward, in_mf, out_mf)) return rc;
-  // One launch sequence over all moduli where the shapes allow it (degree >= 4096,
-  // one arithmetic policy), in groups of kMaxMultiPlans; otherwise plan by plan.
-  {
+  // One launch sequence over all moduli where the shapes allow it (degree 2^12 .. 2^17),
+  // in groups of kMaxMultiPlans; otherwise plan by plan.
+  if (num_plans > 1) {
     DeviceScope scope(plans[0]->device);
     if (scope.err != hipSuccess) return hip_fail(scope.err, "hipSetDevice");
-    bool multi_ok = num_plans > 1;
+    bool multi_ok = true;
     uint64_t k = 0;
     while (multi_ok && k < num_plans) {
       const uint64_t cnt = num_plans - k < (uint64_t)kMaxMultiPlans ? num_plans - k
                                                                      : (uint64_t)kMaxMultiPlans;
       const NttTables* tabs[kMaxMultiPlans];
-      for (uint64_t j = 0; j < cnt; ++j) tabs[j] = &plans[k + j]->t;
+      MultiMap map{};
+      map.inner = (u32)batch_per_plan;
+      map.period = (u32)cnt;
+      for (uint64_t j = 0; j < cnt; ++j) {
+        tabs[j] = &plans[k + j]->t;
+        map.plan_tab[j] = (uint8_t)j;
+      }
       const uint64_t off = k * batch_per_plan * plans[0]->n;
-      hipError_t e = ntt_multi_launch(forward, tabs, (u32)cnt, batch_per_plan, result + off,
-                                      operand + off, out_mf, (hipStream_t)stream);
-      if (e == hipErrorNotSupported) {
-        if (k != 0) return hip_fail(e, "multi-plan NTT launch");  // cannot happen: same shapes
+      hipError_t e = batch_per_plan < (1ull << 31)
+                         ? ntt_multi_launch(forward, tabs, (u32)cnt, map, cnt * batch_per_plan,
+                                            result + off, operand + off, out_mf,
+                                            (hipStream_t)stream)
+                         : hipErrorNotSupported;
+      if (e == hipErrorNotSupported && k == 0) {
         multi_ok = false;
         break;
       }
@@ -720,75 +728,96 @@ static int check_key_switch(const uint64_t* result, const uint64_t* t_target, ui
   return HEXL_AMD_OK;
 }
 
-// Device buffers throughout.  `keys`: host array of D device pointers.
-static int key_switch_device(u64* result, const u64* t_target_iter, u64 n, u64 D, u64 K, u64 R,
-                             u64 C, const u64* moduli, const u64* const* keys, const u64* msf,
-                             hipStream_t st) {
+// Transforms of `polys` consecutive polynomials whose moduli follow `map` (plan ids index
+// `plans`): one multi-plan launch sequence where the shapes allow it, otherwise one launch
+// per polynomial (small degrees -- the reference's own small test vectors).
+static int ntt_mapped(bool forward, const std::vector<const hexl_amd_ntt*>& plans,
+                      const MultiMap& map, u64 polys, u64* result, const u64* operand, u64 n,
+                      u64 out_mf, hipStream_t st) {
+  std::vector<const NttTables*> tabs(plans.size());
+  for (size_t k = 0; k < plans.size(); ++k) tabs[k] = &plans[k]->t;
+  hipError_t e = ntt_multi_launch(forward, tabs.data(), (u32)tabs.size(), map, polys, result,
+                                  operand, out_mf, st);
+  if (e == hipSuccess) return HEXL_AMD_OK;
+  if (e != hipErrorNotSupported) return hip_fail(e, "KeySwitch multi-plan NTT");
+  for (u64 b = 0; b < polys; ++b) {
+    const NttTables& t = plans[map.plan_tab[(b / map.inner) % map.period]]->t;
+    e = forward ? ntt_forward_launch(t, result + b * n, operand + b * n, 1, out_mf, st)
+                : ntt_inverse_launch(t, result + b * n, operand + b * n, 1, out_mf, st);
+    if (e != hipSuccess) return hip_fail(e, "KeySwitch NTT");
+  }
+  return HEXL_AMD_OK;
+}
+
+// Device buffers throughout; T targets that share moduli and keys.  `keys`: host array of
+// D device pointers.  Twelve launches whatever T, D and C are (degree >= 8192): inverse
+// NTT of the targets (2), gather (1), lazy forward NTT of all product operands (2),
+// multiply-accumulate (1), inverse NTT of the last components (2), rounding (1), forward
+// NTT of the corrections (2), finish (1).
+static int key_switch_device(u64* result, const u64* t_target_iter, u64 T, u64 n, u64 D, u64 K,
+                             u64 R, u64 C, const u64* moduli, const u64* const* keys,
+                             const u64* msf, hipStream_t st) {
   int device = 0;
   HX_HIP(hipGetDevice(&device));
-  std::vector<const hexl_amd_ntt*> plan(K, nullptr);
-  for (u64 i = 0; i < K; ++i)
-    if (i < D || i == K - 1) {
-      plan[i] = cached_plan(n, moduli[i], device);
-      if (!plan[i]) return HEXL_AMD_ERR_HIP;  // message set by hexl_amd_ntt_create
-    }
-  // workspace: t_target (D n) | ntt_buf (D n) | t_poly_prod (C R n).  Keyed by the
-  // caller's stream: calls on one stream are serialised and share it, calls on
-  // different streams may overlap on the device and get separate buffers.
-  const size_t words = (size_t)n * (2 * D + C * R);
+  // plan ids: 0..D-1 the decomposition moduli, D the special modulus moduli[K-1]
+  std::vector<const hexl_amd_ntt*> plan(D + 1, nullptr);
+  for (u64 i = 0; i <= D; ++i) {
+    plan[i] = cached_plan(n, moduli[i < D ? i : K - 1], device);
+    if (!plan[i]) return HEXL_AMD_ERR_HIP;  // message set by hexl_amd_ntt_create
+  }
+  // workspace: t_target (T D) | ntt_buf (T D^2) | prod (R T C) | tbuf (T C D) polynomials.
+  // Keyed by the caller's stream: calls on one stream are serialised and share it, calls
+  // on different streams may overlap on the device and get separate buffers.
+  const size_t words = (size_t)n * T * (D + D * D + R * C + C * D);
   void* ws = nullptr;
   HX_HIP(stream_workspace(kWsKeySwitch, st, words * sizeof(u64), &ws));
   u64* t_target = (u64*)ws;
-  u64* ntt_buf = t_target + D * n;
-  u64* prod = ntt_buf + D * n;
+  u64* ntt_buf = t_target + T * D * n;
+  u64* prod = ntt_buf + T * D * D * n;
+  u64* tbuf = prod + R * T * C * n;
+  const KsDims dims{n, (u32)D, (u32)T, (u32)C, (u32)K};
   hipError_t e;
 
-  // key-switch-internal.cpp:38-56: coefficient form of the target per decomposition modulus
-  HX_HIP(hipMemcpyAsync(t_target, t_target_iter, D * n * sizeof(u64), hipMemcpyDeviceToDevice, st));
-  for (u64 j = 0; j < D; ++j) {
-    e = ntt_inverse_launch(plan[j]->t, t_target + j * n, t_target + j * n, 1, 1, st);
-    if (e != hipSuccess) return hip_fail(e, "KeySwitch inverse NTT");
+  // key-switch-internal.cpp:38-56: coefficient form of the targets per decomposition modulus
+  {
+    MultiMap map{};
+    map.inner = 1;
+    map.period = (u32)D;
+    for (u64 j = 0; j < D; ++j) map.plan_tab[j] = (uint8_t)j;
+    if (int rc = ntt_mapped(false, plan, map, T * D, t_target, t_target_iter, n, 1, st)) return rc;
   }
 
-  // :61-131 per RNS index: operands to the key modulus, lazy forward NTT, MAC, reduce
+  // :61-131 per RNS index i: operands to the key modulus, lazy forward NTT, MAC, reduce
+  KsGatherAll g{};
+  KsMacAll m{};
+  for (u64 j = 0; j < D; ++j) m.keys[j] = keys[j];
   for (u64 i = 0; i < R; ++i) {
     const u64 key_index = (i == D) ? K - 1 : i;
     const u64 q = moduli[key_index];
-    KsGather g{};
-    KsMac m{};
-    g.q = q;
-    g.barrett = floor_2_64_over(q);
-    u32 slots = 0;
-    for (u64 j = 0; j < D; ++j) {
-      m.keys[j] = keys[j];
-      if (j == i) continue;
-      g.jmap[slots] = (u32)j;
-      if (moduli[j] > q) g.reduce_mask |= 1u << slots;
-      m.slot[j] = slots++;
-    }
-    e = ks_gather_launch(ntt_buf, t_target, n, slots, g, st);
-    if (e != hipSuccess) return hip_fail(e, "KeySwitch gather");
-    if (slots) {
-      e = ntt_forward_launch(plan[key_index]->t, ntt_buf, ntt_buf, slots, 4, st);
-      if (e != hipSuccess) return hip_fail(e, "KeySwitch forward NTT");
-    }
-    m.decomp = (u32)D;
-    m.self = (u32)i;  // == D for the extra RNS index: no operand from t_target_iter
-    m.key_component_stride = K * n;
-    m.key_index_offset = key_index * n;
-    m.prod_component_stride = R * n;
-    m.prod_offset = i * n;
-    m.q = q;
-    m.barrett = g.barrett;
-    m.two64_mod_q = (u64)((((unsigned __int128)1) << 64) % q);
+    g.q[i] = m.q[i] = q;
+    g.barrett[i] = m.barrett[i] = floor_2_64_over(q);
+    for (u64 j = 0; j < D; ++j)
+      if (j != i && moduli[j] > q) g.reduce_mask[i] |= 1u << j;
+    m.key_index[i] = (u32)key_index;
+    m.two64_mod_q[i] = (u64)((((unsigned __int128)1) << 64) % q);
     const u32 ceil_log = 64 - __builtin_clzll(q);
-    m.shift = ceil_log - 2;
-    m.mu = (u64)((((unsigned __int128)(1ull << (ceil_log + 62 - 64))) << 64) / q);
-    e = ks_mac_launch(prod, t_target_iter, ntt_buf, n, (u32)C, m, st);
-    if (e != hipSuccess) return hip_fail(e, "KeySwitch multiply-accumulate");
+    m.shift[i] = ceil_log - 2;
+    m.mu[i] = (u64)((((unsigned __int128)(1ull << (ceil_log + 62 - 64))) << 64) / q);
   }
+  e = ks_gather_launch(ntt_buf, t_target, dims, g, st);
+  if (e != hipSuccess) return hip_fail(e, "KeySwitch gather");
+  {
+    MultiMap map{};
+    map.inner = 1;
+    map.period = (u32)(D * D);
+    for (u64 s = 0; s < D * D; ++s)
+      map.plan_tab[s] = (uint8_t)(s < D * (D - 1) ? s / (D - 1) : D);
+    if (int rc = ntt_mapped(true, plan, map, T * D * D, ntt_buf, ntt_buf, n, 4, st)) return rc;
+  }
+  e = ks_mac_launch(prod, t_target_iter, ntt_buf, dims, m, st);
+  if (e != hipSuccess) return hip_fail(e, "KeySwitch multiply-accumulate");
 
-  // :134-197 per key component: modulus switching from the special prime
+  // :134-197 modulus switching from the special prime, all (target, key component) at once
   const u64 qk = moduli[K - 1];
   KsRound rd{};
   KsFinish fin{};
@@ -807,20 +836,20 @@ static int key_switch_device(u64* result, const u64* t_target_iter, u64 n, u64 D
     if (s >= qi) s -= qi;
     fin.mod[i] = KsFinishMod{qi, s, (u64)((((unsigned __int128)s) << 64) / qi)};
   }
-  for (u64 kc = 0; kc < C; ++kc) {
-    u64* pk = prod + kc * n * R;
-    u64* t_last = pk + D * n;
-    e = ntt_inverse_launch(plan[K - 1]->t, t_last, t_last, 1, 2, st);
-    if (e != hipSuccess) return hip_fail(e, "KeySwitch inverse NTT (last)");
-    e = ks_round_launch(ntt_buf, t_last, n, (u32)D, rd, st);
-    if (e != hipSuccess) return hip_fail(e, "KeySwitch rounding");
-    for (u64 i = 0; i < D; ++i) {
-      e = ntt_forward_launch(plan[i]->t, ntt_buf + i * n, ntt_buf + i * n, 1, 4, st);
-      if (e != hipSuccess) return hip_fail(e, "KeySwitch forward NTT (switch)");
-    }
-    e = ks_finish_launch(result + n * D * kc, pk, ntt_buf, n, (u32)D, fin, st);
-    if (e != hipSuccess) return hip_fail(e, "KeySwitch finish");
+  u64* t_last = prod + D * T * C * n;  // prod[D][.][.]: T C contiguous polynomials
+  e = ntt_inverse_launch(plan[D]->t, t_last, t_last, T * C, 2, st);
+  if (e != hipSuccess) return hip_fail(e, "KeySwitch inverse NTT (last)");
+  e = ks_round_launch(tbuf, prod, dims, rd, st);
+  if (e != hipSuccess) return hip_fail(e, "KeySwitch rounding");
+  {
+    MultiMap map{};
+    map.inner = 1;
+    map.period = (u32)D;
+    for (u64 i = 0; i < D; ++i) map.plan_tab[i] = (uint8_t)i;
+    if (int rc = ntt_mapped(true, plan, map, T * C * D, tbuf, tbuf, n, 4, st)) return rc;
   }
+  e = ks_finish_launch(result, prod, tbuf, dims, fin, st);
+  if (e != hipSuccess) return hip_fail(e, "KeySwitch finish");
   return HEXL_AMD_OK;
 }
 
@@ -833,9 +862,27 @@ int hexl_amd_key_switch(uint64_t* result, const uint64_t* t_target_iter_ptr, uin
                                 key_modulus_size, rns_modulus_size, key_component_count, moduli,
                                 k_switch_keys, modswitch_factors))
     return rc;
-  return key_switch_device(result, t_target_iter_ptr, n, decomp_modulus_size, key_modulus_size,
+  return key_switch_device(result, t_target_iter_ptr, 1, n, decomp_modulus_size, key_modulus_size,
                            rns_modulus_size, key_component_count, moduli, k_switch_keys,
                            modswitch_factors, (hipStream_t)stream);
+}
+
+int hexl_amd_key_switch_batch(uint64_t* result, const uint64_t* t_target_iter_ptr,
+                              uint64_t num_targets, uint64_t n, uint64_t decomp_modulus_size,
+                              uint64_t key_modulus_size, uint64_t rns_modulus_size,
+                              uint64_t key_component_count, const uint64_t* moduli,
+                              const uint64_t* const* k_switch_keys,
+                              const uint64_t* modswitch_factors, void* stream) {
+  if (int rc = check_key_switch(result, t_target_iter_ptr, n, decomp_modulus_size,
+                                key_modulus_size, rns_modulus_size, key_component_count, moduli,
+                                k_switch_keys, modswitch_factors))
+    return rc;
+  if (num_targets == 0) return HEXL_AMD_OK;
+  if (num_targets * key_component_count > 65535)
+    return fail(HEXL_AMD_ERR_INVALID_ARG, "num_targets * key_component_count must be <= 65535");
+  return key_switch_device(result, t_target_iter_ptr, num_targets, n, decomp_modulus_size,
+                           key_modulus_size, rns_modulus_size, key_component_count, moduli,
+                           k_switch_keys, modswitch_factors, (hipStream_t)stream);
 }
 
 int hexl_amd_key_switch_host(uint64_t* result, const uint64_t* t_target_iter_ptr, uint64_t n,
@@ -863,7 +910,7 @@ int hexl_amd_key_switch_host(uint64_t* result, const uint64_t* t_target_iter_ptr
                           hipMemcpyHostToDevice, st));
     kp[j] = d_keys + j * key_words;
   }
-  if (int rc = key_switch_device(d_res, d_tgt, n, D, K, R, C, moduli, kp.data(),
+  if (int rc = key_switch_device(d_res, d_tgt, 1, n, D, K, R, C, moduli, kp.data(),
                                  modswitch_factors, st))
     return rc;
   HX_HIP(hipMemcpyAsync(result, d_res, res_words * sizeof(u64), hipMemcpyDeviceToHost, st));

@@ -83,15 +83,25 @@ struct PlanDev {
   ModConst mod;
   InvLast il;
 };
-constexpr int kMaxMultiPlans = 32;
+constexpr int kMaxMultiPlans = 40;
+constexpr int kMaxMultiPeriod = 1024;
 
-// One transform over num_plans * polys_per_plan polynomials, polynomial b using plan
-// b / polys_per_plan (tabs[k]->dev must be set; all plans: same degree >= 4096, same
-// arithmetic policy, num_plans <= kMaxMultiPlans -- hipErrorNotSupported otherwise, and
-// the caller loops over the plans instead).
+// Which plan a polynomial of a multi-plan launch uses:
+//   plan = plan_tab[(polynomial / inner) % period]
+// (RNS limbs: inner = polynomials per modulus, period = number of moduli, identity table;
+// KeySwitch: inner = 1, period = polynomials per target, table = modulus of each).
+struct MultiMap {
+  u32 inner, period;
+  uint8_t plan_tab[kMaxMultiPeriod];
+};
+
+// One transform over `polys` polynomials of several moduli (all plans: same degree in
+// [2^12, 2^17]; tabs[k]->dev set; num_plans <= kMaxMultiPlans).  Plans of different
+// arithmetic policies are served by one launch sequence per policy.  Returns
+// hipErrorNotSupported when the shapes do not fit; the caller then loops over plans.
 hipError_t ntt_multi_launch(bool forward, const struct NttTables* const* tabs, u32 num_plans,
-                            u64 polys_per_plan, u64* result, const u64* operand, u64 out_mf,
-                            hipStream_t st);
+                            const MultiMap& map, u64 polys, u64* result, const u64* operand,
+                            u64 out_mf, hipStream_t st);
 
 hipError_t ntt_forward_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
                               u64 out_mf, hipStream_t st);
@@ -131,22 +141,29 @@ struct EltArgs {
 hipError_t eltwise_launch(EltOp op, const EltArgs& args, hipStream_t st);
 hipError_t dyadic_multiply_launch(u64* result, const u64* op1, const u64* op2, u64 n,
                                   const u64* moduli_host, u64 num_moduli, hipStream_t st);
-// ---- KeySwitch stages (keyswitch_kernels.hip); argument blocks travel as kernel
-// arguments, so the number of decomposition moduli per call is bounded.
+// ---- KeySwitch stages (keyswitch_kernels.hip), batched over `targets` ciphertexts that
+// share keys and moduli.  Argument blocks travel as kernel arguments, so the number of
+// decomposition moduli per call is bounded.  Buffer layouts (polynomials of n words):
+//   t_target [target][j]            coefficient form of the target per decomposition modulus
+//   ntt_buf  [target][s], s < D^2   operand of product (i, j != i): s = i (D-1) + (j < i ? j : j-1)
+//                                   for RNS index i < D, s = D (D-1) + j for the extra index D
+//   prod     [i][target][k]         accumulated products per RNS index i <= D, key component k
+//   tbuf     [target][k][i]         the rounded last component brought to modulus i < D
+//   result   [target][k][i]         (the caller's: `targets` results of the reference's layout)
 constexpr int kKsMaxDecomp = 32;
-struct KsGather {
-  u64 q, barrett;          // key modulus of this RNS index, floor(2^64 / q)
-  u32 jmap[kKsMaxDecomp];  // slot -> decomposition modulus
-  u32 reduce_mask;         // bit s: moduli[jmap[s]] > q, reduce
+struct KsDims {
+  u64 n;
+  u32 decomp, targets, components, key_moduli;  // D, T, C, K
 };
-struct KsMac {
+struct KsGatherAll {  // per RNS index i <= D: its key modulus
+  u64 q[kKsMaxDecomp + 1], barrett[kKsMaxDecomp + 1];
+  u32 reduce_mask[kKsMaxDecomp + 1];  // bit j: moduli[j] > q[i], reduce operand j
+};
+struct KsMacAll {
   const u64* keys[kKsMaxDecomp];
-  u32 slot[kKsMaxDecomp];  // decomposition modulus -> slot of ntt_buf (unused for `self`)
-  u32 decomp, self;        // self == decomp: no operand is taken from t_target_iter
-  u64 key_component_stride, key_index_offset;
-  u64 prod_component_stride, prod_offset;
-  u64 q, barrett, two64_mod_q, mu;  // mu, shift: generalised Barrett of MultOp
-  u32 shift;
+  u64 q[kKsMaxDecomp + 1], barrett[kKsMaxDecomp + 1], two64_mod_q[kKsMaxDecomp + 1],
+      mu[kKsMaxDecomp + 1];  // mu, shift: generalised Barrett of MultOp
+  u32 shift[kKsMaxDecomp + 1], key_index[kKsMaxDecomp + 1];
 };
 struct KsRoundMod {
   u64 q, barrett, fix;
@@ -162,13 +179,13 @@ struct KsFinishMod {
 struct KsFinish {
   KsFinishMod mod[kKsMaxDecomp];
 };
-hipError_t ks_gather_launch(u64* out, const u64* t_target, u64 n, u32 slots, const KsGather& g,
-                            hipStream_t st);
-hipError_t ks_mac_launch(u64* prod, const u64* t_target_iter, const u64* ntt_buf, u64 n,
-                         u32 components, const KsMac& m, hipStream_t st);
-hipError_t ks_round_launch(u64* tbuf, const u64* t_last, u64 n, u32 decomp, const KsRound& r,
+hipError_t ks_gather_launch(u64* ntt_buf, const u64* t_target, const KsDims& d,
+                            const KsGatherAll& g, hipStream_t st);
+hipError_t ks_mac_launch(u64* prod, const u64* t_target_iter, const u64* ntt_buf, const KsDims& d,
+                         const KsMacAll& m, hipStream_t st);
+hipError_t ks_round_launch(u64* tbuf, const u64* prod, const KsDims& d, const KsRound& r,
                            hipStream_t st);
-hipError_t ks_finish_launch(u64* result, const u64* prod, const u64* tbuf, u64 n, u32 decomp,
+hipError_t ks_finish_launch(u64* result, const u64* prod, const u64* tbuf, const KsDims& d,
                             const KsFinish& f, hipStream_t st);
 
 hipError_t fill_splitmix_launch(u64* data, u64 n, u64 batch, u64 seed0, u64 bound,

@@ -22,73 +22,98 @@ __device__ __forceinline__ u64 full_reduce(u64 x, u64 q, u64 barrett) {
   return csub(x - __umul64hi(x, barrett) * q, q);
 }
 
-// :77-89 operands of the products for RNS index i: slot s holds decomposition
-// modulus jmap[s], reduced to the key modulus where that one is smaller.
+// Work decomposition of every kernel: blockIdx.x strides over the n coefficients,
+// blockIdx.y selects the modulus / operand, blockIdx.z the (target, key component).
+// No pointer is __restrict__: nothing here is in place, but the buffers are slices of
+// one workspace.
+
+// :77-89 operands of the products: for RNS index i (key modulus q[i]) and every
+// decomposition modulus j != i the coefficient-form target, reduced to q[i] where
+// moduli[j] is larger.  blockIdx.y = s (see internal.h), blockIdx.z = target.
 __global__ void __launch_bounds__(256)
-ks_gather_kernel(u64* out, const u64* t_target, u64 n, KsGather g) {
-  const u32 s = blockIdx.y;
-  const u64* src = t_target + (u64)g.jmap[s] * n;
-  u64* dst = out + (u64)s * n;
-  const bool reduce = (g.reduce_mask >> s) & 1;
+ks_gather_kernel(u64* ntt_buf, const u64* t_target, KsDims d, KsGatherAll g) {
+  const u32 D = d.decomp, s = blockIdx.y, tgt = blockIdx.z;
+  u32 i, j;
+  if (s < D * (D - 1)) {
+    i = s / (D - 1);
+    const u32 r = s - i * (D - 1);
+    j = r < i ? r : r + 1;
+  } else {
+    i = D;
+    j = s - D * (D - 1);
+  }
+  const u64* src = t_target + ((u64)tgt * D + j) * d.n;
+  u64* dst = ntt_buf + ((u64)tgt * D * D + s) * d.n;
+  const bool reduce = (g.reduce_mask[i] >> j) & 1;
+  const u64 q = g.q[i], barrett = g.barrett[i];
   const u64 stride = (u64)gridDim.x * 256;
-  for (u64 l = (u64)blockIdx.x * 256 + threadIdx.x; l < n; l += stride) {
+  for (u64 l = (u64)blockIdx.x * 256 + threadIdx.x; l < d.n; l += stride) {
     const u64 v = src[l];
-    dst[l] = reduce ? full_reduce(v, g.q, g.barrett) : v;
+    dst[l] = reduce ? full_reduce(v, q, barrett) : v;
   }
 }
 
 // :94-130 multiply with the keys, accumulate in 128 bits, reduce once.
-// blockIdx.y = key component k.
+// blockIdx.y = RNS index i, blockIdx.z = target * C + key component k.
 __global__ void __launch_bounds__(256)
-ks_mac_kernel(u64* prod, const u64* t_target_iter, const u64* ntt_buf, u64 n, KsMac m) {
-  const u32 k = blockIdx.y;
-  const u64 key_off = (u64)k * m.key_component_stride + m.key_index_offset;
-  u64* dst = prod + (u64)k * m.prod_component_stride + m.prod_offset;
+ks_mac_kernel(u64* prod, const u64* t_target_iter, const u64* ntt_buf, KsDims d, KsMacAll m) {
+  const u32 D = d.decomp, i = blockIdx.y;
+  const u32 tgt = blockIdx.z / d.components, k = blockIdx.z - tgt * d.components;
+  const u64 n = d.n;
+  const u64 key_off = ((u64)k * d.key_moduli + m.key_index[i]) * n;
+  u64* dst = prod + (((u64)i * d.targets + tgt) * d.components + k) * n;
+  const u64* own = t_target_iter + (u64)tgt * D * n;    // NTT-form operands (j == i)
+  const u64* buf = ntt_buf + ((u64)tgt * D * D + (i < D ? (u64)i * (D - 1) : (u64)D * (D - 1))) * n;
+  const u64 q = m.q[i], barrett = m.barrett[i], two64 = m.two64_mod_q[i], mu = m.mu[i];
+  const u32 shift = m.shift[i];
   const u64 stride = (u64)gridDim.x * 256;
   for (u64 l = (u64)blockIdx.x * 256 + threadIdx.x; l < n; l += stride) {
     u64 lo = 0, hi = 0;
-    for (u32 j = 0; j < m.decomp; ++j) {
-      const u64 a = (j == m.self) ? t_target_iter[(u64)j * n + l]
-                                  : ntt_buf[(u64)m.slot[j] * n + l];
+    for (u32 j = 0; j < D; ++j) {
+      const u64 a = (j == i) ? own[(u64)j * n + l] : buf[(u64)(j < i ? j : (i < D ? j - 1 : j)) * n + l];
       const u64 b = m.keys[j][key_off + l];
       const u64 plo = a * b, phi = __umul64hi(a, b);
       lo += plo;
       hi += phi + (lo < plo);
     }
     // (hi * 2^64 + lo) mod q exactly (BarrettReduce128, util/gcc.hpp:20-28)
-    const u64 r1 = full_reduce(hi, m.q, m.barrett);
-    const u64 r2 = full_reduce(lo, m.q, m.barrett);
-    const u64 plo = r1 * m.two64_mod_q, phi = __umul64hi(r1, m.two64_mod_q);
-    const u64 c1 = m.shift ? ((plo >> m.shift) | (phi << (64 - m.shift))) : plo;
-    const u64 r = csub(plo - __umul64hi(c1, m.mu) * m.q, m.q);
-    dst[l] = csub(r + r2, m.q);
+    const u64 r1 = full_reduce(hi, q, barrett);
+    const u64 r2 = full_reduce(lo, q, barrett);
+    const u64 plo = r1 * two64, phi = __umul64hi(r1, two64);
+    const u64 c1 = shift ? ((plo >> shift) | (phi << (64 - shift))) : plo;
+    const u64 r = csub(plo - __umul64hi(c1, mu) * q, q);
+    dst[l] = csub(r + r2, q);
   }
 }
 
 // :146-175 round the last RNS component (add q_k / 2, reduce mod q_k), bring it to
-// every decomposition modulus and add the correction; blockIdx.y = i.
+// every decomposition modulus and add the correction.
+// blockIdx.y = i < D, blockIdx.z = target * C + k.
 __global__ void __launch_bounds__(256)
-ks_round_kernel(u64* tbuf, const u64* t_last, u64 n, KsRound r) {
-  const KsRoundMod mi = r.mod[blockIdx.y];
-  u64* dst = tbuf + (u64)blockIdx.y * n;
+ks_round_kernel(u64* tbuf, const u64* prod, KsDims d, KsRound r) {
+  const u32 D = d.decomp, i = blockIdx.y;
+  const KsRoundMod mi = r.mod[i];
+  const u64* t_last = prod + ((u64)D * d.targets * d.components + blockIdx.z) * d.n;
+  u64* dst = tbuf + ((u64)blockIdx.z * D + i) * d.n;
   const u64 stride = (u64)gridDim.x * 256;
-  for (u64 l = (u64)blockIdx.x * 256 + threadIdx.x; l < n; l += stride) {
+  for (u64 l = (u64)blockIdx.x * 256 + threadIdx.x; l < d.n; l += stride) {
     const u64 x = t_last[l] + r.qk_half;
     const u64 v = csub(x - __umul64hi(x, r.barrett_k) * r.qk, r.qk);
     dst[l] = (mi.reduce ? full_reduce(v, mi.q, mi.barrett) : v) + mi.fix;
   }
 }
 
-// :180-196 (ct mod q_i - ct mod q_k) * q_k^-1 mod q_i, accumulated into the result;
-// blockIdx.y = i.
+// :180-196 (ct mod q_i - ct mod q_k) * q_k^-1 mod q_i, accumulated into the result.
+// blockIdx.y = i < D, blockIdx.z = target * C + k.
 __global__ void __launch_bounds__(256)
-ks_finish_kernel(u64* result, const u64* prod, const u64* tbuf, u64 n, KsFinish f) {
-  const KsFinishMod mi = f.mod[blockIdx.y];
-  u64* data = result + (u64)blockIdx.y * n;
-  const u64* p = prod + (u64)blockIdx.y * n;
-  const u64* t = tbuf + (u64)blockIdx.y * n;
+ks_finish_kernel(u64* result, const u64* prod, const u64* tbuf, KsDims d, KsFinish f) {
+  const u32 D = d.decomp, i = blockIdx.y;
+  const KsFinishMod mi = f.mod[i];
+  u64* data = result + ((u64)blockIdx.z * D + i) * d.n;
+  const u64* p = prod + ((u64)i * d.targets * d.components + blockIdx.z) * d.n;
+  const u64* t = tbuf + ((u64)blockIdx.z * D + i) * d.n;
   const u64 stride = (u64)gridDim.x * 256;
-  for (u64 l = (u64)blockIdx.x * 256 + threadIdx.x; l < n; l += stride) {
+  for (u64 l = (u64)blockIdx.x * 256 + threadIdx.x; l < d.n; l += stride) {
     u64 x = p[l] + (mi.q << 2) - t[l];  // < 8q
     x = csub(x, mi.q << 2);
     x = csub(x, mi.q << 1);
@@ -103,29 +128,28 @@ static unsigned ks_grid(u64 n) {
   return (unsigned)(b < 65535 ? (b ? b : 1) : 65535);
 }
 
-hipError_t ks_gather_launch(u64* out, const u64* t_target, u64 n, u32 slots, const KsGather& g,
-                            hipStream_t st) {
-  if (slots == 0) return hipSuccess;
-  hipLaunchKernelGGL(ks_gather_kernel, dim3(ks_grid(n), slots), dim3(256), 0, st, out, t_target, n,
-                     g);
+hipError_t ks_gather_launch(u64* ntt_buf, const u64* t_target, const KsDims& d,
+                            const KsGatherAll& g, hipStream_t st) {
+  hipLaunchKernelGGL(ks_gather_kernel, dim3(ks_grid(d.n), d.decomp * d.decomp, d.targets),
+                     dim3(256), 0, st, ntt_buf, t_target, d, g);
   return hipGetLastError();
 }
-hipError_t ks_mac_launch(u64* prod, const u64* t_target_iter, const u64* ntt_buf, u64 n,
-                         u32 components, const KsMac& m, hipStream_t st) {
-  hipLaunchKernelGGL(ks_mac_kernel, dim3(ks_grid(n), components), dim3(256), 0, st, prod,
-                     t_target_iter, ntt_buf, n, m);
+hipError_t ks_mac_launch(u64* prod, const u64* t_target_iter, const u64* ntt_buf, const KsDims& d,
+                         const KsMacAll& m, hipStream_t st) {
+  hipLaunchKernelGGL(ks_mac_kernel, dim3(ks_grid(d.n), d.decomp + 1, d.targets * d.components),
+                     dim3(256), 0, st, prod, t_target_iter, ntt_buf, d, m);
   return hipGetLastError();
 }
-hipError_t ks_round_launch(u64* tbuf, const u64* t_last, u64 n, u32 decomp, const KsRound& r,
+hipError_t ks_round_launch(u64* tbuf, const u64* prod, const KsDims& d, const KsRound& r,
                            hipStream_t st) {
-  hipLaunchKernelGGL(ks_round_kernel, dim3(ks_grid(n), decomp), dim3(256), 0, st, tbuf, t_last, n,
-                     r);
+  hipLaunchKernelGGL(ks_round_kernel, dim3(ks_grid(d.n), d.decomp, d.targets * d.components),
+                     dim3(256), 0, st, tbuf, prod, d, r);
   return hipGetLastError();
 }
-hipError_t ks_finish_launch(u64* result, const u64* prod, const u64* tbuf, u64 n, u32 decomp,
+hipError_t ks_finish_launch(u64* result, const u64* prod, const u64* tbuf, const KsDims& d,
                             const KsFinish& f, hipStream_t st) {
-  hipLaunchKernelGGL(ks_finish_kernel, dim3(ks_grid(n), decomp), dim3(256), 0, st, result, prod,
-                     tbuf, n, f);
+  hipLaunchKernelGGL(ks_finish_kernel, dim3(ks_grid(d.n), d.decomp, d.targets * d.components),
+                     dim3(256), 0, st, result, prod, tbuf, d, f);
   return hipGetLastError();
 }
 

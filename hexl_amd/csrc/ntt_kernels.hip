@@ -451,24 +451,38 @@ strided_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModCons
 // Polynomials of several moduli in one launch (RNS limbs, the per-modulus
 // transforms of KeySwitch): the workgroup's polynomial selects the plan, whose
 // parameters are read from its device-resident copy instead of kernel arguments.
-struct PlanPtrs {
-  const PlanDev* p[kMaxMultiPlans];
-};
 struct MultiCtx {
-  PlanPtrs ptrs;
-  u32 polys_per_plan;
+  const PlanDev* p[kMaxMultiPlans];
+  uint8_t policy[kMaxMultiPlans];  // ArithPolicy of each plan
+  MultiMap map;
 };
+// The plan of polynomial `poly`, or nullptr when it is not of policy `want` (a launch
+// sequence serves one arithmetic policy; workgroups of the others leave at once).
+__device__ __forceinline__ const PlanDev* multi_plan(const MultiCtx& mc, u32 poly, int want) {
+  // (the plan index goes through readfirstlane so that the pointer is fetched with a
+  // cleanly aligned scalar load: left to itself the compiler derived its address from
+  // the byte address of policy[k], base + k plus an offset of 7 k, for an s_load whose
+  // base must be dword aligned -- an aperture violation for k % 4 != 0)
+  const u32 k = __builtin_amdgcn_readfirstlane(
+      (u32)mc.map.plan_tab[(poly / mc.map.inner) % mc.map.period]);
+  const u32 pol = __builtin_amdgcn_readfirstlane((u32)mc.policy[k]);
+  return pol == (u32)want ? mc.p[k] : nullptr;
+}
+template <class A>
+constexpr int policy_id() {
+  return A::kSmall ? kPolicySmall : A::kFp ? kPolicyFp64 : A::kLazy ? kPolicyLazy : kPolicyStrict;
+}
 
 template <bool FWD, int R, class A, bool LAST>
 __global__ void __launch_bounds__(256, (strided_min_waves<R>()))
-strided_pass_multi(u64* out, const u64* in, PlanPtrs ptrs, u32 polys_per_plan, u32 log_n, u32 a0,
-                   u32 flags, u64 items) {
+strided_pass_multi(u64* out, const u64* in, MultiCtx mc, u32 log_n, u32 a0, u32 flags, u64 items) {
   u32 bid = blockIdx.x;
   if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
   if ((u64)bid * 256 + threadIdx.x >= items) return;
   // a workgroup's 4 waves lie in one polynomial (>= 256 columns per polynomial: N >= 2^13)
   const u32 poly = (bid * 4u) >> (log_n - R - 6);
-  const PlanDev* __restrict__ pd = ptrs.p[poly / polys_per_plan];
+  const PlanDev* __restrict__ pd = multi_plan(mc, poly, policy_id<A>());
+  if (!pd) return;
   const ModConst m = pd->mod;
   const InvLast il = pd->il;
   strided_body<FWD, R, A, LAST, kStream, kStream>(out, in, FWD ? pd->fwd : pd->inv, m, log_n, a0,
@@ -909,11 +923,11 @@ tile_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst m
 // a tile lies in one polynomial and no tile is ragged.
 template <bool FWD, int S, int TL, class A, bool LAST>
 __global__ void __launch_bounds__(1 << (TL - kRE), (min_waves<S, 0>()))
-tile_pass_multi(u64* out, const u64* in, PlanPtrs ptrs, u32 polys_per_plan, u32 log_n, u32 flags,
-                u64 total) {
+tile_pass_multi(u64* out, const u64* in, MultiCtx mc, u32 log_n, u32 flags, u64 total) {
   __shared__ u64 lds[1 << TL];
   const u32 poly = (u32)(((u64)blockIdx.x << TL) >> log_n);
-  const PlanDev* __restrict__ pd = ptrs.p[poly / polys_per_plan];
+  const PlanDev* __restrict__ pd = multi_plan(mc, poly, policy_id<A>());
+  if (!pd) return;
   const ModConst m = pd->mod;
   const InvLast il = pd->il;
   tile_body<FWD, S, 0, TL, false, A, LAST, FWD ? kStream : kPlain, FWD ? kStream : kPlain>(
@@ -1190,12 +1204,10 @@ static hipError_t launch_strided(int R, u64* out, const u64* in, const ulonglong
       if (log_n < (u32)RR + 8) return hipErrorNotSupported;                               \
       if (!FWD && a0 == 0)                                                                \
         hipLaunchKernelGGL((strided_pass_multi<FWD, RR, A, !FWD>), dim3(grid), dim3(256), \
-                           0, st, out, in, mc->ptrs, mc->polys_per_plan, log_n, a0,      \
-                           finish, items);                                                \
+                           0, st, out, in, *mc, log_n, a0, finish, items);                \
       else                                                                                \
         hipLaunchKernelGGL((strided_pass_multi<FWD, RR, A, false>), dim3(grid), dim3(256), \
-                           0, st, out, in, mc->ptrs, mc->polys_per_plan, log_n, a0,      \
-                           finish, items);                                                \
+                           0, st, out, in, *mc, log_n, a0, finish, items);                \
     } else if (!FWD && a0 == 0)                                                           \
       hipLaunchKernelGGL((strided_pass<FWD, RR, A, !FWD>), dim3(grid), dim3(256), 0, st, \
                          out, in, tw, m, log_n, a0, finish, items, il);                   \
@@ -1231,7 +1243,7 @@ static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2
       const bool last = !FWD && (u32)S == log_n;
 #define HX_LAUNCH_BM(T, LST)                                                                \
   hipLaunchKernelGGL((tile_pass_multi<FWD, T, TL, A, LST>), dim3(grid), dim3(1 << (TL - kRE)), \
-                     0, st, out, in, mc->ptrs, mc->polys_per_plan, log_n, finish, total)
+                     0, st, out, in, *mc, log_n, finish, total)
       if (S == 11) {
         if constexpr (TL == 11) {
           if (last) HX_LAUNCH_BM(11, !FWD); else HX_LAUNCH_BM(11, false);
@@ -1619,26 +1631,36 @@ static hipError_t multi_impl(bool forward, const NttTables& t0, const MultiCtx& 
 }
 
 hipError_t ntt_multi_launch(bool forward, const NttTables* const* tabs, u32 num_plans,
-                            u64 polys_per_plan, u64* result, const u64* operand, u64 out_mf,
-                            hipStream_t st) {
-  if (num_plans == 0 || polys_per_plan == 0) return hipSuccess;
-  if (num_plans > (u32)kMaxMultiPlans || polys_per_plan >= (1ull << 31)) return hipErrorNotSupported;
+                            const MultiMap& map, u64 polys, u64* result, const u64* operand,
+                            u64 out_mf, hipStream_t st) {
+  if (num_plans == 0 || polys == 0) return hipSuccess;
+  if (num_plans > (u32)kMaxMultiPlans || polys >= (1ull << 31) || map.inner == 0 ||
+      map.period == 0 || map.period > (u32)kMaxMultiPeriod)
+    return hipErrorNotSupported;
   const NttTables& t0 = *tabs[0];
   if (t0.log_n < 12 || t0.log_n > 17) return hipErrorNotSupported;  // one strided + one bottom pass
   MultiCtx mc{};
+  bool have[4] = {false, false, false, false};
   for (u32 k = 0; k < num_plans; ++k) {
-    if (tabs[k]->log_n != t0.log_n || tabs[k]->policy != t0.policy || !tabs[k]->dev)
-      return hipErrorNotSupported;
-    mc.ptrs.p[k] = tabs[k]->dev;
+    if (tabs[k]->log_n != t0.log_n || !tabs[k]->dev) return hipErrorNotSupported;
+    mc.p[k] = tabs[k]->dev;
+    mc.policy[k] = (uint8_t)tabs[k]->policy;
   }
-  mc.polys_per_plan = (u32)polys_per_plan;
-  const u64 polys = (u64)num_plans * polys_per_plan;
-  switch (t0.policy) {
-    case kPolicySmall: return multi_impl<Small>(forward, t0, mc, polys, result, operand, out_mf, st);
-    case kPolicyFp64: return multi_impl<Fp64>(forward, t0, mc, polys, result, operand, out_mf, st);
-    case kPolicyLazy: return multi_impl<Lazy>(forward, t0, mc, polys, result, operand, out_mf, st);
-    default: return multi_impl<Strict>(forward, t0, mc, polys, result, operand, out_mf, st);
+  mc.map = map;
+  for (u32 i = 0; i < map.period; ++i) {
+    if (map.plan_tab[i] >= num_plans) return hipErrorInvalidValue;
+    have[tabs[map.plan_tab[i]]->policy] = true;
   }
+  hipError_t e = hipSuccess;
+  if (have[kPolicySmall] && e == hipSuccess)
+    e = multi_impl<Small>(forward, t0, mc, polys, result, operand, out_mf, st);
+  if (have[kPolicyFp64] && e == hipSuccess)
+    e = multi_impl<Fp64>(forward, t0, mc, polys, result, operand, out_mf, st);
+  if (have[kPolicyLazy] && e == hipSuccess)
+    e = multi_impl<Lazy>(forward, t0, mc, polys, result, operand, out_mf, st);
+  if (have[kPolicyStrict] && e == hipSuccess)
+    e = multi_impl<Strict>(forward, t0, mc, polys, result, operand, out_mf, st);
+  return e;
 }
 
 // The arithmetic policy a plan for modulus q is built for (its tables depend on it).

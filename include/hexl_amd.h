@@ -247,7 +247,20 @@ int hexl_amd_key_switch(uint64_t* result, const uint64_t* t_target_iter_ptr,
                         uint64_t key_component_count, const uint64_t* moduli,
                         const uint64_t* const* k_switch_keys,
                         const uint64_t* modswitch_factors, void* stream);
-/* Same with host buffers everywhere (synchronous). */
+/* Many ciphertexts with the same keys and moduli in one call -- the loop SEAL runs around
+ * KeySwitch (one call per ciphertext, key-switch-internal.cpp:25-201 each time) as ONE
+ * sequence of twelve launches: t_target_iter_ptr holds num_targets targets back to back
+ * (each decomp_modulus_size x n), result num_targets results back to back (each
+ * key_component_count x decomp_modulus_size x n, accumulated into).  Every per-modulus
+ * transform of every target runs in one multi-plan NTT launch.  num_targets *
+ * key_component_count <= 65535. */
+int hexl_amd_key_switch_batch(uint64_t* result, const uint64_t* t_target_iter_ptr,
+                              uint64_t num_targets, uint64_t n,
+                              uint64_t decomp_modulus_size, uint64_t key_modulus_size,
+                              uint64_t rns_modulus_size, uint64_t key_component_count,
+                              const uint64_t* moduli, const uint64_t* const* k_switch_keys,
+                              const uint64_t* modswitch_factors, void* stream);
+/* Same as hexl_amd_key_switch with host buffers everywhere (synchronous). */
 int hexl_amd_key_switch_host(uint64_t* result, const uint64_t* t_target_iter_ptr,
                              uint64_t n, uint64_t decomp_modulus_size,
                              uint64_t key_modulus_size, uint64_t rns_modulus_size,

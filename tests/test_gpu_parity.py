@@ -860,6 +860,33 @@ def test_key_switch_random_vs_oracle(hx, ho, n, D, K, C, bits):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n,D,K,C,T,bits", [(4096, 3, 4, 2, 5, 50), (8192, 4, 5, 2, 3, 54),
+                                            (64, 2, 3, 2, 4, 40), (16384, 7, 8, 2, 2, 45)])
+def test_key_switch_batch_vs_oracle(hx, ho, n, D, K, C, T, bits):
+    """Many ciphertexts with the same keys in one call (one sequence of twelve launches, the
+    per-modulus transforms of all targets in multi-plan NTT launches) against the oracle
+    run target by target; moduli of mixed size, hence of mixed arithmetic policy."""
+    rng = np.random.default_rng(n + D + T)
+    moduli = [int(q) for q in ho.generate_primes(K, bits, True, n)]
+    if D >= 2:
+        moduli[0] = int(ho.generate_primes(1, bits - 8, True, n)[0])
+        moduli[1] = int(ho.generate_primes(1, min(bits + 6, 60), False, n)[0])
+    R = D + 1
+    keys = [np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                            for _ in range(C) for i in range(K)]) for j in range(D)]
+    msf = [int(rng.integers(1, moduli[i], dtype=np.uint64)) for i in range(D)]
+    targets = [np.concatenate([rng.integers(0, moduli[j], n, dtype=np.uint64) for j in range(D)])
+               for _ in range(T)]
+    results = [np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                               for _ in range(C) for i in range(D)]) for _ in range(T)]
+    want = np.concatenate([ho.key_switch(results[t], targets[t], n, D, K, R, C, moduli, keys, msf)
+                           for t in range(T)])
+    d_res = dev(hx, np.concatenate(results))
+    hx.KeySwitchBatch(d_res, dev(hx, np.concatenate(targets)), T, n, D, K, R, C, moduli,
+                      [dev(hx, k) for k in keys], msf)
+    assert np.array_equal(host(hx, d_res), want)
+
+
 def test_key_switch_rejects_bad_arguments(hx, ho):
     n = 16
     q = [int(x) for x in ho.generate_primes(3, 40, True, n)]

@@ -57,6 +57,15 @@ t0 = time.perf_counter()
 want = ho.key_switch(result, target, n, D, K, D + 1, C, moduli, keys, msf)
 tc = time.perf_counter() - t0
 assert np.array_equal(hx.to_numpy(d_r), want)
-t = gpu_time(lambda: hx.KeySwitch(d_r, d_t, n, D, K, D + 1, C, moduli, d_keys, msf), reps=10)
+t = gpu_time(lambda: hx.KeySwitch(d_r, d_t, n, D, K, D + 1, C, moduli, d_keys, msf), reps=20)
 print(f"KeySwitch n={n}, {D} decomposition moduli, {C} key components: GPU {t * 1e6:8.1f} us per call "
-      f"(launch-bound: about {2 * D + (D + 1) * 4 + C * (4 + 2 * D)} kernel launches), oracle 1 thread {tc * 1e3:7.2f} ms")
+      f"(12 launches), oracle 1 thread {tc * 1e3:7.2f} ms")
+# many targets per call
+for T in (4, 16, 64, 256):
+    d_tt = hx.from_numpy(np.tile(target, T))
+    d_rr = hx.from_numpy(np.tile(result, T))
+    hx.KeySwitchBatch(d_rr, d_tt, T, n, D, K, D + 1, C, moduli, d_keys, msf)
+    got = hx.to_numpy(d_rr).reshape(T, -1)
+    assert np.array_equal(got[0], want) and np.array_equal(got[T - 1], want)
+    t = gpu_time(lambda: hx.KeySwitchBatch(d_rr, d_tt, T, n, D, K, D + 1, C, moduli, d_keys, msf), reps=10)
+    print(f"KeySwitchBatch {T:4d} targets: GPU {t * 1e6:9.1f} us per call = {t * 1e6 / T:7.1f} us per target")

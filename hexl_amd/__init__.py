@@ -29,7 +29,7 @@ _LIB_PATH = os.environ.get("HEXL_AMD_LIB") or os.path.join(_HERE, "lib", "libhex
 __all__ = [
     "NTT", "EltwiseAddMod", "EltwiseSubMod", "EltwiseMultMod", "EltwiseFMAMod",
     "EltwiseReduceMod", "EltwiseReduceFMAMod", "EltwiseCmpAdd", "EltwiseCmpSubMod", "CMPINT", "DyadicMultiply", "KeySwitch",
-    "KeySwitchBatch",
+    "KeySwitchBatch", "DyadicMultiplyBatch",
     "HexlAmdError", "lib", "LIB_PATH",
     "MinimalPrimitiveRoot", "GeneratePrimes", "IsPrime", "InverseMod", "MultiplyMod",
     "PowMod", "IsPrimitiveRoot", "ReverseBits", "MultiplyFactor", "fill_splitmix",
@@ -82,6 +82,7 @@ def _load():
     sig("hexl_amd_eltwise_reduce_fma_mod", ci, p64, p64, u64, p64, u64, u64, u64, vp)
     sig("hexl_amd_eltwise_host", ci, ci, p64, p64, p64, u64, u64, u64, u64, u64)
     sig("hexl_amd_dyadic_multiply", ci, p64, p64, p64, u64, C.POINTER(u64), u64, vp)
+    sig("hexl_amd_dyadic_multiply_batch", ci, p64, p64, p64, u64, u64, C.POINTER(u64), u64, vp)
     sig("hexl_amd_dyadic_multiply_host", ci, p64, p64, p64, u64, C.POINTER(u64), u64)
     sig("hexl_amd_key_switch", ci, p64, p64, u64, u64, u64, u64, u64, C.POINTER(u64),
         C.POINTER(vp), C.POINTER(u64), vp)
@@ -126,7 +127,7 @@ C_ABI_SYMBOLS = [
     "hexl_amd_eltwise_sub_mod_scalar", "hexl_amd_eltwise_mult_mod", "hexl_amd_eltwise_fma_mod",
     "hexl_amd_eltwise_reduce_mod", "hexl_amd_eltwise_reduce_fma_mod", "hexl_amd_eltwise_host",
     "hexl_amd_eltwise_cmp_add", "hexl_amd_eltwise_cmp_sub_mod", "hexl_amd_eltwise_cmp_host",
-    "hexl_amd_dyadic_multiply", "hexl_amd_dyadic_multiply_host",
+    "hexl_amd_dyadic_multiply", "hexl_amd_dyadic_multiply_batch", "hexl_amd_dyadic_multiply_host",
     "hexl_amd_key_switch", "hexl_amd_key_switch_batch", "hexl_amd_key_switch_host",
     "hexl_amd_multiply_factor", "hexl_amd_inverse_mod", "hexl_amd_multiply_mod",
     "hexl_amd_pow_mod", "hexl_amd_is_primitive_root", "hexl_amd_generate_primitive_root",
@@ -396,6 +397,15 @@ def DyadicMultiply(result, operand1, operand2, n, moduli):
     k = n * len(moduli)
     _check(lib.hexl_amd_dyadic_multiply(_ptr(result, 3 * k), _ptr(operand1, 2 * k), _ptr(operand2, 2 * k), n, arr,
                                         len(moduli), _stream()))
+
+
+def DyadicMultiplyBatch(result, operand1, operand2, num_pairs, n, moduli):
+    """num_pairs ciphertext pairs with the same moduli in one launch."""
+    arr = (C.c_uint64 * len(moduli))(*[int(m) for m in moduli])
+    k = n * len(moduli) * num_pairs
+    _check(lib.hexl_amd_dyadic_multiply_batch(_ptr(result, 3 * k), _ptr(operand1, 2 * k),
+                                              _ptr(operand2, 2 * k), num_pairs, n, arr,
+                                              len(moduli), _stream()))
 
 
 def KeySwitch(result, t_target_iter, n, decomp_modulus_size, key_modulus_size, rns_modulus_size,

@@ -636,8 +636,20 @@ int hexl_amd_dyadic_multiply(uint64_t* result, const uint64_t* operand1, const u
                              void* stream) {
   if (int rc = check_dyadic(result, operand1, operand2, n, moduli, num_moduli)) return rc;
   if (num_moduli == 0) return HEXL_AMD_OK;
-  hipError_t e = dyadic_multiply_launch(result, operand1, operand2, n, moduli, num_moduli,
+  hipError_t e = dyadic_multiply_launch(result, operand1, operand2, n, moduli, num_moduli, 1,
                                         (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "dyadic multiply launch");
+  return HEXL_AMD_OK;
+}
+
+int hexl_amd_dyadic_multiply_batch(uint64_t* result, const uint64_t* operand1,
+                                   const uint64_t* operand2, uint64_t num_pairs, uint64_t n,
+                                   const uint64_t* moduli, uint64_t num_moduli, void* stream) {
+  if (int rc = check_dyadic(result, operand1, operand2, n, moduli, num_moduli)) return rc;
+  if (num_moduli == 0 || num_pairs == 0) return HEXL_AMD_OK;
+  if (num_pairs > 65535) return fail(HEXL_AMD_ERR_INVALID_ARG, "num_pairs must be <= 65535");
+  hipError_t e = dyadic_multiply_launch(result, operand1, operand2, n, moduli, num_moduli,
+                                        num_pairs, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "dyadic multiply launch");
   return HEXL_AMD_OK;
 }
@@ -661,7 +673,7 @@ int hexl_amd_dyadic_multiply_host(uint64_t* result, const uint64_t* operand1,
   // coefficients the reference leaves untouched (n > 512 not a multiple of 512) keep
   // whatever the caller's result buffer holds
   HX_HIP(hipMemcpyAsync(dr, result, 3 * poly, hipMemcpyHostToDevice, st));
-  hipError_t e = dyadic_multiply_launch(dr, dx, dy, n, moduli, num_moduli, st);
+  hipError_t e = dyadic_multiply_launch(dr, dx, dy, n, moduli, num_moduli, 1, st);
   if (e != hipSuccess) return hip_fail(e, "dyadic multiply launch");
   HX_HIP(hipMemcpyAsync(result, dr, 3 * poly, hipMemcpyDeviceToHost, st));
   HX_HIP(hipStreamSynchronize(st));

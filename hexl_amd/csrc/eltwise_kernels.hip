@@ -301,6 +301,10 @@ struct DyadicModuli {
 __global__ void __launch_bounds__(256)
 dyadic_multiply_kernel(u64* res, const u64* x, const u64* y, u64 n, u64 n_proc, u64 poly_size,
                        u64 first_modulus, DyadicModuli mods) {
+  // blockIdx.z = ciphertext pair of a batched call: operands are 2, results 3 polynomials
+  x += (u64)blockIdx.z * 2 * poly_size;
+  y += (u64)blockIdx.z * 2 * poly_size;
+  res += (u64)blockIdx.z * 3 * poly_size;
   const MultOp op = mods.mult[blockIdx.y];
   const u64 base = (first_modulus + blockIdx.y) * n;
   const u64 stride = (u64)gridDim.x * 256;
@@ -325,7 +329,8 @@ static MultOp make_mult_op(u64 q, u64 in_mf) {
 }
 
 hipError_t dyadic_multiply_launch(u64* result, const u64* op1, const u64* op2, u64 n,
-                                  const u64* moduli, u64 num_moduli, hipStream_t st) {
+                                  const u64* moduli, u64 num_moduli, u64 pairs,
+                                  hipStream_t st) {
   // dyadic-multiply-internal.cpp:33-34: whole tiles of min(n, 512) coefficients
   const u64 tile = n < 512 ? n : 512;
   const u64 n_proc = (n / tile) * tile;
@@ -339,8 +344,8 @@ hipError_t dyadic_multiply_launch(u64* result, const u64* op1, const u64* op2, u
     for (u64 i = count; i < kDyadicModuliPerLaunch; ++i) mods.mult[i] = mods.mult[0];
     unsigned gx = grid_for(n_proc);
     if (gx > 65535u * 16) gx = 65535u * 16;
-    hipLaunchKernelGGL(dyadic_multiply_kernel, dim3(gx, (unsigned)count), dim3(256), 0, st, result,
-                       op1, op2, n, n_proc, poly_size, first, mods);
+    hipLaunchKernelGGL(dyadic_multiply_kernel, dim3(gx, (unsigned)count, (unsigned)pairs),
+                       dim3(256), 0, st, result, op1, op2, n, n_proc, poly_size, first, mods);
   }
   return hipGetLastError();
 }

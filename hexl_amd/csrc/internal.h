@@ -139,8 +139,10 @@ struct EltArgs {
 };
 
 hipError_t eltwise_launch(EltOp op, const EltArgs& args, hipStream_t st);
+// `pairs` ciphertext pairs back to back (operands 2, results 3 polynomials of n * num_moduli)
 hipError_t dyadic_multiply_launch(u64* result, const u64* op1, const u64* op2, u64 n,
-                                  const u64* moduli_host, u64 num_moduli, hipStream_t st);
+                                  const u64* moduli_host, u64 num_moduli, u64 pairs,
+                                  hipStream_t st);
 // ---- KeySwitch stages (keyswitch_kernels.hip), batched over `targets` ciphertexts that
 // share keys and moduli.  Argument blocks travel as kernel arguments, so the number of
 // decomposition moduli per call is bounded.  Buffer layouts (polynomials of n words):

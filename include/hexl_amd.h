@@ -226,7 +226,14 @@ int hexl_amd_dyadic_multiply(uint64_t* result, const uint64_t* operand1,
                              const uint64_t* operand2, uint64_t n,
                              const uint64_t* moduli, uint64_t num_moduli,
                              void* stream);
-/* Same with host buffers (synchronous). */
+/* num_pairs ciphertext pairs with the same moduli in one launch: operands hold num_pairs
+ * x 2 polynomials, result num_pairs x 3 (the loop a caller runs around DyadicMultiply).
+ * num_pairs <= 65535. */
+int hexl_amd_dyadic_multiply_batch(uint64_t* result, const uint64_t* operand1,
+                                   const uint64_t* operand2, uint64_t num_pairs, uint64_t n,
+                                   const uint64_t* moduli, uint64_t num_moduli,
+                                   void* stream);
+/* Same as hexl_amd_dyadic_multiply with host buffers (synchronous). */
 int hexl_amd_dyadic_multiply_host(uint64_t* result, const uint64_t* operand1,
                                   const uint64_t* operand2, uint64_t n,
                                   const uint64_t* moduli, uint64_t num_moduli);

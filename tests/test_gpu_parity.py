@@ -816,6 +816,26 @@ def test_dyadic_multiply_rejects_bad_arguments(hx):
         hx.DyadicMultiply(d, d, d, 3, [1 << 62])
 
 
+def test_dyadic_multiply_batch(hx, ho):
+    """Several ciphertext pairs per launch against the oracle pair by pair (n = 1000: the
+    reference processes whole 512-coefficient tiles only and leaves the tail untouched)."""
+    rng = np.random.default_rng(5)
+    for n, k, pairs in ((4096, 3, 5), (1000, 2, 3)):
+        moduli = [int(q) for q in ho.generate_primes(k, 50, True, 4096)]
+        xs = [np.concatenate([rng.integers(0, q, n, dtype=np.uint64) for q in moduli] * 2)
+              for _ in range(pairs)]
+        ys = [np.concatenate([rng.integers(0, q, n, dtype=np.uint64) for q in moduli] * 2)
+              for _ in range(pairs)]
+        out = dev(hx, np.full(3 * n * k * pairs, 7, dtype=np.uint64))
+        hx.DyadicMultiplyBatch(out, dev(hx, np.concatenate(xs)), dev(hx, np.concatenate(ys)),
+                               pairs, n, moduli)
+        got = host(hx, out).reshape(pairs, -1)
+        for p in range(pairs):
+            want = ho.dyadic_multiply(xs[p], ys[p], n, moduli,
+                                      result=np.full(3 * n * k, 7, dtype=np.uint64))
+            assert np.array_equal(got[p], want)
+
+
 # ---------------------------------------------------------------- KeySwitch
 def _run_key_switch(hx, result, target, n, D, K, R, C, moduli, keys, msf):
     d_res = dev(hx, result)

@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -70,6 +71,7 @@ struct Staging {
   void* buf = nullptr;
   size_t cap = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;  // second lane of the pipelined host path
   ~Staging() {
     // Process teardown may already have destroyed the HIP runtime; leak.
   }
@@ -79,17 +81,21 @@ struct Staging {
       if (device >= 0 && (buf || stream)) {  // release what belongs to the previous device
         if (hipSetDevice(device) == hipSuccess) {
           if (stream) (void)hipStreamSynchronize(stream);
+          if (stream2) (void)hipStreamSynchronize(stream2);
           if (buf) (void)hipFree(buf);
           if (stream) (void)hipStreamDestroy(stream);
+          if (stream2) (void)hipStreamDestroy(stream2);
         }
         HX_HIP(hipSetDevice(dev));
       }
       buf = nullptr;
       cap = 0;
       stream = nullptr;
+      stream2 = nullptr;
       device = dev;
     }
     if (!stream) HX_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (!stream2) HX_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
     if (cap < bytes) {
       if (buf) HX_HIP(hipFree(buf));
       buf = nullptr;
@@ -428,23 +434,84 @@ int hexl_amd_ntt_inverse_rns(const hexl_amd_ntt* const* plans, uint64_t num_plan
                      stream);
 }
 
+// Host buffers (what an unmodified intel::hexl caller hands over): stage to the device,
+// transform, copy back.  Optionally (HEXL_AMD_HOST_PIPELINE_MIN_MB=<size>) large calls are
+// cut into chunks that alternate between two streams, each with its own device staging
+// buffer, the caller's pages pinned for the duration of the call (hipHostRegister), so
+// that the H2D copy of chunk k+1 runs under the kernels and the D2H copy of chunk k.
+// Off by default: on the MI355X boxes of this pool the link moves 53 GB/s in one direction
+// and 53 GB/s in both directions together, from pageable memory as fast as from pinned
+// (tools/pcie_probe.py), so the plain sequence below already runs at the link rate
+// (54-55 GB/s in+out, tools/host_path_rate.py) and pipelining gains nothing.
+static size_t host_pipeline_min_bytes() {
+  static const size_t v = [] {
+    const char* e = getenv("HEXL_AMD_HOST_PIPELINE_MIN_MB");
+    return e && atol(e) > 0 ? (size_t)atol(e) << 20 : ~(size_t)0;
+  }();
+  return v;
+}
+static size_t host_chunk_bytes() {
+  static const size_t v = [] {
+    const char* e = getenv("HEXL_AMD_HOST_CHUNK_MB");
+    return (size_t)(e && atol(e) > 0 ? atol(e) : 16) << 20;
+  }();
+  return v;
+}
+
 static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t* operand,
                         uint64_t batch, bool forward, uint64_t in_mf, uint64_t out_mf) {
   if (int rc = check_ntt_args(p, result, operand, forward, in_mf, out_mf)) return rc;
   if (batch == 0) return HEXL_AMD_OK;
   DeviceScope scope(p->device);
   if (scope.err != hipSuccess) return hip_fail(scope.err, "hipSetDevice");
-  const size_t bytes = (size_t)batch * p->n * sizeof(u64);
-  if (int rc = g_staging.ensure(p->device, bytes)) return rc;
-  u64* d = (u64*)g_staging.buf;
-  hipStream_t st = g_staging.stream;
-  HX_HIP(hipMemcpyAsync(d, operand, bytes, hipMemcpyHostToDevice, st));
-  hipError_t e = forward ? ntt_forward_launch(p->t, d, d, batch, out_mf, st)
-                         : ntt_inverse_launch(p->t, d, d, batch, out_mf, st);
-  if (e != hipSuccess) return hip_fail(e, "NTT launch");
-  HX_HIP(hipMemcpyAsync(result, d, bytes, hipMemcpyDeviceToHost, st));
-  HX_HIP(hipStreamSynchronize(st));
-  return HEXL_AMD_OK;
+  const size_t poly_bytes = (size_t)p->n * sizeof(u64);
+  const size_t bytes = (size_t)batch * poly_bytes;
+  auto run = [&](u64* d, u64 polys, hipStream_t st) {
+    return forward ? ntt_forward_launch(p->t, d, d, polys, out_mf, st)
+                   : ntt_inverse_launch(p->t, d, d, polys, out_mf, st);
+  };
+  if (bytes < host_pipeline_min_bytes() || batch < 4) {
+    if (int rc = g_staging.ensure(p->device, bytes)) return rc;
+    u64* d = (u64*)g_staging.buf;
+    hipStream_t st = g_staging.stream;
+    HX_HIP(hipMemcpyAsync(d, operand, bytes, hipMemcpyHostToDevice, st));
+    hipError_t e = run(d, batch, st);
+    if (e != hipSuccess) return hip_fail(e, "NTT launch");
+    HX_HIP(hipMemcpyAsync(result, d, bytes, hipMemcpyDeviceToHost, st));
+    HX_HIP(hipStreamSynchronize(st));
+    return HEXL_AMD_OK;
+  }
+  u64 chunk_polys = host_chunk_bytes() / poly_bytes;
+  if (chunk_polys == 0) chunk_polys = 1;
+  if (chunk_polys > (batch + 1) / 2) chunk_polys = (batch + 1) / 2;  // at least two chunks
+  const size_t chunk_bytes = (size_t)chunk_polys * poly_bytes;
+  if (int rc = g_staging.ensure(p->device, 2 * chunk_bytes)) return rc;
+  u64* dbuf[2] = {(u64*)g_staging.buf, (u64*)g_staging.buf + chunk_polys * p->n};
+  hipStream_t st[2] = {g_staging.stream, g_staging.stream2};
+  // pin the caller's pages so that the copies are asynchronous DMA
+  const bool pin_in = hipHostRegister((void*)operand, bytes, hipHostRegisterDefault) == hipSuccess;
+  const bool pin_out = (const void*)result == (const void*)operand
+                           ? false
+                           : hipHostRegister((void*)result, bytes, hipHostRegisterDefault) == hipSuccess;
+  if (!pin_in || (!pin_out && (const void*)result != (const void*)operand)) (void)hipGetLastError();
+  int rc = HEXL_AMD_OK;
+  for (u64 first = 0, k = 0; first < batch && rc == HEXL_AMD_OK; first += chunk_polys, ++k) {
+    const u64 polys = batch - first < chunk_polys ? batch - first : chunk_polys;
+    const size_t cb = (size_t)polys * poly_bytes;
+    const int lane = (int)(k & 1);
+    hipError_t e = hipMemcpyAsync(dbuf[lane], operand + first * p->n, cb, hipMemcpyHostToDevice,
+                                  st[lane]);
+    if (e == hipSuccess) e = run(dbuf[lane], polys, st[lane]);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(result + first * p->n, dbuf[lane], cb, hipMemcpyDeviceToHost, st[lane]);
+    if (e != hipSuccess) rc = hip_fail(e, "pipelined host NTT");
+  }
+  hipError_t e0 = hipStreamSynchronize(st[0]), e1 = hipStreamSynchronize(st[1]);
+  if (pin_in) (void)hipHostUnregister((void*)operand);
+  if (pin_out) (void)hipHostUnregister((void*)result);
+  if (rc == HEXL_AMD_OK && e0 != hipSuccess) rc = hip_fail(e0, "hipStreamSynchronize");
+  if (rc == HEXL_AMD_OK && e1 != hipSuccess) rc = hip_fail(e1, "hipStreamSynchronize");
+  return rc;
 }
 
 int hexl_amd_ntt_forward_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t* operand,

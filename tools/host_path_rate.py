@@ -12,7 +12,7 @@ import hexl_amd as hx  # noqa: E402
 
 N, q = 65536, 18014398510661633
 ntt = hx.NTT(N, q)
-for batch in (1, 16, 256):
+for batch in (1, 16, 64, 256, 1024):
     x = np.random.default_rng(1).integers(0, q, (batch, N), dtype=np.uint64)
     ref = x.copy()
     p = x.ctypes.data_as(C.c_void_p)

@@ -6,9 +6,13 @@
  * inv-ntt-avx512.cpp), not a scalar one.  It is NOT a copy of that path: the
  * butterfly network, twiddle indexing and ranges are exactly those of
  * ho_ntt_forward_radix2 / ho_ntt_inverse_radix2 (the reference's native
- * algorithm, ntt-radix-2.cpp:17-261, :330-519), with the stages whose butterfly
- * gap is >= 8 executed 8 butterflies at a time and the three gap-4/2/1 stages
- * left scalar.  Every intermediate is the same value as in the scalar code, so
+ * algorithm, ntt-radix-2.cpp:17-261, :330-519), executed 8 butterflies at a
+ * time: the stages whose butterfly gap is >= 8 straight from memory, the gap-4 /
+ * 2 / 1 stages on two vectors at a time with in-register permutations and
+ * per-lane twiddles, and -- as the reference's production path does above N =
+ * 1024 (fwd-ntt-avx512.cpp:384-403, inv-ntt-avx512.cpp:318-345) -- depth first
+ * once a sub-transform fits the L1 data cache (blocks of 2048 coefficients =
+ * 16 KiB).  Every intermediate is the same value as in the scalar code, so
  * outputs are bit-identical to it for every (in_mf, out_mf)
  * (tests/test_oracle_kat.py::test_avx512_variant_matches_scalar).
  */
@@ -52,6 +56,105 @@ static inline uint64_t mul_lazy1(uint64_t y, uint64_t W, uint64_t Wp, uint64_t q
   return y * W - ho_mul_hi64(y, Wp) * q;
 }
 
+#define HO_BLOCK 2048u /* coefficients of a depth-first block */
+
+HO_AVX512 static inline __m512i idx8(long long a, long long b, long long c, long long d,
+                                     long long e, long long f, long long g, long long h) {
+  return _mm512_setr_epi64(a, b, c, d, e, f, g, h);
+}
+
+/* Per-lane twiddles of a stage with gap t in {1, 2, 4}: the 8 lanes of a vector pair
+ * cover 8 / t consecutive groups, each twiddle repeated t times. */
+HO_AVX512 static inline __m512i lane_twiddles(const uint64_t* w, uint64_t t) {
+  if (t == 1) return _mm512_loadu_si512((const void*)w);
+  if (t == 2)
+    return _mm512_permutexvar_epi64(idx8(0, 0, 1, 1, 2, 2, 3, 3),
+                                    _mm512_zextsi256_si512(_mm256_loadu_si256((const void*)w)));
+  return _mm512_permutexvar_epi64(idx8(0, 0, 0, 0, 1, 1, 1, 1),
+                                  _mm512_zextsi128_si512(_mm_loadu_si128((const void*)w)));
+}
+
+/* Two consecutive vectors A, B (16 coefficients) of a stage with gap t in {1, 2, 4}:
+ * X = the first elements of the 8 butterflies, Y = the second ones; and back. */
+HO_AVX512 static inline void split_xy(__m512i A, __m512i B, uint64_t t, __m512i* X, __m512i* Y) {
+  if (t == 4) {
+    *X = _mm512_permutex2var_epi64(A, idx8(0, 1, 2, 3, 8, 9, 10, 11), B);
+    *Y = _mm512_permutex2var_epi64(A, idx8(4, 5, 6, 7, 12, 13, 14, 15), B);
+  } else if (t == 2) {
+    *X = _mm512_permutex2var_epi64(A, idx8(0, 1, 4, 5, 8, 9, 12, 13), B);
+    *Y = _mm512_permutex2var_epi64(A, idx8(2, 3, 6, 7, 10, 11, 14, 15), B);
+  } else {
+    *X = _mm512_permutex2var_epi64(A, idx8(0, 2, 4, 6, 8, 10, 12, 14), B);
+    *Y = _mm512_permutex2var_epi64(A, idx8(1, 3, 5, 7, 9, 11, 13, 15), B);
+  }
+}
+HO_AVX512 static inline void merge_xy(__m512i X, __m512i Y, uint64_t t, __m512i* A, __m512i* B) {
+  if (t == 4) {
+    *A = _mm512_permutex2var_epi64(X, idx8(0, 1, 2, 3, 8, 9, 10, 11), Y);
+    *B = _mm512_permutex2var_epi64(X, idx8(4, 5, 6, 7, 12, 13, 14, 15), Y);
+  } else if (t == 2) {
+    *A = _mm512_permutex2var_epi64(X, idx8(0, 1, 8, 9, 2, 3, 10, 11), Y);
+    *B = _mm512_permutex2var_epi64(X, idx8(4, 5, 12, 13, 6, 7, 14, 15), Y);
+  } else {
+    *A = _mm512_permutex2var_epi64(X, idx8(0, 8, 1, 9, 2, 10, 3, 11), Y);
+    *B = _mm512_permutex2var_epi64(X, idx8(4, 12, 5, 13, 6, 14, 7, 15), Y);
+  }
+}
+
+/* One forward stage (m groups in the whole transform, gap t = n / 2m) over the
+ * coefficients [first, first + count) -- whole groups --, reading src, writing dst. */
+HO_AVX512 static void fwd_stage(uint64_t* dst, const uint64_t* src, uint64_t first, uint64_t count,
+                                uint64_t m, uint64_t t, uint64_t q, const uint64_t* W,
+                                const uint64_t* Wp) {
+  const uint64_t two_q = q << 1;
+  const __m512i vq = _mm512_set1_epi64((long long)q), v2q = _mm512_set1_epi64((long long)two_q);
+  const uint64_t g0 = first / (2 * t), groups = count / (2 * t);
+  if (t >= 8) {
+    for (uint64_t g = 0; g < groups; ++g) {
+      const __m512i vW = _mm512_set1_epi64((long long)W[m + g0 + g]);
+      const __m512i vWp = _mm512_set1_epi64((long long)Wp[m + g0 + g]);
+      const uint64_t off = first + g * 2 * t;
+      for (uint64_t j = 0; j < t; j += 8) {
+        const uint64_t a = off + j, b = a + t;
+        __m512i X = _mm512_loadu_si512((const void*)(src + a));
+        __m512i Y = _mm512_loadu_si512((const void*)(src + b));
+        __m512i tx = csub8(X, v2q);
+        __m512i T = mul_lazy8(Y, vW, vWp, vq);
+        _mm512_storeu_si512((void*)(dst + a), _mm512_add_epi64(tx, T));
+        _mm512_storeu_si512((void*)(dst + b), _mm512_sub_epi64(_mm512_add_epi64(tx, v2q), T));
+      }
+    }
+    return;
+  }
+  uint64_t e = 0; /* coefficients done */
+  if (count >= 16) {
+    for (; e + 16 <= count; e += 16) {
+      const uint64_t g = g0 + e / (2 * t);
+      __m512i A = _mm512_loadu_si512((const void*)(src + first + e));
+      __m512i B = _mm512_loadu_si512((const void*)(src + first + e + 8));
+      __m512i X, Y;
+      split_xy(A, B, t, &X, &Y);
+      const __m512i vW = lane_twiddles(W + m + g, t), vWp = lane_twiddles(Wp + m + g, t);
+      __m512i tx = csub8(X, v2q);
+      __m512i T = mul_lazy8(Y, vW, vWp, vq);
+      merge_xy(_mm512_add_epi64(tx, T), _mm512_sub_epi64(_mm512_add_epi64(tx, v2q), T), t, &A, &B);
+      _mm512_storeu_si512((void*)(dst + first + e), A);
+      _mm512_storeu_si512((void*)(dst + first + e + 8), B);
+    }
+  }
+  for (; e < count; e += 2 * t) { /* fewer than 16 coefficients: scalar */
+    const uint64_t g = g0 + e / (2 * t);
+    for (uint64_t j = 0; j < t; ++j) {
+      const uint64_t a = first + e + j, b = a + t;
+      const uint64_t x = src[a], y = src[b];
+      const uint64_t tx = (x >= two_q) ? x - two_q : x;
+      const uint64_t T = mul_lazy1(y, W[m + g], Wp[m + g], q);
+      dst[a] = tx + T;
+      dst[b] = tx + two_q - T;
+    }
+  }
+}
+
 HO_AVX512 void ho_ntt_forward_radix2_avx512(uint64_t* result, const uint64_t* operand,
                                             uint64_t n, uint64_t q,
                                             const uint64_t* root_pows,
@@ -60,38 +163,23 @@ HO_AVX512 void ho_ntt_forward_radix2_avx512(uint64_t* result, const uint64_t* op
   (void)in_mf;
   const uint64_t two_q = q << 1;
   const __m512i vq = _mm512_set1_epi64((long long)q), v2q = _mm512_set1_epi64((long long)two_q);
-  uint64_t t = n >> 1;
   const uint64_t* src = operand;
-  for (uint64_t m = 1; m < n; m <<= 1) {
-    uint64_t offset = 0;
-    for (uint64_t i = 0; i < m; ++i) {
-      const uint64_t W = root_pows[m + i], Wp = precon_root_pows[m + i];
-      if (t >= 8) {
-        const __m512i vW = _mm512_set1_epi64((long long)W), vWp = _mm512_set1_epi64((long long)Wp);
-        for (uint64_t j = 0; j < t; j += 8) {
-          const uint64_t a = offset + j, b = a + t;
-          __m512i X = _mm512_loadu_si512((const void*)(src + a));
-          __m512i Y = _mm512_loadu_si512((const void*)(src + b));
-          __m512i tx = csub8(X, v2q);
-          __m512i T = mul_lazy8(Y, vW, vWp, vq);
-          _mm512_storeu_si512((void*)(result + a), _mm512_add_epi64(tx, T));
-          _mm512_storeu_si512((void*)(result + b),
-                              _mm512_sub_epi64(_mm512_add_epi64(tx, v2q), T));
-        }
-      } else {
-        for (uint64_t j = 0; j < t; ++j) {
-          const uint64_t a = offset + j, b = a + t;
-          const uint64_t x = src[a], y = src[b];
-          const uint64_t tx = (x >= two_q) ? x - two_q : x;
-          const uint64_t T = mul_lazy1(y, W, Wp, q);
-          result[a] = tx + T;
-          result[b] = tx + two_q - T;
-        }
-      }
-      offset += (t << 1);
-    }
-    t >>= 1;
+  /* breadth first while a group is larger than a block ... */
+  uint64_t m = 1, t = n >> 1;
+  for (; m < n && 2 * t > HO_BLOCK; m <<= 1, t >>= 1) {
+    fwd_stage(result, src, 0, n, m, t, q, root_pows, precon_root_pows);
     src = result;
+  }
+  /* ... then every block through all remaining stages while it sits in L1 */
+  if (m < n) {
+    const uint64_t block = 2 * t;
+    for (uint64_t first = 0; first < n; first += block) {
+      const uint64_t* s = src;
+      for (uint64_t mm = m, tt = t; mm < n; mm <<= 1, tt >>= 1) {
+        fwd_stage(result, s, first, block, mm, tt, q, root_pows, precon_root_pows);
+        s = result;
+      }
+    }
   }
   if (out_mf == 1) {
     uint64_t i = 0;
@@ -108,6 +196,59 @@ HO_AVX512 void ho_ntt_forward_radix2_avx512(uint64_t* result, const uint64_t* op
   }
 }
 
+/* One inverse stage (m groups, gap t = n / 2m; the stage's first twiddle is
+ * inv_root_pows[root0], group g uses root0 + g) over [first, first + count). */
+HO_AVX512 static void inv_stage(uint64_t* dst, const uint64_t* src, uint64_t first, uint64_t count,
+                                uint64_t root0, uint64_t t, uint64_t q, const uint64_t* W,
+                                const uint64_t* Wp) {
+  const uint64_t two_q = q << 1;
+  const __m512i vq = _mm512_set1_epi64((long long)q), v2q = _mm512_set1_epi64((long long)two_q);
+  const uint64_t g0 = first / (2 * t), groups = count / (2 * t);
+  if (t >= 8) {
+    for (uint64_t g = 0; g < groups; ++g) {
+      const __m512i vW = _mm512_set1_epi64((long long)W[root0 + g0 + g]);
+      const __m512i vWp = _mm512_set1_epi64((long long)Wp[root0 + g0 + g]);
+      const uint64_t off = first + g * 2 * t;
+      for (uint64_t j = 0; j < t; j += 8) {
+        const uint64_t a = off + j, b = a + t;
+        __m512i X = _mm512_loadu_si512((const void*)(src + a));
+        __m512i Y = _mm512_loadu_si512((const void*)(src + b));
+        __m512i s = _mm512_add_epi64(X, Y);
+        __m512i d = _mm512_sub_epi64(_mm512_add_epi64(X, v2q), Y);
+        _mm512_storeu_si512((void*)(dst + a), csub8(s, v2q));
+        _mm512_storeu_si512((void*)(dst + b), mul_lazy8(d, vW, vWp, vq));
+      }
+    }
+    return;
+  }
+  uint64_t e = 0;
+  if (count >= 16) {
+    for (; e + 16 <= count; e += 16) {
+      const uint64_t g = root0 + g0 + e / (2 * t);
+      __m512i A = _mm512_loadu_si512((const void*)(src + first + e));
+      __m512i B = _mm512_loadu_si512((const void*)(src + first + e + 8));
+      __m512i X, Y;
+      split_xy(A, B, t, &X, &Y);
+      const __m512i vW = lane_twiddles(W + g, t), vWp = lane_twiddles(Wp + g, t);
+      __m512i s = _mm512_add_epi64(X, Y);
+      __m512i d = _mm512_sub_epi64(_mm512_add_epi64(X, v2q), Y);
+      merge_xy(csub8(s, v2q), mul_lazy8(d, vW, vWp, vq), t, &A, &B);
+      _mm512_storeu_si512((void*)(dst + first + e), A);
+      _mm512_storeu_si512((void*)(dst + first + e + 8), B);
+    }
+  }
+  for (; e < count; e += 2 * t) {
+    const uint64_t g = root0 + g0 + e / (2 * t);
+    for (uint64_t j = 0; j < t; ++j) {
+      const uint64_t a = first + e + j, b = a + t;
+      const uint64_t x = src[a], y = src[b];
+      const uint64_t s = x + y, d = x + two_q - y;
+      dst[a] = (s >= two_q) ? s - two_q : s;
+      dst[b] = mul_lazy1(d, W[g], Wp[g], q);
+    }
+  }
+}
+
 HO_AVX512 void ho_ntt_inverse_radix2_avx512(uint64_t* result, const uint64_t* operand,
                                             uint64_t n, uint64_t q,
                                             const uint64_t* inv_root_pows,
@@ -117,36 +258,30 @@ HO_AVX512 void ho_ntt_inverse_radix2_avx512(uint64_t* result, const uint64_t* op
   const uint64_t two_q = q << 1;
   const __m512i vq = _mm512_set1_epi64((long long)q), v2q = _mm512_set1_epi64((long long)two_q);
   const uint64_t n_div_2 = n >> 1;
-  uint64_t t = 1, root_index = 1;
+  /* the stage with m groups (gap t = n / 2m) starts at root index 1 + (n/2 - m) * 2 ... i.e.
+   * the stages m = n/2, n/4, ..., 2 use n/2, n/4, ... consecutive twiddles from index 1 on */
   const uint64_t* src = operand;
-  for (uint64_t m = n_div_2; m > 1; m >>= 1) {
-    uint64_t offset = 0;
-    for (uint64_t i = 0; i < m; ++i, ++root_index) {
-      const uint64_t W = inv_root_pows[root_index], Wp = precon_inv_root_pows[root_index];
-      if (t >= 8) {
-        const __m512i vW = _mm512_set1_epi64((long long)W), vWp = _mm512_set1_epi64((long long)Wp);
-        for (uint64_t j = 0; j < t; j += 8) {
-          const uint64_t a = offset + j, b = a + t;
-          __m512i X = _mm512_loadu_si512((const void*)(src + a));
-          __m512i Y = _mm512_loadu_si512((const void*)(src + b));
-          __m512i s = _mm512_add_epi64(X, Y);
-          __m512i d = _mm512_sub_epi64(_mm512_add_epi64(X, v2q), Y);
-          _mm512_storeu_si512((void*)(result + a), csub8(s, v2q));
-          _mm512_storeu_si512((void*)(result + b), mul_lazy8(d, vW, vWp, vq));
-        }
-      } else {
-        for (uint64_t j = 0; j < t; ++j) {
-          const uint64_t a = offset + j, b = a + t;
-          const uint64_t x = src[a], y = src[b];
-          const uint64_t s = x + y, d = x + two_q - y;
-          result[a] = (s >= two_q) ? s - two_q : s;
-          result[b] = mul_lazy1(d, W, Wp, q);
-        }
-      }
-      offset += (t << 1);
+  const uint64_t block = n < HO_BLOCK ? n : HO_BLOCK;
+  /* depth first: every block through the stages whose groups fit in it (not the root stage) */
+  uint64_t m_after = n_div_2, t_after = 1, root_after = 1;
+  for (uint64_t first = 0; first < n; first += block) {
+    const uint64_t* s = src;
+    uint64_t m = n_div_2, t = 1, root = 1;
+    for (; m > 1 && 2 * t <= block; m >>= 1, t <<= 1) {
+      inv_stage(result, s, first, block, root, t, q, inv_root_pows, precon_inv_root_pows);
+      s = result;
+      root += m;
     }
-    t <<= 1;
+    m_after = m;
+    t_after = t;
+    root_after = root;
+  }
+  if (m_after < n_div_2) src = result;
+  /* breadth first for the stages whose groups span several blocks */
+  for (uint64_t m = m_after, t = t_after, root = root_after; m > 1; m >>= 1, t <<= 1) {
+    inv_stage(result, src, 0, n, root, t, q, inv_root_pows, precon_inv_root_pows);
     src = result;
+    root += m;
   }
   if (result != operand && n == 2) memcpy(result, operand, n * sizeof(uint64_t));
 

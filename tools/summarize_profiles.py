@@ -1,8 +1,9 @@
 """Turn gpurun_out/prof/ (tools/collect_profiles.sh) into the committed summaries:
 
-    profiles/r1_kernel_stats.csv   rocprofv3 --stats per-kernel table
-    profiles/r1_pmc_summary.md     counters per dispatch, HBM traffic vs algorithmic
-    profiles/r1_hbm_traffic.json   HBM bytes per launch, read by bench.py
+    profiles/rN_kernel_stats.csv   rocprofv3 --stats per-kernel table
+    profiles/rN_pmc_summary.md     counters per dispatch, HBM traffic vs algorithmic
+    profiles/rN_hbm_traffic.json   HBM bytes per launch, read by bench.py
+(N = the round, argv[1], default 2)
 
 HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE counts
 streaming reads at half their size (calibrated below on copy kernels of known
@@ -19,6 +20,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "2"
 N, BATCH = 65536, 4096
 ALG = 16.0 * N * BATCH
 
@@ -48,11 +50,11 @@ def family(k):
 def main():
     stats = glob.glob(os.path.join(SRC, "trace", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
-        shutil.copy(stats[0], os.path.join(DST, "r1_kernel_stats.csv"))
+        shutil.copy(stats[0], os.path.join(DST, f"r{ROUND}_kernel_stats.csv"))
     fetch, write = counters("fetch"), counters("write")
     calf, calw = counters("cal_fetch"), counters("cal_write")
     sq, lds = counters("sq"), counters("lds")
-    out = ["# Round-1 PMC summary (rocprofv3 --pmc, separate passes; averages per dispatch)", "",
+    out = [f"# Round-{ROUND} PMC summary (rocprofv3 --pmc, separate passes; averages per dispatch)", "",
            "Collected by `tools/collect_profiles.sh`, summarised by `tools/summarize_profiles.py`.",
            "Command: `rocprofv3 --pmc <counters> -- python bench.py --steps 3 --warmup 1 "
            "--no-cpu-baseline` (N=65536, 55-bit q, batch 4096; default plan = strided_pass<5 "
@@ -91,12 +93,12 @@ def main():
         if family(k) and d.get("SQ_WAVES"):
             out.append(f"- {short(k)}: {d['SQ_INSTS_VALU'] / d['SQ_WAVES']:.0f} VALU instructions "
                        f"per wave, {d['SQ_WAVES']:.0f} waves")
-    open(os.path.join(DST, "r1_pmc_summary.md"), "w").write("\n".join(out) + "\n")
-    json.dump({"source": "profiles/r1_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+    open(os.path.join(DST, f"r{ROUND}_pmc_summary.md"), "w").write("\n".join(out) + "\n")
+    json.dump({"source": f"profiles/r{ROUND}_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                "separate passes, FETCH_SIZE x2 gfx950 correction)",
                "hbm_bytes_per_launch": traffic, "by_bench_kernel_family": fam,
                "workload": f"N={N}, q=18014398510661633, batch={BATCH} (bench.py default), one launch"},
-              open(os.path.join(DST, "r1_hbm_traffic.json"), "w"), indent=1)
+              open(os.path.join(DST, f"r{ROUND}_hbm_traffic.json"), "w"), indent=1)
     print("\n".join(out[-12:]))
 
 

@@ -213,6 +213,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-secondary", action="store_true", help=argparse.SUPPRESS)  # profile runs
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -316,9 +317,9 @@ def main():
     # fraction of the 8 TB/s HBM peak (algorithmic bytes: SURVEY.md 8d / BASELINE.md 4).
     mult = None
     secondary = None
-    if rank == 0 and batch == BATCH:
+    if rank == 0 and batch == BATCH and not args.no_secondary:
         mult = timed_eltwise(hx, torch, "EltwiseMultMod(input_mod_factor=1)", N, batch, q)
-    if rank == 0 and world == 1 and batch == BATCH:
+    if rank == 0 and world == 1 and batch == BATCH and not args.no_secondary:
         del data
         torch.cuda.empty_cache()
         secondary = secondary_configs(hx, torch)

@@ -12,9 +12,9 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- \
-  python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_under_trace.json 2> $OUT/trace.log
+  python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_under_trace.json 2> $OUT/trace.log
 run_pmc() {  # name, counters..., then -- command
   local name=$1; shift
   local ctr=()

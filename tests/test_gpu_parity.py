@@ -907,6 +907,40 @@ def test_key_switch_batch_vs_oracle(hx, ho, n, D, K, C, T, bits):
     assert np.array_equal(host(hx, d_res), want)
 
 
+def test_key_switch_two_streams_do_not_share_scratch(hx, ho):
+    """KeySwitch calls issued from one thread on two streams overlap on the device; their
+    scratch (coefficient-form targets, operand transforms, products) is keyed by stream, so
+    both results are right (round 1 kept one scratch per thread: advisor finding)."""
+    import torch
+    n, D, K, C = 8192, 3, 4, 2
+    rng = np.random.default_rng(17)
+    moduli = [int(q) for q in ho.generate_primes(K, 54, True, n)]
+    keys = [np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                            for _ in range(C) for i in range(K)]) for _ in range(D)]
+    msf = [int(rng.integers(1, moduli[i], dtype=np.uint64)) for i in range(D)]
+    d_keys = [dev(hx, k) for k in keys]
+    cases = []
+    for _ in range(2):
+        target = np.concatenate([rng.integers(0, moduli[j], n, dtype=np.uint64) for j in range(D)])
+        result = np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                                 for _ in range(C) for i in range(D)])
+        want = ho.key_switch(result, target, n, D, K, D + 1, C, moduli, keys, msf)
+        cases.append((dev(hx, target), dev(hx, result), want))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    outs = [[], []]
+    for rep in range(6):  # interleaved issue: the two streams' launches alternate
+        for i, (d_t, d_r, want) in enumerate(cases):
+            with torch.cuda.stream(streams[i]):
+                o = d_r.clone()
+                hx.KeySwitch(o, d_t, n, D, K, D + 1, C, moduli, d_keys, msf)
+                outs[i].append(o)
+    torch.cuda.synchronize()
+    for i, (d_t, d_r, want) in enumerate(cases):
+        for o in outs[i]:
+            assert np.array_equal(host(hx, o), want)
+
+
 def test_key_switch_rejects_bad_arguments(hx, ho):
     n = 16
     q = [int(x) for x in ho.generate_primes(3, 40, True, n)]

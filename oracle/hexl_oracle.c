@@ -378,6 +378,134 @@ void ho_ntt_inverse_radix2(uint64_t* result, const uint64_t* operand,
     for (uint64_t i = 0; i < n; ++i) result[i] = reduce_mod_k(result[i], q, 2);
 }
 
+/* ------------------------------------------------------------------------ */
+/* hexl/ntt/ntt-radix-4.cpp: the reference's second native implementation.  A */
+/* radix-4 butterfly is four radix-2 butterflies (ntt-default.hpp:62-100,      */
+/* :127-157), so every value equals the radix-2 network's; the reference's     */
+/* tests assert radix-4 == radix-2 (test/test-ntt.cpp:406-478).                 */
+/* ------------------------------------------------------------------------ */
+
+static int is_power_of_four(uint64_t n) {
+  return n && !(n & (n - 1)) && (n & 0x5555555555555555ULL);
+}
+
+/* ntt-default.hpp:62-100 FwdButterflyRadix4 on (x0, x1, x2, x3), in place */
+static inline void fwd_butterfly4(uint64_t* x0, uint64_t* x1, uint64_t* x2, uint64_t* x3,
+                                  const uint64_t* W, const uint64_t* Wp, uint64_t i1,
+                                  uint64_t q, uint64_t two_q) {
+  const uint64_t i2 = 2 * i1, i3 = 2 * i1 + 1;
+  fwd_butterfly(x0, x2, *x0, *x2, W[i1], Wp[i1], q, two_q);
+  fwd_butterfly(x1, x3, *x1, *x3, W[i1], Wp[i1], q, two_q);
+  fwd_butterfly(x0, x1, *x0, *x1, W[i2], Wp[i2], q, two_q);
+  fwd_butterfly(x2, x3, *x2, *x3, W[i3], Wp[i3], q, two_q);
+}
+
+/* ntt-radix-4.cpp:17-400 ForwardTransformToBitReverseRadix4 */
+void ho_ntt_forward_radix4(uint64_t* result, const uint64_t* operand, uint64_t n, uint64_t q,
+                           const uint64_t* root_pows, const uint64_t* precon_root_pows,
+                           uint64_t in_mf, uint64_t out_mf) {
+  (void)in_mf;
+  const uint64_t two_q = q << 1;
+  const int pow4 = is_power_of_four(n);
+  uint64_t m_start, t;
+  if (!pow4) { /* :47-71 a radix-2 step first when log2(n) is odd */
+    t = n >> 1;
+    for (uint64_t j = 0; j < t; ++j)
+      fwd_butterfly(&result[j], &result[j + t], operand[j], operand[j + t], root_pows[1],
+                    precon_root_pows[1], q, two_q);
+    m_start = 2;
+    t = n >> 3;
+  } else { /* :75-199 the first radix-4 pass reads the operand */
+    t = n >> 2;
+    for (uint64_t j = 0; j < t; ++j) {
+      uint64_t a = operand[j], b = operand[j + t], c = operand[j + 2 * t], d = operand[j + 3 * t];
+      fwd_butterfly4(&a, &b, &c, &d, root_pows, precon_root_pows, 1, q, two_q);
+      result[j] = a;
+      result[j + t] = b;
+      result[j + 2 * t] = c;
+      result[j + 3 * t] = d;
+    }
+    m_start = 4;
+    t >>= 2;
+  }
+  for (uint64_t m = m_start; m < n; m <<= 2) { /* :204-384 */
+    for (uint64_t i = 0; i < m; ++i) {
+      uint64_t* x = result + i * 4 * t;
+      for (uint64_t j = 0; j < t; ++j)
+        fwd_butterfly4(&x[j], &x[j + t], &x[j + 2 * t], &x[j + 3 * t], root_pows,
+                       precon_root_pows, m + i, q, two_q);
+    }
+    t >>= 2;
+  }
+  if (out_mf == 1) /* :386-397 */
+    for (uint64_t i = 0; i < n; ++i) result[i] = reduce_mod_k(result[i], q, 4);
+}
+
+/* ntt-default.hpp:127-157 InvButterflyRadix4 */
+static inline void inv_butterfly4(uint64_t* x0, uint64_t* x1, uint64_t* x2, uint64_t* x3,
+                                  const uint64_t* W, const uint64_t* Wp, uint64_t i1,
+                                  uint64_t i2, uint64_t i3, uint64_t q, uint64_t two_q) {
+  inv_butterfly(x0, x1, *x0, *x1, W[i1], Wp[i1], q, two_q);
+  inv_butterfly(x2, x3, *x2, *x3, W[i2], Wp[i2], q, two_q);
+  inv_butterfly(x0, x2, *x0, *x2, W[i3], Wp[i3], q, two_q);
+  inv_butterfly(x1, x3, *x1, *x3, W[i3], Wp[i3], q, two_q);
+}
+
+/* ntt-radix-4.cpp:402-700 InverseTransformFromBitReverseRadix4 */
+void ho_ntt_inverse_radix4(uint64_t* result, const uint64_t* operand, uint64_t n, uint64_t q,
+                           const uint64_t* inv_root_pows, const uint64_t* precon_inv_root_pows,
+                           uint64_t in_mf, uint64_t out_mf) {
+  (void)in_mf;
+  const uint64_t two_q = q << 1, n_div_2 = n >> 1;
+  const int pow4 = is_power_of_four(n);
+  const uint64_t* src = operand;
+  if (pow4) { /* :423-442 a radix-2 step first when log2(n) is even */
+    for (uint64_t j = 0; j < n_div_2; ++j)
+      inv_butterfly(&result[2 * j], &result[2 * j + 1], operand[2 * j], operand[2 * j + 1],
+                    inv_root_pows[1 + j], precon_inv_root_pows[1 + j], q, two_q);
+    src = result;
+  }
+  uint64_t t = pow4 ? 2 : 1;
+  uint64_t w1 = 1 + (pow4 ? n_div_2 : 0);               /* :447 */
+  uint64_t w3 = n_div_2 + 1 + (pow4 ? (n >> 2) : 0);    /* :448 */
+  for (uint64_t m = n >> (pow4 ? 3 : 2); m > 0; m >>= 2) { /* :452-650 */
+    for (uint64_t i = 0; i < m; ++i) {
+      const uint64_t off = i * 4 * t;
+      const uint64_t i1 = w1++, i2 = w1++, i3 = w3++;
+      for (uint64_t j = 0; j < t; ++j) {
+        uint64_t a = src[off + j], b = src[off + j + t], c = src[off + j + 2 * t],
+                 d = src[off + j + 3 * t];
+        inv_butterfly4(&a, &b, &c, &d, inv_root_pows, precon_inv_root_pows, i1, i2, i3, q, two_q);
+        result[off + j] = a;
+        result[off + j + t] = b;
+        result[off + j + 2 * t] = c;
+        result[off + j + 3 * t] = d;
+      }
+    }
+    src = result;
+    t <<= 2;
+    w1 += m;
+    w3 += m / 2;
+  }
+  if (result != operand && n == 2) memcpy(result, operand, n * sizeof(uint64_t)); /* :654-656 */
+  /* :659-680 the last stage with N^-1 folded in, as in the radix-2 transform */
+  const uint64_t W = inv_root_pows[n - 1];
+  const uint64_t inv_n = ho_inverse_mod(n, q);
+  const uint64_t inv_n_precon = ho_multiply_factor(inv_n, 64, q);
+  const uint64_t inv_n_w = ho_multiply_mod(inv_n, W, q);
+  const uint64_t inv_n_w_precon = ho_multiply_factor(inv_n_w, 64, q);
+  uint64_t* X = result;
+  uint64_t* Y = X + n_div_2;
+  for (uint64_t j = 0; j < n_div_2; ++j) {
+    const uint64_t tx = ho_add_uint_mod(X[j], Y[j], two_q);
+    const uint64_t ty = X[j] + two_q - Y[j];
+    X[j] = ho_multiply_mod_lazy64(tx, inv_n, inv_n_precon, q);
+    Y[j] = ho_multiply_mod_lazy64(ty, inv_n_w, inv_n_w_precon, q);
+  }
+  if (out_mf == 1) /* :682-690 */
+    for (uint64_t i = 0; i < n; ++i) result[i] = reduce_mod_k(result[i], q, 2);
+}
+
 /* ntt-radix-2.cpp:263-293 ReferenceForwardTransformToBitReverse */
 void ho_ntt_forward_reference(uint64_t* operand, uint64_t n, uint64_t q,
                               const uint64_t* root_pows) {

@@ -47,6 +47,16 @@ void ho_ntt_inverse_radix2(uint64_t* result, const uint64_t* operand,
                            const uint64_t* inv_root_pows,
                            const uint64_t* precon_inv_root_pows, uint64_t in_mf,
                            uint64_t out_mf);
+/* hexl/ntt/ntt-radix-4.cpp:17-400, :402-700 -- the reference's radix-4 native transforms */
+void ho_ntt_forward_radix4(uint64_t* result, const uint64_t* operand,
+                           uint64_t n, uint64_t q, const uint64_t* root_pows,
+                           const uint64_t* precon_root_pows, uint64_t in_mf,
+                           uint64_t out_mf);
+void ho_ntt_inverse_radix4(uint64_t* result, const uint64_t* operand,
+                           uint64_t n, uint64_t q,
+                           const uint64_t* inv_root_pows,
+                           const uint64_t* precon_inv_root_pows, uint64_t in_mf,
+                           uint64_t out_mf);
 /* hexl_oracle_avx512.c: 8-lane variants of the two transforms above (cpu_baseline
  * of bench.py); call only when ho_has_avx512() != 0. */
 int ho_has_avx512(void);

@@ -56,6 +56,8 @@ def _load():
     sig("ho_ntt_tables", None, u64, u64, u64, p64, p64, p64, p64)
     sig("ho_ntt_forward_radix2", None, p64, p64, u64, u64, p64, p64, u64, u64)
     sig("ho_ntt_inverse_radix2", None, p64, p64, u64, u64, p64, p64, u64, u64)
+    sig("ho_ntt_forward_radix4", None, p64, p64, u64, u64, p64, p64, u64, u64)
+    sig("ho_ntt_inverse_radix4", None, p64, p64, u64, u64, p64, p64, u64, u64)
     sig("ho_ntt_forward_reference", None, p64, u64, u64, p64)
     sig("ho_ntt_inverse_reference", None, p64, u64, u64, p64)
     sig("ho_eltwise_add_mod", None, p64, p64, p64, u64, u64)
@@ -169,6 +171,22 @@ class NTT:
                                       _p(self.precon_inv_root_pows), in_mf,
                                       out_mf)
         return out.reshape(x.shape)
+
+    def forward_radix4(self, operand, in_mf=1, out_mf=1, inplace=False):
+        """The reference's radix-4 native transform (ntt-radix-4.cpp:17-400), one polynomial."""
+        x = _arr(operand).copy()
+        out = x if inplace else np.empty_like(x)
+        lib.ho_ntt_forward_radix4(_p(out), _p(x), self.n, self.q, _p(self.root_pows),
+                                  _p(self.precon_root_pows), in_mf, out_mf)
+        return out
+
+    def inverse_radix4(self, operand, in_mf=1, out_mf=1, inplace=False):
+        """ntt-radix-4.cpp:402-700"""
+        x = _arr(operand).copy()
+        out = x if inplace else np.empty_like(x)
+        lib.ho_ntt_inverse_radix4(_p(out), _p(x), self.n, self.q, _p(self.inv_root_pows),
+                                  _p(self.precon_inv_root_pows), in_mf, out_mf)
+        return out
 
     def forward_inplace(self, buf, in_mf=1, out_mf=1):
         assert buf.dtype == np.uint64 and buf.size == self.n

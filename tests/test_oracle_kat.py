@@ -178,6 +178,35 @@ def test_ntt_radix2_vs_reference(n, bits):
     assert (i2 % np.uint64(q) == ntt.inverse(x2 % np.uint64(q), 1, 1)).all()
 
 
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 1024, 2048, 4096, 8192])
+@pytest.mark.parametrize("bits", [27, 49, 60])
+def test_ntt_radix4_equals_radix2(n, bits):
+    """The reference's second native implementation (hexl/ntt/ntt-radix-4.cpp) restated and
+    held against the radix-2 one the way the reference's tests do (test/test-ntt.cpp:318-355,
+    :422-452): in place and out of place, every (in, out) factor -- lazy outputs included,
+    because a radix-4 butterfly is four radix-2 butterflies and every value coincides."""
+    q = ho.generate_primes(1, bits, True, n)[0]
+    ntt = ho.NTT(n, q)
+    for in_mf, out_mf in ((1, 1), (2, 1), (4, 1), (4, 4), (1, 4)):
+        x = ho.fill_splitmix(n, bits + n + in_mf, in_mf * q)
+        want = ntt.forward(x, in_mf, out_mf)
+        assert (ntt.forward_radix4(x, in_mf, out_mf) == want).all()
+        assert (ntt.forward_radix4(x, in_mf, out_mf, inplace=True) == want).all()
+    for in_mf, out_mf in ((1, 1), (2, 1), (2, 2), (1, 2)):
+        x = ho.fill_splitmix(n, bits + n + 7 * in_mf, in_mf * q)
+        want = ntt.inverse(x, in_mf, out_mf)
+        assert (ntt.inverse_radix4(x, in_mf, out_mf) == want).all()
+        assert (ntt.inverse_radix4(x, in_mf, out_mf, inplace=True) == want).all()
+
+
+@pytest.mark.parametrize("case", KAT["ntt_forward"]["cases"], ids=lambda c: f"n{c['n']}_q{c['q']}")
+def test_ntt_radix4_kat(case):
+    """The reference's hand vectors through the radix-4 restatement (test/test-ntt.cpp:318-355)."""
+    ntt = ho.NTT(case["n"], case["q"])
+    assert ntt.forward_radix4(U(case["in"]), 1, 1).tolist() == case["out"]
+    assert ntt.inverse_radix4(U(case["out"]), 1, 1).tolist() == case["in"]
+
+
 def test_ntt_headline_config_roundtrip():
     """BASELINE.json configs[2]: N=65536, q = first 55-bit prime."""
     n = 65536

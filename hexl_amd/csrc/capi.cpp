@@ -755,16 +755,28 @@ namespace {
 // (hexl/include/hexl/experimental/seal/ntt-cache.hpp:27-53).  Entries live for
 // the life of the process.
 const hexl_amd_ntt* cached_plan(u64 n, u64 q, int device) {
+  // a per-thread front cache keeps the steady state off the global mutex
+  thread_local std::map<std::tuple<u64, u64, int>, const hexl_amd_ntt*> local;
+  const auto key = std::make_tuple(n, q, device);
+  auto hit = local.find(key);
+  if (hit != local.end()) return hit->second;
   static std::mutex mu;
   static std::map<std::tuple<u64, u64, int>, hexl_amd_ntt*> cache;
-  std::lock_guard<std::mutex> lock(mu);
-  auto key = std::make_tuple(n, q, device);
-  auto it = cache.find(key);
-  if (it != cache.end()) return it->second;
-  hexl_amd_ntt* p = nullptr;
-  if (hexl_amd_ntt_create(&p, n, q, 0, device) != HEXL_AMD_OK) return nullptr;
-  cache.emplace(key, p);
-  return p;
+  const hexl_amd_ntt* plan = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) {
+      plan = it->second;
+    } else {
+      hexl_amd_ntt* p = nullptr;
+      if (hexl_amd_ntt_create(&p, n, q, 0, device) != HEXL_AMD_OK) return nullptr;
+      cache.emplace(key, p);
+      plan = p;
+    }
+  }
+  local.emplace(key, plan);
+  return plan;
 }
 
 u64 floor_2_64_over(u64 q) { return (u64)((((unsigned __int128)1) << 64) / q); }

@@ -1377,7 +1377,7 @@ struct Tuning {
     fused_min_batch = env_u32("HEXL_AMD_FUSED_MIN_BATCH", 64);
     fused_wg_per_cu = env_u32("HEXL_AMD_FUSED_WG_PER_CU", 0);
     const char* f = getenv("HEXL_AMD_FP64");
-    fp64 = (f && f[0] == '0') ? 0 : 1;
+    fp64 = (f && f[0] == '0') ? 0 : (f && f[0] == '2') ? 2 : 1;
   }
 };
 static Tuning& tuning() {
@@ -1390,7 +1390,7 @@ int set_tuning(const char* key, u64 value) {
   else if (strcmp(key, "fused_window") == 0 && value < (1u << 16)) t.fused_window = (u32)value;
   else if (strcmp(key, "fused_min_batch") == 0 && value >= 1) t.fused_min_batch = (u32)value;
   else if (strcmp(key, "fused_wg_per_cu") == 0) t.fused_wg_per_cu = (u32)value;
-  else if (strcmp(key, "fp64") == 0 && value <= 1) t.fp64 = (u32)value;
+  else if (strcmp(key, "fp64") == 0 && value <= 2) t.fp64 = (u32)value;
   else return -1;
   return 0;
 }
@@ -1667,8 +1667,10 @@ hipError_t ntt_multi_launch(bool forward, const NttTables* const* tabs, u32 num_
 // HEXL_AMD_FP64=0 (or set_tuning("fp64", 0) before the plan is created) keeps 31..50-bit
 // moduli on the integer Lazy policy (A/B runs).
 int choose_policy(u64 q) {
-  if (q < kSmallModulusBound) return kPolicySmall;
-  if (q < kFp64ModulusBound && tuning().fp64.load()) return kPolicyFp64;
+  const bool fp = tuning().fp64.load() != 0;
+  // HEXL_AMD_FP64=2: Fp64 also below 2^30 (A/B against the 32-bit Small policy)
+  if (q < kSmallModulusBound && !(fp && tuning().fp64.load() == 2)) return kPolicySmall;
+  if (q < kFp64ModulusBound && fp) return kPolicyFp64;
   if (q < kLazyModulusBound) return kPolicyLazy;
   return kPolicyStrict;
 }

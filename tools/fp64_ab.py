@@ -30,17 +30,19 @@ def kernels(ntt, x, steps):
     return e0.elapsed_time(e1) / steps, {k: sum(v) / len(v) for k, v in agg.items()}
 
 
+BITS = int(sys.argv[1]) if len(sys.argv) > 1 else 49   # 28: Small (fp64 = 0) against Fp64 (fp64 = 2)
+ON = 2 if BITS < 30 else 1
 for n, batch, steps in ((65536, 4096, 10), (4096, 256, 200)):
-    q = hx.GeneratePrimes(1, 49, True, n)[0]
+    q = hx.GeneratePrimes(1, BITS, True, n)[0]
     x = torch.empty((batch, n), dtype=torch.int64, device="cuda")
     hx.fill_splitmix(x, n, batch, 1, q)
     ref = x[:2].clone()
-    for fp in (0, 1, 0, 1):
+    for fp in (0, ON, 0, ON):
         hx.set_tuning("fp64", fp)
         ntt = hx.NTT(n, q)
         ms, k = kernels(ntt, x, steps)
         assert torch.equal(ref, x[:2])
         print("N=%d batch=%d q=%d %-5s %8.4f ms/step  %s" % (
-            n, batch, q, "fp64" if fp else "lazy", ms,
+            n, batch, q, "fp64" if fp else ("small" if BITS < 30 else "lazy"), ms,
             "  ".join("%s=%.4f" % (a.replace("ntt_", ""), b) for a, b in sorted(k.items()))), flush=True)
     hx.set_tuning("fp64", 1)

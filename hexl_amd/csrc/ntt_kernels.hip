@@ -502,7 +502,7 @@ strided_pass_multi(u64* out, const u64* in, MultiCtx mc, u32 log_n, u32 a0, u32 
 #endif
 constexpr int kRE = HEXL_AMD_RE;  // log2 elements per thread (3: the shipped geometry)
 constexpr int kE = 1 << kRE;
-constexpr int kMaxTileLog = 12;
+constexpr int kMaxTileLog = 13;
 
 // XOR swizzle of the 8-byte slot index: every ds_read_b64 (32-lane groups, 64
 // banks) and ds_write_b64 (16-lane groups, 32 banks) access pattern of every
@@ -1268,7 +1268,8 @@ static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2
                      0, st, out, in, tw, m, log_n, finish, total, il)
 #define HX_LAUNCH_B(T)                                                                    \
   case T:                                                                                 \
-    if constexpr (T <= TL && (TL <= 10 || T >= 9) && (TL != 11 || T == 11)) {             \
+    if constexpr (T <= TL && (TL <= 10 || T >= 9) && (TL != 11 || T == 11) &&               \
+                  (TL != 13 || T == 13)) {             \
       if (!FWD && (u32)T == log_n) {                                                      \
         if (guard)                                                                        \
           HX_LAUNCH_B2(T, true, !FWD);                                                    \
@@ -1296,6 +1297,7 @@ static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2
     HX_LAUNCH_B(10)
     HX_LAUNCH_B(11)
     HX_LAUNCH_B(12)
+    HX_LAUNCH_B(13)
     default:
       return hipErrorInvalidValue;
   }
@@ -1365,7 +1367,7 @@ static u32 env_u32(const char* name, u32 dflt) {
 // Process-wide tuning state: defaults from the environment, changeable at run time
 // through hexl_amd_set_tuning (tests compare the plans in one process).
 struct Tuning {
-  std::atomic<u32> plan, fused_window, fused_min_batch, fused_wg_per_cu, fp64;
+  std::atomic<u32> plan, fused_window, fused_min_batch, fused_wg_per_cu, fp64, tile13;
   Tuning() {
     const char* e = getenv("HEXL_AMD_PLAN");
     plan = (e && strcmp(e, "tiled") == 0) ? kPlanTiled : (e && strcmp(e, "fused") == 0) ? kPlanFused
@@ -1378,6 +1380,8 @@ struct Tuning {
     fused_wg_per_cu = env_u32("HEXL_AMD_FUSED_WG_PER_CU", 0);
     const char* f = getenv("HEXL_AMD_FP64");
     fp64 = (f && f[0] == '0') ? 0 : (f && f[0] == '2') ? 2 : 1;
+    const char* t13 = getenv("HEXL_AMD_TILE13");
+    tile13 = (t13 && t13[0] == '0') ? 0 : 1;
   }
 };
 static Tuning& tuning() {
@@ -1391,6 +1395,7 @@ int set_tuning(const char* key, u64 value) {
   else if (strcmp(key, "fused_min_batch") == 0 && value >= 1) t.fused_min_batch = (u32)value;
   else if (strcmp(key, "fused_wg_per_cu") == 0) t.fused_wg_per_cu = (u32)value;
   else if (strcmp(key, "fp64") == 0 && value <= 2) t.fp64 = (u32)value;
+  else if (strcmp(key, "tile13") == 0 && value <= 1) t.tile13 = (u32)value;
   else return -1;
   return 0;
 }
@@ -1399,11 +1404,18 @@ static bool plan_strided_requested() { return plan_mode() != kPlanTiled; }
 static u32 fused_window() { return tuning().fused_window.load(); }
 static u64 fused_min_batch() { return tuning().fused_min_batch.load(); }
 
-static Plan make_plan(int L) {
+static Plan make_plan(int L, bool allow_tile13 = true) {
   Plan p{};
   if (L <= 12) {  // one kernel, one HBM round trip
     p.tl = L <= 10 ? 10 : 12;
     p.bottom = L;
+    return p;
+  }
+  if (L == 13 && allow_tile13 && tuning().tile13.load()) {
+    // N = 8192 also fits one workgroup's LDS: 64 KiB tile, 1024 threads x 8 elements, two
+    // workgroups (32 waves) per CU -- one HBM round trip instead of two
+    p.tl = 13;
+    p.bottom = 13;
     return p;
   }
   if (plan_strided_requested() && L >= 13) {
@@ -1459,6 +1471,8 @@ static hipError_t launch_bottom_tl(int tl, int S, u64* out, const u64* in, const
     return launch_bottom<FWD, 10, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc);
   if (tl == 11)
     return launch_bottom<FWD, 11, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc);
+  if (tl == 13)
+    return launch_bottom<FWD, 13, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc);
   return launch_bottom<FWD, 12, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc);
 }
 
@@ -1624,7 +1638,7 @@ hipError_t ntt_inverse_launch(const NttTables& t, u64* result, const u64* operan
 template <class A>
 static hipError_t multi_impl(bool forward, const NttTables& t0, const MultiCtx& mc, u64 polys,
                              u64* result, const u64* operand, u64 out_mf, hipStream_t st) {
-  Plan p = make_plan((int)t0.log_n);
+  Plan p = make_plan((int)t0.log_n, /*allow_tile13=*/false);  // the multi-plan kernels: 11 / 12 stages
   if (plan_mode() == kPlanTiled) return hipErrorNotSupported;
   return forward ? forward_seq<A>(t0, p, result, operand, polys, out_mf, st, &mc)
                  : inverse_seq<A>(t0, p, result, operand, polys, out_mf, st, &mc);

@@ -334,7 +334,9 @@ int hexl_amd_profile_get(int i, const char** name, float* ms);
  *   "fused_wg_per_cu"  persistent workgroups per CU (0 = occupancy query)
  *   "fp64"             1 (default) = plans for 2^30 <= q < 2^50 use the Fp64 arithmetic
  *                      policy (exact integers in doubles), 0 = the integer Lazy policy;
- *                      read when a plan is created */
+ *                      read when a plan is created
+ *   "tile13"           1 (default) = N = 8192 runs as one kernel on a 64 KiB LDS tile (one HBM
+ *                      round trip), 0 = strided pass + tile pass like N = 2^14..2^16 */
 int hexl_amd_set_tuning(const char* key, uint64_t value);
 
 #ifdef __cplusplus

@@ -500,9 +500,12 @@ strided_pass_multi(u64* out, const u64* in, MultiCtx mc, u32 log_n, u32 a0, u32 
 #ifndef HEXL_AMD_RE
 #define HEXL_AMD_RE 3
 #endif
-constexpr int kRE = HEXL_AMD_RE;  // log2 elements per thread (3: the shipped geometry)
-constexpr int kE = 1 << kRE;
-constexpr int kMaxTileLog = 13;
+// log2 elements per thread: 3 (8 elements, rounds of 3 stages) for every tile pass but the
+// 14-stage one of N = 2^14, whose 128 KiB tile is one 1024-thread workgroup per CU with 16
+// elements per thread (rounds of 4 stages, 4 waves per SIMD, <= 128 VGPRs).
+constexpr int re_of(int S) { return S >= 14 ? 4 : HEXL_AMD_RE; }
+constexpr int el_of(int S) { return 1 << re_of(S); }
+constexpr int kMaxTileLog = 14;
 
 // XOR swizzle of the 8-byte slot index: every ds_read_b64 (32-lane groups, 64
 // banks) and ds_write_b64 (16-lane groups, 32 banks) access pattern of every
@@ -518,6 +521,8 @@ __device__ __forceinline__ u32 lds_slot(u32 p) {
 // tile-index units (it includes the CB column bits).
 template <int S, int CB>
 struct Rounds {
+  static constexpr int kRE = re_of(S);
+  static constexpr int kE = 1 << kRE;
   static constexpr int NR = (S + kRE - 1) / kRE;
   static constexpr int R0 = S - (NR - 1) * kRE;
   static constexpr int r(int j) { return j == 0 ? R0 : kRE; }
@@ -558,9 +563,9 @@ __device__ __forceinline__ u32 tile_index(u32 vt, int e) {
 }
 
 // vt >> w for vt = s*threads + tid, visibly uniform when 2^w >= threads.
-template <int w, int TL>
+template <int w, int TL, int RE>
 __device__ __forceinline__ u32 vt_high(int s, u32 tid) {
-  constexpr int kThreadsLog = TL - kRE;
+  constexpr int kThreadsLog = TL - RE;
   if (w >= kThreadsLog) return (u32)s >> (w - kThreadsLog);
   return (((u32)s << kThreadsLog) + tid) >> w;
 }
@@ -594,6 +599,7 @@ __device__ __forceinline__ u64 tile_uniform_offset(const TileGeom& g, u32 dp) {
 template <int S, int CB, int TL, int j, class T>
 __device__ __forceinline__ void round_twiddles(T* wv, const T* __restrict__ tw, u32 tid,
                                                const TileGeom& g) {
+  constexpr int kRE = re_of(S), kE = el_of(S);
   using RD = Rounds<S, CB>;
   constexpr int r = RD::r(j), w = RD::w(j), u = RD::u(j);
   constexpr int SS = kE >> r;
@@ -602,7 +608,7 @@ __device__ __forceinline__ void round_twiddles(T* wv, const T* __restrict__ tw, 
   for (int s = 0; s < SS; ++s) {
     // sub-block-and-group index of the run: the bits of vt above the gap, minus
     // the column bits (which do not select a twiddle)
-    u32 node = level + (((g.tile_blk0 << u) + vt_high<w, TL>(s, tid)) & (level - 1));
+    u32 node = level + (((g.tile_blk0 << u) + vt_high<w, TL, RD::kRE>(s, tid)) & (level - 1));
 #ifndef HX_EXP_NO_SCALAR_TW  // developer experiment: per-lane loads for every twiddle
     if (w >= 6) node = __builtin_amdgcn_readfirstlane(node);  // uniform across the wave
 #endif
@@ -613,6 +619,7 @@ __device__ __forceinline__ void round_twiddles(T* wv, const T* __restrict__ tw, 
 template <int S, int CB, int j, class A, bool FWD, bool LAST>
 __device__ __forceinline__ void round_compute(u64* x, const TwT<A>* wv, const ModConst& m,
                                               const InvLast& il) {
+  constexpr int kRE = re_of(S), kE = el_of(S);
   constexpr int r = Rounds<S, CB>::r(j);
   constexpr int SS = kE >> r;
 #ifdef HX_EXP_NOCOMPUTE  // developer experiment: data movement only
@@ -638,6 +645,7 @@ __device__ __forceinline__ u64& lds_at(u64* lds, u32 byte_addr) {
 
 template <int S, int CB, int TL, int j>
 __device__ __forceinline__ void lds_load_round(u64* x, u64* lds, u32 tid) {
+  constexpr int kRE = re_of(S), kE = el_of(S);
   constexpr int r = Rounds<S, CB>::r(j), w = Rounds<S, CB>::w(j);
   constexpr int SS = kE >> r;
   constexpr int kThreads = 1 << (TL - kRE);
@@ -651,6 +659,7 @@ __device__ __forceinline__ void lds_load_round(u64* x, u64* lds, u32 tid) {
 
 template <int S, int CB, int TL, int j>
 __device__ __forceinline__ void lds_store_round(const u64* x, u64* lds, u32 tid) {
+  constexpr int kRE = re_of(S), kE = el_of(S);
   constexpr int r = Rounds<S, CB>::r(j), w = Rounds<S, CB>::w(j);
   constexpr int SS = kE >> r;
   constexpr int kThreads = 1 << (TL - kRE);
@@ -685,6 +694,7 @@ template <int S, int CB, int TL, int J, class A>
 __device__ __forceinline__ void fwd_mid_rounds(u64* x, u64* lds, const TwT<A>* tw, u32 tid,
                                                const TileGeom& g, const ModConst& m,
                                                const InvLast& il, const TwT<A>* pre) {
+  constexpr int kRE = re_of(S), kE = el_of(S);
   using RD = Rounds<S, CB>;
   if constexpr (J < RD::NR) {
     TwT<A> wv[kE], wn[kE];
@@ -711,6 +721,7 @@ __device__ __forceinline__ void inv_mid_rounds(u64* x, u64* lds, const TwT<A>* t
                                                const TileGeom& g, const ModConst& m,
                                                const InvLast& il, const TwT<A>* pre,
                                                TwT<A>* pre0) {
+  constexpr int kRE = re_of(S), kE = el_of(S);
   using RD = Rounds<S, CB>;
   if constexpr (J >= 1) {
     TwT<A> wv[kE], wn[kE];
@@ -755,6 +766,7 @@ __device__ __forceinline__ TileGeom make_geom(u32 tile, u32 log_n) {
 // wave owns in the deepest round (inverse fetch, forward store), 64 per access.
 template <bool ROUND0, int S, int CB, int TL>
 __device__ __forceinline__ u32 xfer_p0(u32 tid, int i) {
+  constexpr int kRE = re_of(S), kE = el_of(S);
   using RD = Rounds<S, CB>;
   if (ROUND0) {
     constexpr int r = RD::r(0), w = RD::w(0);
@@ -773,6 +785,7 @@ __device__ __forceinline__ constexpr u32 xfer_dp(int i) {
 template <bool ROUND0, int S, int CB, int TL, bool GUARD, class A, int LDK>
 __device__ __forceinline__ void fetch_tile(u64* x, const u64* in, u32 tid, const TileGeom& g,
                                            u64 total, bool first, const ModConst& m) {
+  constexpr int kRE = re_of(S), kE = el_of(S);
 #pragma unroll
   for (int i = 0; i < kE; ++i) {
     const u32 p0 = xfer_p0<ROUND0, S, CB, TL>(tid, i);
@@ -820,7 +833,7 @@ __device__ __forceinline__ void store_elem(u64* out, u32 tid, int i, u64 v,
 // use; the short bottom passes of small N (several sub-runs per thread in round
 // 0) would spill under that cap and get 6 (<= 80 VGPRs).
 template <int S, int CB>
-constexpr int min_waves() { return (S >= 10 || CB > 0) ? 8 : 6; }
+constexpr int min_waves() { return S >= 14 ? 4 : (S >= 10 || CB > 0) ? 8 : 6; }
 
 // LAST (inverse only): the pass contains the root stage of the transform.
 // tile_body: the work of one workgroup on tile `bid`; `lds` = 2^TL words of LDS.
@@ -831,6 +844,7 @@ __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
                                           const ulonglong2* __restrict__ tw_raw, const ModConst& m,
                                           u32 log_n, u32 flags, u64 total, const InvLast& il,
                                           u32 bid) {
+  constexpr int kRE = re_of(S), kE = el_of(S);
   using RD = Rounds<S, CB>;
   constexpr int NR = RD::NR;
   const TwT<A>* __restrict__ tw = reinterpret_cast<const TwT<A>*>(tw_raw);
@@ -909,7 +923,7 @@ __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
 }
 
 template <bool FWD, int S, int CB, int TL, bool GUARD, class A, bool LAST>
-__global__ void __launch_bounds__(1 << (TL - kRE), (min_waves<S, CB>()))
+__global__ void __launch_bounds__(1 << (TL - re_of(S)), (min_waves<S, CB>()))
 tile_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst m, u32 log_n,
           u32 flags, u64 total, InvLast il) {
   __shared__ u64 lds[1 << TL];
@@ -922,7 +936,7 @@ tile_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst m
 // Bottom pass over polynomials of several moduli (see strided_pass_multi); N >= 2^TL, so
 // a tile lies in one polynomial and no tile is ragged.
 template <bool FWD, int S, int TL, class A, bool LAST>
-__global__ void __launch_bounds__(1 << (TL - kRE), (min_waves<S, 0>()))
+__global__ void __launch_bounds__(1 << (TL - re_of(S)), (min_waves<S, 0>()))
 tile_pass_multi(u64* out, const u64* in, MultiCtx mc, u32 log_n, u32 flags, u64 total) {
   __shared__ u64 lds[1 << TL];
   const u32 poly = (u32)(((u64)blockIdx.x << TL) >> log_n);
@@ -1242,7 +1256,7 @@ static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2
       if (log_n < (u32)TL || (S != 11 && S != 12) || S > TL) return hipErrorNotSupported;
       const bool last = !FWD && (u32)S == log_n;
 #define HX_LAUNCH_BM(T, LST)                                                                \
-  hipLaunchKernelGGL((tile_pass_multi<FWD, T, TL, A, LST>), dim3(grid), dim3(1 << (TL - kRE)), \
+  hipLaunchKernelGGL((tile_pass_multi<FWD, T, TL, A, LST>), dim3(grid), dim3(1 << (TL - re_of(T))), \
                      0, st, out, in, *mc, log_n, finish, total)
       if (S == 11) {
         if constexpr (TL == 11) {
@@ -1264,12 +1278,12 @@ static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2
     }
   }
 #define HX_LAUNCH_B2(T, G, LST)                                                           \
-  hipLaunchKernelGGL((tile_pass<FWD, T, 0, TL, G, A, LST>), dim3(grid), dim3(1 << (TL - kRE)), \
+  hipLaunchKernelGGL((tile_pass<FWD, T, 0, TL, G, A, LST>), dim3(grid), dim3(1 << (TL - re_of(T))), \
                      0, st, out, in, tw, m, log_n, finish, total, il)
 #define HX_LAUNCH_B(T)                                                                    \
   case T:                                                                                 \
     if constexpr (T <= TL && (TL <= 10 || T >= 9) && (TL != 11 || T == 11) &&               \
-                  (TL != 13 || T == 13)) {             \
+                  (TL != 13 || T == 13) && (TL != 14 || T == 14)) {             \
       if (!FWD && (u32)T == log_n) {                                                      \
         if (guard)                                                                        \
           HX_LAUNCH_B2(T, true, !FWD);                                                    \
@@ -1298,6 +1312,7 @@ static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2
     HX_LAUNCH_B(11)
     HX_LAUNCH_B(12)
     HX_LAUNCH_B(13)
+    HX_LAUNCH_B(14)
     default:
       return hipErrorInvalidValue;
   }
@@ -1319,7 +1334,7 @@ static hipError_t launch_top(int S, u64* out, const u64* in, const ulonglong2* t
   case T:                                                                                   \
     if constexpr (T <= TL - 4 && (TL == 10 || T >= 7))                                      \
       hipLaunchKernelGGL((tile_pass<FWD, T, TL - T, TL, false, A, !FWD>), dim3(grid),       \
-                         dim3(1 << (TL - kRE)), 0, st, out, in, tw, m, log_n, finish, total, \
+                         dim3(1 << (TL - re_of(T))), 0, st, out, in, tw, m, log_n, finish, total, \
                          il);                                                               \
     else                                                                                    \
       return hipErrorInvalidValue;                                                          \
@@ -1381,7 +1396,7 @@ struct Tuning {
     const char* f = getenv("HEXL_AMD_FP64");
     fp64 = (f && f[0] == '0') ? 0 : (f && f[0] == '2') ? 2 : 1;
     const char* t13 = getenv("HEXL_AMD_TILE13");
-    tile13 = (t13 && t13[0] == '0') ? 0 : 1;
+    tile13 = (t13 && t13[0] == '0') ? 0 : (t13 && t13[0] == '1') ? 1 : 2;
   }
 };
 static Tuning& tuning() {
@@ -1395,7 +1410,7 @@ int set_tuning(const char* key, u64 value) {
   else if (strcmp(key, "fused_min_batch") == 0 && value >= 1) t.fused_min_batch = (u32)value;
   else if (strcmp(key, "fused_wg_per_cu") == 0) t.fused_wg_per_cu = (u32)value;
   else if (strcmp(key, "fp64") == 0 && value <= 2) t.fp64 = (u32)value;
-  else if (strcmp(key, "tile13") == 0 && value <= 1) t.tile13 = (u32)value;
+  else if (strcmp(key, "tile13") == 0 && value <= 2) t.tile13 = (u32)value;
   else return -1;
   return 0;
 }
@@ -1404,11 +1419,19 @@ static bool plan_strided_requested() { return plan_mode() != kPlanTiled; }
 static u32 fused_window() { return tuning().fused_window.load(); }
 static u64 fused_min_batch() { return tuning().fused_min_batch.load(); }
 
-static Plan make_plan(int L, bool allow_tile13 = true) {
+static Plan make_plan(int L, bool allow_tile13 = true, u64 batch = ~0ull) {
   Plan p{};
   if (L <= 12) {  // one kernel, one HBM round trip
     p.tl = L <= 10 ? 10 : 12;
     p.bottom = L;
+    return p;
+  }
+  if (L == 14 && allow_tile13 && tuning().tile13.load() >= 2 && batch >= 192) {
+    // N = 16384: 128 KiB tile, one workgroup of 1024 threads x 16 elements per CU (one
+    // workgroup per polynomial: batches that do not fill the CUs keep the two-pass shape,
+    // whose tile pass spreads a polynomial over 8 workgroups)
+    p.tl = 14;
+    p.bottom = 14;
     return p;
   }
   if (L == 13 && allow_tile13 && tuning().tile13.load()) {
@@ -1473,6 +1496,8 @@ static hipError_t launch_bottom_tl(int tl, int S, u64* out, const u64* in, const
     return launch_bottom<FWD, 11, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc);
   if (tl == 13)
     return launch_bottom<FWD, 13, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc);
+  if (tl == 14)
+    return launch_bottom<FWD, 14, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc);
   return launch_bottom<FWD, 12, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc);
 }
 
@@ -1605,7 +1630,7 @@ static hipError_t inverse_seq(const NttTables& t, const Plan& p, u64* result, co
 template <bool FWD, class A>
 static hipError_t transform_impl(const NttTables& t, u64* result, const u64* operand, u64 batch,
                                  u64 out_mf, hipStream_t st) {
-  const Plan p = make_plan((int)t.log_n);
+  const Plan p = make_plan((int)t.log_n, true, batch);
   if (plan_mode() == kPlanFused && p.n_strided == 1 && p.bottom == 11 && !p.top_tile &&
       p.strided[0] >= 4 && batch >= fused_min_batch() && batch < (1ull << 23))
     return launch_fused<FWD, A>(p.strided[0], t, result, operand, batch, out_mf == 1 ? 2 : 1, st);

@@ -335,8 +335,10 @@ int hexl_amd_profile_get(int i, const char** name, float* ms);
  *   "fp64"             1 (default) = plans for 2^30 <= q < 2^50 use the Fp64 arithmetic
  *                      policy (exact integers in doubles), 0 = the integer Lazy policy;
  *                      read when a plan is created
- *   "tile13"           1 (default) = N = 8192 runs as one kernel on a 64 KiB LDS tile (one HBM
- *                      round trip), 0 = strided pass + tile pass like N = 2^14..2^16 */
+ *   "tile13"           which degrees above 4096 run as ONE kernel on an LDS tile holding the
+ *                      whole polynomial (one HBM round trip instead of two): 2 (default) =
+ *                      N = 8192 (64 KiB tile) and N = 16384 (128 KiB tile, batches >= 192),
+ *                      1 = N = 8192 only, 0 = neither */
 int hexl_amd_set_tuning(const char* key, uint64_t value);
 
 #ifdef __cplusplus

@@ -448,6 +448,42 @@ def test_ntt_fp64_policy_matches_integer_policy(hx, n, batch):
         assert int(x.min()) >= 0 and int(x.max()) < 2 * q and torch.equal(x % q, a)
 
 
+@pytest.mark.parametrize("logn", [13, 14])
+@pytest.mark.parametrize("bits", [28, 45, 54, 60])
+def test_ntt_single_kernel_plans(hx, ho, logn, bits):
+    """N = 8192 / 16384 as ONE kernel on a 64 / 128 KiB LDS tile (16 elements per thread and
+    rounds of four stages at N = 16384; batches >= 192 there) against the two-pass plan, bit
+    for bit, and against the oracle; every arithmetic policy, lazy outputs, out of place."""
+    import torch
+    n, batch = 1 << logn, 200
+    q = ho.generate_primes(1, bits, True, n)[0]
+    gnt, ont = hx.NTT(n, q), ho.NTT(n, q)
+    x = torch.empty((batch, n), dtype=torch.int64, device="cuda")
+    try:
+        for fwd in (True, False):
+            fn = gnt.ComputeForward if fwd else gnt.ComputeInverse
+            for in_mf, out_mf in (((1, 1), (4, 4)) if fwd else ((1, 1), (2, 2))):
+                hx.fill_splitmix(x, n, batch, 5 + in_mf, in_mf * q)
+                res = []
+                for t13 in (0, 2):
+                    hx.set_tuning("tile13", t13)
+                    a = x.clone()
+                    fn(a, a, in_mf, out_mf)
+                    b = torch.full_like(x, -1)
+                    fn(b, x, in_mf, out_mf)
+                    assert torch.equal(a, b)
+                    res.append(a)
+                if out_mf == 1:
+                    assert torch.equal(res[0], res[1])
+                    ref = (ont.forward if fwd else ont.inverse)(host(hx, x[[0, 77, 199]]) % np.uint64(q), 1, 1)
+                    assert (host(hx, res[1][[0, 77, 199]]) == ref).all()
+                else:
+                    assert torch.equal(res[0] % q, res[1] % q)
+                    assert int(res[1].min()) >= 0 and int(res[1].max()) < out_mf * q
+    finally:
+        hx.set_tuning("tile13", 2)
+
+
 @pytest.mark.parametrize("logn", [15, 16])
 @pytest.mark.parametrize("bits", [28, 45, 54, 60])
 def test_ntt_fused_plan_matches_split_plan(hx, logn, bits):

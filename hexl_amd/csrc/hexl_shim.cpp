@@ -295,6 +295,27 @@ void KeySwitch(uint64_t* result, const uint64_t* t_target_iter_ptr, uint64_t n,
                                    moduli, k_switch_keys, modswitch_factors));
 }
 
+void KeySwitchBatch(uint64_t* result, const uint64_t* t_target_iter_ptr, uint64_t num_targets,
+                    uint64_t n, uint64_t decomp_modulus_size, uint64_t key_modulus_size,
+                    uint64_t rns_modulus_size, uint64_t key_component_count,
+                    const uint64_t* moduli, const uint64_t** k_switch_keys,
+                    const uint64_t* modswitch_factors) {
+  if (!on_device(result, t_target_iter_ptr, k_switch_keys ? k_switch_keys[0] : nullptr))
+    throw std::invalid_argument("KeySwitchBatch takes device memory");
+  check(hexl_amd_key_switch_batch(result, t_target_iter_ptr, num_targets, n, decomp_modulus_size,
+                                  key_modulus_size, rns_modulus_size, key_component_count, moduli,
+                                  k_switch_keys, modswitch_factors, nullptr));
+}
+
+void DyadicMultiplyBatch(uint64_t* result, const uint64_t* operand1, const uint64_t* operand2,
+                         uint64_t num_pairs, uint64_t n, const uint64_t* moduli,
+                         uint64_t num_moduli) {
+  if (!on_device(result, operand1, operand2))
+    throw std::invalid_argument("DyadicMultiplyBatch takes device memory");
+  check(hexl_amd_dyadic_multiply_batch(result, operand1, operand2, num_pairs, n, moduli,
+                                       num_moduli, nullptr));
+}
+
 void EltwiseCmpAdd(uint64_t* result, const uint64_t* operand1, uint64_t n, CMPINT cmp,
                    uint64_t bound, uint64_t diff) {
   if (on_device(result, operand1, nullptr))

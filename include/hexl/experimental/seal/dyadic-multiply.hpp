@@ -12,5 +12,12 @@ namespace hexl {
 void DyadicMultiply(uint64_t* result, const uint64_t* operand1, const uint64_t* operand2,
                     uint64_t n, const uint64_t* moduli, uint64_t num_moduli);
 
+/// Additive extension (not in the reference): `num_pairs` ciphertext pairs with the same
+/// moduli in one launch; operands hold num_pairs x 2 polynomials, result num_pairs x 3, all
+/// DEVICE memory (hexl_amd_dyadic_multiply_batch).
+void DyadicMultiplyBatch(uint64_t* result, const uint64_t* operand1, const uint64_t* operand2,
+                         uint64_t num_pairs, uint64_t n, const uint64_t* moduli,
+                         uint64_t num_moduli);
+
 }  // namespace hexl
 }  // namespace intel

@@ -9,25 +9,27 @@
 // multiplies by W = R[n] and its children are 2n, 2n+1 -- exactly the
 // reference's root_of_unity_powers[m + i] indexing (ntt-radix-2.cpp:128-129).
 // The device tables are therefore heap-ordered arrays of (W, W') pairs, one
-// 16-byte load per twiddle; the inverse table holds R[n]^-1 at the same heap
-// index (the reference's stage-ordered inverse layout, ntt-internal.cpp:143-154,
-// is kept on the host for the getters only).
+// 16-byte load per twiddle (one double per twiddle under the Fp64 arithmetic
+// policy); the inverse table holds R[n]^-1 at the same heap index (the
+// reference's stage-ordered inverse layout, ntt-internal.cpp:143-154, is kept
+// on the host for the getters only).
 //
 // Everything is built from a register-resident "subtree": a thread owns 2^r
 // elements and runs r stages on them with no communication.
 //
 //   strided_pass<R>   register-only pass (no LDS): each thread owns one column,
 //     2^R elements N >> (a0 + R) apart, lanes = adjacent columns (coalesced),
-//     twiddles wave-uniform (scalar loads).  HBM-bound: 0.70 ms for 4 GiB in +
-//     4 GiB out.  The default top pass for N >= 2^13 (4 + 12 stages for N = 2^16).
+//     twiddles wave-uniform (scalar loads).  HBM-bound: 0.68 ms for 2 GiB in +
+//     2 GiB out.  The top pass for N >= 2^15 (5 + 11 stages for N = 2^16).
 //   tile_pass<S, CB, TL>  One workgroup (2^(TL-3) threads x 8 elements) owns a tile
 //     of 2^TL elements in LDS (TL = 12: 32 KiB, 4 workgroups = 32 waves per CU) and
 //     runs S stages on it as ceil(S/3) subtree rounds separated by LDS
 //     transposes.  The tile-index bits are [ sub-block | S stage bits | CB column
 //     bits ]:
 //       CB = 0      the tile is 2^TL contiguous coefficients = whole sub-blocks of
-//                   heap level log2(N) - S ("bottom" stages; N <= 4096 is this
-//                   kernel alone, one HBM round trip);
+//                   heap level log2(N) - S ("bottom" stages; N <= 2^14 is this
+//                   kernel alone, one HBM round trip: a 64 KiB tile for N = 2^13,
+//                   a 128 KiB tile with 16 elements per thread for N = 2^14);
 //       CB = TL - S all 2^S rows x 2^CB adjacent columns of one polynomial ("top"
 //                   stages of the HEXL_AMD_PLAN=tiled alternative).
 //     LDS slots are XOR-swizzled so that every ds_read_b64 / ds_write_b64 pattern
@@ -40,8 +42,11 @@
 //     Bound by VALU issue (integer multiplies), not by HBM: see DESIGN.md.
 //
 // Values stay lazy as in the reference's Harvey butterflies
-// (hexl/ntt/ntt-default.hpp:28-42, :112-125); see modarith.h for the two range
-// policies.  Canonical outputs (output_mod_factor == 1) are bit-identical to the
+// (hexl/ntt/ntt-default.hpp:28-42, :112-125); see modarith.h for the four
+// arithmetic policies.  Below the kernels: fused_pass (both passes in one
+// persistent launch: measured slower, opt-in), the multi-plan variants
+// (polynomials of several moduli in one launch: RNS limbs, KeySwitch), and the
+// host-side planning.  Canonical outputs (output_mod_factor == 1) are bit-identical to the
 // reference; lazy outputs are congruent and inside the reference's ranges.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>

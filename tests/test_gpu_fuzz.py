@@ -1,0 +1,204 @@
+"""Randomised differential tests: the HIP path against the CPU oracle on random
+(N, q, batch, mod factors, in place / out of place) draws, weighted towards the
+boundaries between the arithmetic policies and between the launch plans.
+
+The default run draws a few dozen cases; HEXL_AMD_FUZZ_CASES=<n> and
+HEXL_AMD_FUZZ_SEED=<s> make it a soak test (`tools/` has no copy of this: only
+`tests/` may use the oracle).  Every failure message carries the draw, so a case
+can be replayed.
+"""
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = int(os.environ.get("HEXL_AMD_FUZZ_CASES", "48"))
+SEED = int(os.environ.get("HEXL_AMD_FUZZ_SEED", "20260926"))
+MAX_ELEMS = 1 << 21  # per case: keeps the scalar oracle below ~0.2 s
+
+# GeneratePrimes bit sizes (q in [2^b, 2^(b+1))) on both sides of the policy boundaries
+# (q < 2^30, 2^50, 2^56) and up to the API's limit (q < 2^62)
+BITS = [20, 27, 28, 29, 30, 35, 44, 48, 49, 50, 53, 54, 55, 56, 58, 59, 60, 61]
+
+
+@pytest.fixture(scope="module")
+def hx():
+    import hexl_amd
+    return hexl_amd
+
+
+@pytest.fixture(scope="module")
+def ho():
+    from oracle import hexl_oracle
+    return hexl_oracle
+
+
+_prime_cache = {}
+
+
+def draw_prime(ho, rng, logn):
+    """A prime q = 1 mod 2N of a random size; both ends of the size's range are drawn."""
+    for _ in range(64):
+        bits = rng.choice(BITS)
+        if bits < logn + 2:
+            continue
+        key = (bits, logn)
+        if key not in _prime_cache:
+            try:
+                lo = ho.generate_primes(3, bits, True, 1 << logn)
+                hi = ho.generate_primes(3, bits, False, 1 << logn)
+                _prime_cache[key] = [int(p) for p in lo] + [int(p) for p in hi]
+            except RuntimeError:  # fewer than three such primes in the range
+                _prime_cache[key] = []
+        if _prime_cache[key]:
+            return rng.choice(_prime_cache[key])
+    raise AssertionError("no modulus size fits")
+
+
+def rand_u64(rng, shape, bound):
+    """uniform in [0, bound), bound < 2^64, with the extremes planted"""
+    g = np.random.default_rng(rng.getrandbits(63))
+    x = g.integers(0, bound, size=shape, dtype=np.uint64, endpoint=False)
+    flat = x.reshape(-1)
+    flat[rng.randrange(flat.size)] = bound - 1
+    flat[rng.randrange(flat.size)] = 0
+    return x
+
+
+@pytest.mark.parametrize("idx", range(CASES))
+def test_fuzz_ntt(hx, ho, idx):
+    rng = random.Random(SEED * 1000003 + idx)
+    logn = rng.choice([1, 2, 3, 5, 8, 10, 11, 12, 12, 13, 13, 14, 14, 15, 16, 16, 17])
+    n = 1 << logn
+    q = draw_prime(ho, rng, logn)
+    # batches around the plan thresholds (192 for the one-kernel N = 2^14 plan) and ragged ones
+    batch = min(rng.choice([1, 1, 2, 3, 5, 8, 17, 64, 191, 192, 193, 256]), max(1, MAX_ELEMS // n))
+    forward = rng.random() < 0.5
+    in_mf, out_mf = rng.choice([(1, 1), (2, 1), (4, 1), (1, 4), (2, 4), (4, 4)] if forward
+                               else [(1, 1), (2, 1), (1, 2), (2, 2)])
+    inplace = rng.random() < 0.5
+    tag = dict(idx=idx, n=n, q=q, batch=batch, fwd=forward, in_mf=in_mf, out_mf=out_mf,
+               inplace=inplace)
+    x = rand_u64(rng, (batch, n), in_mf * q)
+    oracle = ho.NTT(n, q)
+    exp = (oracle.forward if forward else oracle.inverse)(x, in_mf, out_mf)
+    plan = hx.NTT(n, q)
+    src = hx.from_numpy(x)
+    import torch
+    dst = src if inplace else torch.full_like(src, 0x5A5A5A5A)
+    (plan.ComputeForward if forward else plan.ComputeInverse)(dst, src, in_mf, out_mf)
+    got = hx.to_numpy(dst).reshape(batch, n)
+    if out_mf == 1:
+        assert np.array_equal(got, exp), tag
+    else:
+        assert (got < np.uint64(out_mf * q)).all(), tag
+        assert np.array_equal(got % np.uint64(q), exp % np.uint64(q)), tag
+    if not inplace:
+        assert np.array_equal(hx.to_numpy(src).reshape(batch, n), x), tag
+
+
+@pytest.mark.parametrize("idx", range(CASES))
+def test_fuzz_ntt_rns(hx, ho, idx):
+    """Several moduli in one call (the multi-plan launches), mixed policies allowed."""
+    rng = random.Random(SEED * 7919 + idx)
+    logn = rng.choice([3, 8, 10, 12, 13, 14, 15, 16])
+    n = 1 << logn
+    primes = []
+    while len(primes) < rng.choice([2, 3, 5, 8]):
+        p = draw_prime(ho, rng, logn)
+        if p not in primes:
+            primes.append(p)
+    polys = min(rng.choice([1, 2, 3, 7]), max(1, MAX_ELEMS // (n * len(primes))))
+    forward = rng.random() < 0.5
+    tag = dict(idx=idx, n=n, primes=primes, polys=polys, fwd=forward)
+    x = np.stack([rand_u64(rng, (polys, n), q) for q in primes])  # (prime, poly, n)
+    exp = np.stack([(ho.NTT(n, q).forward if forward else ho.NTT(n, q).inverse)(x[i], 1, 1)
+                    for i, q in enumerate(primes)])
+    plans = [hx.NTT(n, q) for q in primes]
+    buf = hx.from_numpy(x.reshape(-1)).reshape(len(primes), polys, n)
+    (hx.ComputeForwardRNS if forward else hx.ComputeInverseRNS)(plans, buf, buf, 1, 1)
+    assert np.array_equal(hx.to_numpy(buf).reshape(x.shape), exp), tag
+
+
+ELT_OPS = ["add", "add_scalar", "sub", "sub_scalar", "mult", "fma", "fma_null", "reduce",
+           "cmp_add", "cmp_sub_mod"]
+
+
+@pytest.mark.parametrize("idx", range(CASES))
+def test_fuzz_eltwise(hx, ho, idx):
+    rng = random.Random(SEED * 104729 + idx)
+    op = rng.choice(ELT_OPS)
+    n = rng.choice([1, 2, 7, 8, 9, 63, 64, 65, 255, 1000, 4096, 4099, 65536, 100003, 1 << 20])
+    import torch
+    tag = dict(idx=idx, op=op, n=n)
+
+    def prime(max_bits):
+        bits = rng.choice([b for b in BITS if b <= max_bits])
+        return int(ho.generate_primes(1, bits, rng.random() < 0.5, 1)[0])
+
+    if op in ("add", "sub", "add_scalar", "sub_scalar"):
+        q = prime(61)
+        a = rand_u64(rng, n, q)
+        if op.endswith("scalar"):
+            s = rng.randrange(q)
+            exp = (ho.eltwise_add_mod if op[0] == "a" else ho.eltwise_sub_mod)(a, s, q)
+            r = hx.from_numpy(a)
+            (hx.EltwiseAddMod if op[0] == "a" else hx.EltwiseSubMod)(r, r, s, n, q)
+        else:
+            b = rand_u64(rng, n, q)
+            exp = (ho.eltwise_add_mod if op[0] == "a" else ho.eltwise_sub_mod)(a, b, q)
+            r = torch.zeros(n, dtype=torch.int64, device="cuda")
+            (hx.EltwiseAddMod if op[0] == "a" else hx.EltwiseSubMod)(
+                r, hx.from_numpy(a), hx.from_numpy(b), n, q)
+    elif op == "mult":
+        in_mf = rng.choice([1, 2, 4])
+        q = prime(61 if in_mf <= 2 else 60)
+        a, b = rand_u64(rng, n, in_mf * q), rand_u64(rng, n, in_mf * q)
+        exp = ho.eltwise_mult_mod(a, b, q, in_mf)
+        r = hx.from_numpy(a)
+        hx.EltwiseMultMod(r, r, hx.from_numpy(b), n, q, in_mf)
+    elif op in ("fma", "fma_null"):
+        in_mf = rng.choice([1, 2, 4, 8])
+        q = prime(60)
+        a = rand_u64(rng, n, in_mf * q)
+        s = rng.randrange(in_mf * q)
+        c = rand_u64(rng, n, in_mf * q) if op == "fma" else None
+        exp = ho.eltwise_fma_mod(a, s, c, q, in_mf)
+        r = torch.zeros(n, dtype=torch.int64, device="cuda")
+        hx.EltwiseFMAMod(r, hx.from_numpy(a), s, hx.from_numpy(c) if c is not None else None,
+                         n, q, in_mf)
+    elif op == "reduce":
+        q = prime(61)
+        in_mf, out_mf = rng.choice([(q, 1), (q, 2), (2, 1), (4, 1), (4, 2)])
+        bound = (1 << 64) if in_mf == q else in_mf * q
+        a = rand_u64(rng, n, bound)
+        exp = ho.eltwise_reduce_mod(a, q, in_mf, out_mf)
+        r = torch.zeros(n, dtype=torch.int64, device="cuda")
+        hx.EltwiseReduceMod(r, hx.from_numpy(a), n, q, in_mf, out_mf)
+        tag.update(q=q, in_mf=in_mf, out_mf=out_mf)
+        got = hx.to_numpy(r)
+        if in_mf == q and out_mf == 2:  # the one lazy output of the family
+            assert (got < np.uint64(2 * q)).all(), tag
+            assert np.array_equal(got % np.uint64(q), exp % np.uint64(q)), tag
+            return
+    elif op == "cmp_add":
+        cmp = rng.randrange(8)
+        bound, diff = rng.getrandbits(rng.choice([3, 20, 63])), rng.getrandbits(40) + 1
+        a = rand_u64(rng, n, 1 << rng.choice([4, 21, 62]))
+        exp = ho.eltwise_cmp_add(a, cmp, bound, diff)
+        r = hx.from_numpy(a)
+        hx.EltwiseCmpAdd(r, r, n, cmp, bound, diff)
+        tag.update(cmp=cmp, bound=bound, diff=diff)
+    else:
+        cmp = rng.randrange(8)
+        q = prime(61)
+        bound, diff = rng.randrange(1 << 63), rng.randrange(1, q)
+        a = rand_u64(rng, n, 1 << 64)
+        exp = ho.eltwise_cmp_sub_mod(a, q, cmp, bound, diff)
+        r = hx.from_numpy(a)
+        hx.EltwiseCmpSubMod(r, r, n, q, cmp, bound, diff)
+        tag.update(q=q, cmp=cmp, bound=bound, diff=diff)
+    assert np.array_equal(hx.to_numpy(r), np.asarray(exp, dtype=np.uint64)), tag

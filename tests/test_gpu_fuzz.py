@@ -202,3 +202,57 @@ def test_fuzz_eltwise(hx, ho, idx):
         hx.EltwiseCmpSubMod(r, r, n, q, cmp, bound, diff)
         tag.update(q=q, cmp=cmp, bound=bound, diff=diff)
     assert np.array_equal(hx.to_numpy(r), np.asarray(exp, dtype=np.uint64)), tag
+
+
+@pytest.mark.parametrize("idx", range(max(8, CASES // 4)))
+def test_fuzz_key_switch(hx, ho, idx):
+    """KeySwitchBatch with random sizes and RNS bases of mixed modulus size (hence mixed
+    arithmetic policy inside one multi-plan launch) against the oracle, target by target."""
+    rng = random.Random(SEED * 31337 + idx)
+    logn = rng.choice([3, 6, 10, 11, 12, 13, 14])
+    n = 1 << logn
+    D = rng.choice([1, 2, 3, 4, 7])
+    K = D + 1 + rng.choice([0, 0, 1, 2])
+    C = rng.choice([2, 2, 3])
+    T = rng.choice([1, 2, 3, 5]) if n * D * K <= (1 << 18) else 1
+    moduli = []
+    while len(moduli) < K:
+        bits = rng.choice([b for b in BITS if logn + 3 <= b <= 59])  # SEAL's limit: 60-bit primes
+        try:
+            p = int(ho.generate_primes(1, bits, rng.random() < 0.5, n)[0])
+        except RuntimeError:
+            continue
+        if p not in moduli:
+            moduli.append(p)
+    tag = dict(idx=idx, n=n, D=D, K=K, C=C, T=T, moduli=moduli)
+    keys = [np.concatenate([rand_u64(rng, n, moduli[i]) for _ in range(C) for i in range(K)])
+            for _ in range(D)]
+    msf = [rng.randrange(1, moduli[i]) for i in range(D)]
+    targets = [np.concatenate([rand_u64(rng, n, moduli[j]) for j in range(D)]) for _ in range(T)]
+    results = [np.concatenate([rand_u64(rng, n, moduli[i]) for _ in range(C) for i in range(D)])
+               for _ in range(T)]
+    want = np.concatenate([ho.key_switch(results[t], targets[t], n, D, K, D + 1, C, moduli, keys, msf)
+                           for t in range(T)])
+    d_res = hx.from_numpy(np.concatenate(results))
+    hx.KeySwitchBatch(d_res, hx.from_numpy(np.concatenate(targets)), T, n, D, K, D + 1, C, moduli,
+                      [hx.from_numpy(k) for k in keys], msf)
+    assert np.array_equal(hx.to_numpy(d_res), want), tag
+
+
+@pytest.mark.parametrize("idx", range(max(8, CASES // 4)))
+def test_fuzz_dyadic_multiply(hx, ho, idx):
+    rng = random.Random(SEED * 2741 + idx)
+    n = rng.choice([8, 64, 1000, 1024, 4096, 8192, 16384])
+    k = rng.choice([1, 2, 3, 5, 9])
+    pairs = rng.choice([1, 2, 4]) if n * k <= (1 << 16) else 1
+    moduli = [int(ho.generate_primes(1, rng.choice([b for b in BITS if b <= 60]),
+                                     rng.random() < 0.5, 1)[0]) for _ in range(k)]
+    tag = dict(idx=idx, n=n, moduli=moduli, pairs=pairs)
+    ops1 = [np.concatenate([rand_u64(rng, n, q) for _ in range(2) for q in moduli]) for _ in range(pairs)]
+    ops2 = [np.concatenate([rand_u64(rng, n, q) for _ in range(2) for q in moduli]) for _ in range(pairs)]
+    want = np.concatenate([ho.dyadic_multiply(ops1[p], ops2[p], n, moduli) for p in range(pairs)])
+    import torch
+    d_res = torch.zeros(3 * n * k * pairs, dtype=torch.int64, device="cuda")
+    hx.DyadicMultiplyBatch(d_res, hx.from_numpy(np.concatenate(ops1)), hx.from_numpy(np.concatenate(ops2)),
+                           pairs, n, moduli)
+    assert np.array_equal(hx.to_numpy(d_res), want), tag

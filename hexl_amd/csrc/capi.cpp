@@ -859,8 +859,11 @@ static int key_switch_device(u64* result, const u64* t_target_iter, u64 T, u64 n
   // workspace: t_target (T D) | ntt_buf (T D^2) | prod (R T C) | tbuf (T C D) polynomials.
   // Keyed by the caller's stream: calls on one stream are serialised and share it, calls
   // on different streams may overlap on the device and get separate buffers.
+  // The sequence lock keeps another host thread's KeySwitch on the same stream from
+  // interleaving its launches with these (or regrowing the buffer under them).
   const size_t words = (size_t)n * T * (D + D * D + R * C + C * D);
   void* ws = nullptr;
+  StreamSequenceLock sequence(st);
   HX_HIP(stream_workspace(kWsKeySwitch, st, words * sizeof(u64), &ws));
   u64* t_target = (u64*)ws;
   u64* ntt_buf = t_target + T * D * n;

@@ -1551,6 +1551,7 @@ static hipError_t launch_fused_r(const NttTables& t, u64* result, const u64* ope
   const u32 cap = (u32)batch + window + grid + 4;
   const size_t bytes = sizeof(FusedCtl) + (size_t)kFusedMaxXcd * cap * sizeof(FusedSlot);
   void* ws = nullptr;
+  StreamSequenceLock sequence(st);  // memset + launch of one call stay adjacent on the stream
   e = stream_workspace(kWsFusedNtt, st, bytes, &ws);
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(ws, 0, bytes, st);

@@ -2,8 +2,10 @@
 #include "workspace.h"
 
 #include <map>
+#include <memory>
 #include <mutex>
 #include <tuple>
+#include <utility>
 
 namespace hexl_amd {
 namespace {
@@ -16,7 +18,27 @@ std::map<std::tuple<int, hipStream_t, int>, Entry>& table() {
   static auto* t = new std::map<std::tuple<int, hipStream_t, int>, Entry>;  // never destroyed:
   return *t;  // HIP may already be torn down when static destructors run
 }
+std::map<std::pair<int, hipStream_t>, std::unique_ptr<std::mutex>>& sequence_table() {
+  static auto* t = new std::map<std::pair<int, hipStream_t>, std::unique_ptr<std::mutex>>;
+  return *t;
+}
 }  // namespace
+
+StreamSequenceLock::StreamSequenceLock(hipStream_t stream) : mu_(nullptr) {
+  int device = 0;
+  (void)hipGetDevice(&device);
+  std::mutex* mu;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto& slot = sequence_table()[std::make_pair(device, stream)];
+    if (!slot) slot.reset(new std::mutex);
+    mu = slot.get();  // entries are never erased: the pointer stays valid
+  }
+  mu->lock();
+  mu_ = mu;
+}
+
+StreamSequenceLock::~StreamSequenceLock() { static_cast<std::mutex*>(mu_)->unlock(); }
 
 hipError_t stream_workspace(WorkspacePurpose purpose, hipStream_t stream, size_t bytes,
                             void** out) {

@@ -14,13 +14,29 @@ namespace hexl_amd {
 enum WorkspacePurpose : int {
   kWsFusedNtt = 0,   // scheduler state of fused_pass (ntt_kernels.hip)
   kWsKeySwitch = 1,  // t_target | ntt_buf | t_poly_prod of KeySwitch (capi.cpp)
-  kWsTwiddlePtrs = 2,
 };
 
 // Device buffer of at least `bytes` bytes for `purpose` on (current device, stream).
 // Growing synchronises the device (hipFree) -- it happens once per size class.
 hipError_t stream_workspace(WorkspacePurpose purpose, hipStream_t stream, size_t bytes,
                             void** out);
+
+// Held while a multi-launch sequence that uses a stream workspace is being ENQUEUED
+// (KeySwitch: twelve launches over one scratch buffer): two host threads that issue such
+// sequences on the same stream would otherwise interleave their launches -- stream order
+// then serialises the kernels, but of two half-finished sequences over one buffer -- or
+// free the buffer the other is still enqueuing against.  Keyed like the buffers by
+// (current device, stream); enqueueing is microseconds, the kernels run outside the lock.
+class StreamSequenceLock {
+ public:
+  explicit StreamSequenceLock(hipStream_t stream);
+  ~StreamSequenceLock();
+  StreamSequenceLock(const StreamSequenceLock&) = delete;
+  StreamSequenceLock& operator=(const StreamSequenceLock&) = delete;
+
+ private:
+  void* mu_;
+};
 
 // Frees every cached buffer of the current process (all devices).  The caller
 // guarantees no operation that uses them is in flight.

@@ -247,7 +247,11 @@ int hexl_amd_dyadic_multiply_host(uint64_t* result, const uint64_t* operand1,
  * arrays.  Plans for (n, moduli[i]) are created on first use and cached, as the
  * reference's GetNTT does (ntt-cache.hpp:27-53).  Requires rns_modulus_size ==
  * decomp_modulus_size + 1 <= key_modulus_size, decomp_modulus_size <= 32,
- * NTT-friendly primes below 2^61. */
+ * NTT-friendly primes below 2^61.
+ * Scratch: the intermediates live in a device buffer keyed by (device, stream).
+ * Calls on one stream reuse it in stream order -- from several host threads too: a
+ * call's launches are enqueued under a per-stream lock; calls on different streams
+ * get different buffers and may overlap on the device. */
 int hexl_amd_key_switch(uint64_t* result, const uint64_t* t_target_iter_ptr,
                         uint64_t n, uint64_t decomp_modulus_size,
                         uint64_t key_modulus_size, uint64_t rns_modulus_size,

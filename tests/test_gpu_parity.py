@@ -977,6 +977,53 @@ def test_key_switch_two_streams_do_not_share_scratch(hx, ho):
             assert np.array_equal(host(hx, o), want)
 
 
+def test_key_switch_two_threads_one_stream(hx, ho):
+    """Two host threads issuing KeySwitch on the SAME stream (both on the default stream):
+    each call's twelve launches must stay together on the stream, or the two calls run over
+    each other's scratch (the sequence lock of workspace.h)."""
+    import threading
+    import torch
+    n, D, K, C = 4096, 3, 4, 2
+    rng = np.random.default_rng(23)
+    moduli = [int(q) for q in ho.generate_primes(K, 52, True, n)]
+    keys = [np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                            for _ in range(C) for i in range(K)]) for _ in range(D)]
+    msf = [int(rng.integers(1, moduli[i], dtype=np.uint64)) for i in range(D)]
+    d_keys = [dev(hx, k) for k in keys]
+    cases = []
+    for _ in range(2):
+        target = np.concatenate([rng.integers(0, moduli[j], n, dtype=np.uint64) for j in range(D)])
+        result = np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                                 for _ in range(C) for i in range(D)])
+        want = ho.key_switch(result, target, n, D, K, D + 1, C, moduli, keys, msf)
+        cases.append((dev(hx, target), dev(hx, result), want))
+    torch.cuda.synchronize()
+    outs, errors = [[], []], []
+    start = threading.Barrier(2)
+
+    def work(i):
+        try:
+            d_t, d_r, _ = cases[i]
+            start.wait()
+            for _ in range(40):
+                o = d_r.clone()
+                hx.KeySwitch(o, d_t, n, D, K, D + 1, C, moduli, d_keys, msf)
+                outs[i].append(o)
+        except Exception as exc:  # noqa: BLE001 - reported below
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for i in range(2):
+        for o in outs[i]:
+            assert np.array_equal(host(hx, o), cases[i][2])
+
+
 def test_key_switch_rejects_bad_arguments(hx, ho):
     n = 16
     q = [int(x) for x in ho.generate_primes(3, 40, True, n)]

@@ -72,8 +72,17 @@ struct Staging {
   size_t cap = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // second lane of the pipelined host path
+  // A thread that ends gives its buffer and streams back (callers that run every task on
+  // a fresh std::thread would otherwise leak one staging area per task).  Thread-local
+  // destructors run when the thread ends and, for the main thread, at exit() BEFORE
+  // static destructors and atexit handlers, i.e. while the HIP runtime is still up;
+  // errors are ignored all the same.
   ~Staging() {
-    // Process teardown may already have destroyed the HIP runtime; leak.
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (stream2) (void)hipStreamSynchronize(stream2);
+    if (buf) (void)hipFree(buf);
+    if (stream) (void)hipStreamDestroy(stream);
+    if (stream2) (void)hipStreamDestroy(stream2);
   }
   // `dev` is the current device.
   int ensure(int dev, size_t bytes) {

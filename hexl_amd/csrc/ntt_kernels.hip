@@ -956,6 +956,58 @@ tile_pass_multi(u64* out, const u64* in, MultiCtx mc, u32 log_n, u32 flags, u64 
       lds, out, in, FWD ? pd->fwd : pd->inv, m, log_n, flags, total, il, blockIdx.x);
 }
 
+// ---------------------------------------------------------------------------
+// mixed_pass: workgroups of BOTH passes in one launch (N = 2^16, 4 + 12 stages)
+// ---------------------------------------------------------------------------
+// The strided pass is HBM-bound with most VALU slots idle, the tile pass VALU-bound
+// with HBM a quarter idle, and run one after the other they add up.  Two launches on
+// two streams do overlap but in whatever proportion the dispatcher happens to produce
+// (measured twice: no gain).  Here the proportion is fixed by construction: the batch
+// is cut into chunks, launch i holds the strided-pass workgroups of chunk i AND the
+// tile-pass workgroups of chunk i-1 (forward; the inverse has the roles swapped),
+// interleaved S,T,T along each XCD's block sequence, so every CU hosts both kinds all
+// the time.  No dependency inside a launch (different chunks; stream order separates
+// the two passes of a chunk), hence no control words and no spinning -- unlike
+// fused_pass.  Both bodies must live under ONE register allocation: the 4-stage strided
+// body (50 VGPRs) and the 12-stage tile body fit the 64-VGPR / 8-waves-per-SIMD budget,
+// which is why the split is 4 + 12 here and not the 5 + 11 of the two-launch plan.
+struct MixedSide {
+  u64* out;
+  const u64* in;
+  u32 flags;
+  u32 per_xcd;  // workgroups of this role per XCD (blocks / 8)
+};
+
+template <bool FWD, class A>
+__global__ void __launch_bounds__(512, 8)
+mixed_pass(MixedSide sd, MixedSide td, const ulonglong2* __restrict__ tw, ModConst m, u32 log_n,
+           u64 t_total, InvLast il) {
+  __shared__ u64 lds[1 << 12];
+  const u32 b = blockIdx.x, xcd = b & 7, j = b >> 3;
+  const u32 g = sd.per_xcd < (td.per_xcd >> 1) ? sd.per_xcd : (td.per_xcd >> 1);  // whole S,T,T groups
+  bool is_s;
+  u32 idx;
+  if (j < 3 * g) {
+    const u32 grp = j / 3, pos = j - 3 * grp;
+    is_s = pos == 0;
+    idx = is_s ? grp : 2 * grp + pos - 1;
+  } else {  // what is left of the longer role
+    const u32 r = j - 3 * g, s_left = sd.per_xcd - g;
+    is_s = r < s_left;
+    idx = is_s ? g + r : 2 * g + (r - s_left);
+  }
+  if (is_s) {
+    // XCD-contiguous order as in strided_pass; a 512-thread workgroup is two of its
+    // 256-thread work items (strided_body derives the wave index from bid and threadIdx)
+    const u32 bid = xcd * sd.per_xcd + idx;
+    strided_body<FWD, 4, A, !FWD, kStream, kStream>(sd.out, sd.in, tw, m, log_n, 0, sd.flags,
+                                                    bid * 2, il);
+  } else {
+    tile_body<FWD, 12, 0, 12, false, A, false, FWD ? kStream : kPlain, FWD ? kStream : kPlain>(
+        lds, td.out, td.in, tw, m, log_n, td.flags, t_total, il, idx * 8 + xcd);
+  }
+}
+
 // (Round-1 experiment, removed: `tile_stream`, a persistent variant of the bottom pass
 // with two LDS tile buffers per workgroup, the next tile prefetched by
 // `global_load ... lds` DMA (no VGPRs, permutation applied on the global side) and the
@@ -1380,7 +1432,7 @@ struct Plan {
 // slower than two launches, see its header and DESIGN.md); HEXL_AMD_PLAN=tiled
 // selects two LDS-tiled kernels (6 + 10 stages on 1024-element tiles for N = 2^16;
 // 4 % slower).
-enum PlanMode { kPlanFused = 0, kPlanSplit = 1, kPlanTiled = 2 };
+enum PlanMode { kPlanFused = 0, kPlanSplit = 1, kPlanTiled = 2, kPlanMixed = 3 };
 static u32 env_u32(const char* name, u32 dflt) {
   const char* e = getenv(name);
   if (!e || !*e) return dflt;
@@ -1390,11 +1442,14 @@ static u32 env_u32(const char* name, u32 dflt) {
 // Process-wide tuning state: defaults from the environment, changeable at run time
 // through hexl_amd_set_tuning (tests compare the plans in one process).
 struct Tuning {
-  std::atomic<u32> plan, fused_window, fused_min_batch, fused_wg_per_cu, fp64, tile13;
+  std::atomic<u32> plan, fused_window, fused_min_batch, fused_wg_per_cu, fp64, tile13, mixed_chunk;
   Tuning() {
     const char* e = getenv("HEXL_AMD_PLAN");
-    plan = (e && strcmp(e, "tiled") == 0) ? kPlanTiled : (e && strcmp(e, "fused") == 0) ? kPlanFused
-                                                                                       : kPlanSplit;
+    plan = (e && strcmp(e, "tiled") == 0)   ? kPlanTiled
+           : (e && strcmp(e, "fused") == 0) ? kPlanFused
+           : (e && strcmp(e, "mixed") == 0) ? kPlanMixed
+                                            : kPlanSplit;
+    mixed_chunk = env_u32("HEXL_AMD_MIXED_CHUNK", 512);
     // Slots (polynomials) an XCD may have in flight between the first phase-1 claim
     // and the last phase-2 claim; the smallest batch the fused launch is used for;
     // workgroups per CU of the persistent grid (0 = occupancy query).
@@ -1413,7 +1468,8 @@ static Tuning& tuning() {
 }
 int set_tuning(const char* key, u64 value) {
   Tuning& t = tuning();
-  if (strcmp(key, "plan") == 0 && value <= kPlanTiled) t.plan = (u32)value;
+  if (strcmp(key, "plan") == 0 && value <= kPlanMixed) t.plan = (u32)value;
+  else if (strcmp(key, "mixed_chunk") == 0 && value >= 1 && value < (1u << 20)) t.mixed_chunk = (u32)value;
   else if (strcmp(key, "fused_window") == 0 && value < (1u << 16)) t.fused_window = (u32)value;
   else if (strcmp(key, "fused_min_batch") == 0 && value >= 1) t.fused_min_batch = (u32)value;
   else if (strcmp(key, "fused_wg_per_cu") == 0) t.fused_wg_per_cu = (u32)value;
@@ -1631,6 +1687,49 @@ static hipError_t inverse_seq(const NttTables& t, const Plan& p, u64* result, co
   return hipSuccess;
 }
 
+// N = 2^16 as a pipeline of mixed launches (see mixed_pass): chunk i's first pass shares
+// launch i with chunk i-1's second pass.
+template <bool FWD, class A>
+static hipError_t launch_mixed(const NttTables& t, u64* result, const u64* operand, u64 batch,
+                               u64 out_mf, hipStream_t st) {
+  const u64 chunk = tuning().mixed_chunk.load();
+  const u64 chunks = (batch + chunk - 1) / chunk;
+  const u32 fin = out_mf == 1 ? 2 : 1;
+  const u32 log_n = t.log_n;  // 16
+  const u64 n = 1ull << log_n;
+  ScopedKernelTimer timer(FWD ? "ntt_fwd_mixed_pass" : "ntt_inv_mixed_pass", st);
+  for (u64 i = 0; i <= chunks; ++i) {
+    // first-pass role: chunk i; second-pass role: chunk i - 1
+    const bool has1 = i < chunks, has2 = i >= 1;
+    const u64 off1 = i * chunk, off2 = (i - 1) * chunk;
+    const u64 polys1 = has1 ? (batch - off1 < chunk ? batch - off1 : chunk) : 0;
+    const u64 polys2 = has2 ? (batch - off2 < chunk ? batch - off2 : chunk) : 0;
+    // forward: pass 1 = strided (operand -> result), pass 2 = tile (in place on result);
+    // inverse: pass 1 = tile (operand -> result), pass 2 = strided (in place, root stage)
+    const u64 s_polys = FWD ? polys1 : polys2, t_polys = FWD ? polys2 : polys1;
+    const u64 s_off = (FWD ? off1 : off2) * n, t_off = (FWD ? off2 : off1) * n;
+    MixedSide sd{}, td{};
+    if (s_polys) {
+      sd.out = result + s_off;
+      sd.in = (FWD ? operand : result) + s_off;
+      sd.flags = FWD ? kFirstPass : fin;
+      sd.per_xcd = (u32)s_polys;  // N / 16 columns / 512 threads = 8 workgroups per polynomial
+    }
+    if (t_polys) {
+      td.out = result + t_off;
+      td.in = (FWD ? result : operand) + t_off;
+      td.flags = FWD ? fin : kFirstPass;
+      td.per_xcd = (u32)(t_polys * 2);  // 16 tiles per polynomial
+    }
+    const unsigned grid = (unsigned)((sd.per_xcd + td.per_xcd) * 8);
+    hipLaunchKernelGGL((mixed_pass<FWD, A>), dim3(grid), dim3(512), 0, st, sd, td,
+                       FWD ? t.fwd : t.inv, t.mod, log_n, t_polys << log_n, t.inv_last);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 // (Round-1 experiment, removed: cutting the batch into chunks that alternate
 // between the caller's stream and an internal one, so that the HBM-bound strided
 // pass of chunk k+1 runs concurrently with the VALU-bound tile pass of chunk k.
@@ -1643,6 +1742,11 @@ static hipError_t transform_impl(const NttTables& t, u64* result, const u64* ope
   if (plan_mode() == kPlanFused && p.n_strided == 1 && p.bottom == 11 && !p.top_tile &&
       p.strided[0] >= 4 && batch >= fused_min_batch() && batch < (1ull << 23))
     return launch_fused<FWD, A>(p.strided[0], t, result, operand, batch, out_mf == 1 ? 2 : 1, st);
+  if constexpr (A::kLazy || A::kFp) {  // the policies mixed_pass is instantiated for
+    if (plan_mode() == kPlanMixed && t.log_n == 16 && batch >= 2 * (u64)tuning().mixed_chunk.load() &&
+        batch < (1ull << 24))
+      return launch_mixed<FWD, A>(t, result, operand, batch, out_mf, st);
+  }
   return FWD ? forward_seq<A>(t, p, result, operand, batch, out_mf, st)
              : inverse_seq<A>(t, p, result, operand, batch, out_mf, st);
 }

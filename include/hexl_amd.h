@@ -332,7 +332,10 @@ int hexl_amd_profile_get(int i, const char** name, float* ms);
  *                      launches), 0 = fused (N = 2^15, 2^16: both passes in one
  *                      persistent launch, the intermediate read back from the
  *                      XCD's L2; slower, kept as an experiment), 2 = tiled (two
- *                      LDS-tiled launches)
+ *                      LDS-tiled launches), 3 = mixed (N = 2^16, batches of at least two
+ *                      chunks: workgroups of chunk i's first pass and chunk i-1's second
+ *                      pass share a launch; as fast as two launches, kept as an experiment)
+ *   "mixed_chunk"      polynomials per chunk of the mixed plan (default 512)
  *   "fused_window"     polynomials one XCD keeps in flight (>= 1)
  *   "fused_min_batch"  smallest batch the fused launch is used for (>= 1)
  *   "fused_wg_per_cu"  persistent workgroups per CU (0 = occupancy query)

@@ -518,6 +518,43 @@ def test_ntt_fused_plan_matches_split_plan(hx, logn, bits):
         hx.set_tuning("fused_min_batch", 64)
 
 
+@pytest.mark.parametrize("bits", [54, 49])
+def test_ntt_mixed_plan_matches_split_plan(hx, bits):
+    """The mixed plan (N = 2^16: workgroups of chunk i's first pass and of chunk i-1's
+    second pass in one launch) gives the same bits as the default two-launch plan -- full,
+    ragged and single-chunk pipelines, canonical and lazy outputs, in place and out of place."""
+    import torch
+    n = 65536
+    q = hx.GeneratePrimes(1, bits, True, n)[0]
+    ntt = hx.NTT(n, q)
+    try:
+        for chunk, batch in ((4, 8), (4, 11), (3, 7), (16, 64)):
+            hx.set_tuning("mixed_chunk", chunk)
+            x = torch.empty((batch, n), dtype=torch.int64, device="cuda")
+            hx.fill_splitmix(x, n, batch, 5 + chunk, q)
+            for fwd in (True, False):
+                fn = ntt.ComputeForward if fwd else ntt.ComputeInverse
+                for out_mf in ((1, 4) if fwd else (1, 2)):
+                    res = {}
+                    for plan in (hx.PLAN_SPLIT, hx.PLAN_MIXED):
+                        hx.set_tuning("plan", plan)
+                        a = x.clone()
+                        fn(a, a, 1, out_mf)
+                        b = torch.full_like(x, -1)
+                        fn(b, x, 1, out_mf)
+                        assert torch.equal(a, b)
+                        res[plan] = a
+                    got, want = res[hx.PLAN_MIXED], res[hx.PLAN_SPLIT]
+                    if out_mf == 1:
+                        assert torch.equal(got, want)
+                    else:  # lazy outputs: same residues, inside the reference's range
+                        assert int(got.min()) >= 0 and int(got.max()) < out_mf * q
+                        assert torch.equal(got % q, want % q)
+    finally:
+        hx.set_tuning("plan", hx.PLAN_SPLIT)
+        hx.set_tuning("mixed_chunk", 512)
+
+
 def test_ntt_headline_full_size_properties(hx, ho):
     """BASELINE configs[2] at full size: N=65536, 55-bit q, batch=4096 (2 GiB).
     Size-independent properties on the device plus oracle spot checks."""

@@ -489,7 +489,8 @@ PLAN_FUSED, PLAN_SPLIT, PLAN_TILED, PLAN_MIXED = 0, 1, 2, 3
 def set_tuning(key, value):
     """Tuning / diagnostic knobs of the transform launch logic (include/hexl_amd.h):
     "plan" (PLAN_FUSED / PLAN_SPLIT / PLAN_TILED / PLAN_MIXED), "fused_window",
-    "fused_min_batch", "fused_wg_per_cu", "mixed_chunk", "tile13", "fp64" (read at plan creation).  Results never depend on them."""
+    "fused_min_batch", "fused_wg_per_cu", "mixed_chunk", "tile13", "fp64" and "h60" (both read at plan
+    creation).  Results never depend on them."""
     _check(lib.hexl_amd_set_tuning(key.encode(), int(value)))
 
 

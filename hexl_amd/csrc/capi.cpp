@@ -219,10 +219,11 @@ int hexl_amd_ntt_create(hexl_amd_ntt** out, uint64_t degree, uint64_t modulus,
     p->host[6][i] = nt::multiply_factor(IR[i], 64, q);
   }
   // Device tables: heap-ordered (value, Shoup factor) pairs -- the factor has 32 / 63 / 64
-  // fractional bits under the Small / Lazy / Strict arithmetic policy -- or, under Fp64,
+  // fractional bits under the Small / Lazy and Harvey60 / Strict arithmetic policy -- or, under Fp64,
   // one double per twiddle: the value balanced into (-q/2, q/2].
   const int policy = choose_policy(q);
-  const u64 shoup_bits = policy == kPolicySmall ? 32 : policy == kPolicyLazy ? 63 : 64;
+  const u64 shoup_bits =
+      policy == kPolicySmall ? 32 : (policy == kPolicyLazy || policy == kPolicyHarvey60) ? 63 : 64;
   auto balanced = [q](u64 w) { return w > q / 2 ? -(double)(q - w) : (double)w; };
   auto bits_of = [](double d) {
     u64 b;

@@ -27,13 +27,24 @@ constexpr u64 kSmallModulusBound = 1ull << 30;
 // doubles, one-word balanced twiddles).
 constexpr u64 kFp64ModulusBound = 1ull << 50;
 
-enum ArithPolicy : int { kPolicySmall = 0, kPolicyFp64 = 1, kPolicyLazy = 2, kPolicyStrict = 3 };
+// Moduli in [kLazyModulusBound, kHarvey60ModulusBound) use the Harvey60 policy (Harvey ranges
+// on doubled values; 63-bit Shoup factors like Lazy).
+constexpr u64 kHarvey60ModulusBound = 1ull << 60;
+
+enum ArithPolicy : int {
+  kPolicySmall = 0,
+  kPolicyFp64 = 1,
+  kPolicyLazy = 2,
+  kPolicyStrict = 3,
+  kPolicyHarvey60 = 4,
+  kNumPolicies = 5
+};
 int choose_policy(u64 q);  // ntt_kernels.hip
 
 // Device-resident state of one NTT plan.
 struct NttTables {
   // heap-ordered twiddles.  Integer policies: (R[n], floor(R[n] 2^s / q)) pairs, s = 32
-  // (Small), 63 (Lazy) or 64 (Strict).  Fp64: an array of doubles, R[n] balanced into
+  // (Small), 63 (Lazy, Harvey60) or 64 (Strict).  Fp64: an array of doubles, R[n] balanced into
   // (-q/2, q/2] (the pointer type is nominal).
   const ulonglong2* fwd;
   const ulonglong2* inv;  // the same for R[n]^-1

@@ -9,7 +9,8 @@
 // Semantics follow the reference's scalar primitives
 // (hexl/include/hexl/number-theory/number-theory.hpp:127-141 MultiplyModLazy,
 // :195-205 BarrettReduce64, :214-258 ReduceMod; hexl/ntt/ntt-default.hpp:28-42
-// and :112-125 for the two Harvey butterflies).  Two range policies:
+// and :112-125 for the two Harvey butterflies).  Range policies of the 64-bit integer
+// arithmetic (Small, Harvey60 and Fp64 are described at their structs below):
 //
 //   Strict (any q < 2^62): the reference's invariants -- forward values in
 //     [0,4q) with one conditional subtraction per butterfly, inverse values in
@@ -25,7 +26,7 @@
 //     skips the conditional subtractions inside each register subtree and
 //     restores [0,8q) at subtree exit.  14 (forward) / 15 (inverse)
 //     instructions per butterfly.
-// Both produce the same canonical outputs; lazy outputs stay inside the
+// All policies produce the same canonical outputs; lazy outputs stay inside the
 // reference's ranges ([0,4q) forward, [0,2q) inverse).
 #pragma once
 #include <stdint.h>
@@ -37,6 +38,14 @@
 #else
 #define HX_HD inline
 #define HX_D inline
+#endif
+
+// HX_OPAQUE(v): the value of v passes through an empty asm statement, so the compiler
+// cannot reassociate or narrow the expression that produced it.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HX_OPAQUE(v) asm("" : "+v"(v))
+#else
+#define HX_OPAQUE(v) (void)0
 #endif
 
 namespace hexl_amd {
@@ -83,6 +92,9 @@ struct ModConst {
   u64 two_q;
   u64 neg_q;  // 2^64 - q (Strict policy)
   u64 neg_two_q;  // 2^64 - 2q
+  // Harvey60 policy only:
+  u64 four_q;
+  u64 neg_four_q;  // 2^64 - 4q
   // Lazy policy only:
   u64 six_q;
   u32 fin_mul;    // floor(2^(31 + fin_shift) / q)
@@ -98,6 +110,8 @@ inline ModConst make_mod_const(u64 q) {  // host only
   m.two_q = q << 1;
   m.neg_q = 0 - q;
   m.neg_two_q = 0 - (q << 1);
+  m.four_q = q << 2;  // only meaningful (and only read) for q < 2^60
+  m.neg_four_q = 0 - (q << 2);
   m.six_q = 6 * q;  // only meaningful (and only read) for q < 2^56
   u32 b = 0;
   while (b < 63 && (q >> (b + 1)) != 0) ++b;
@@ -109,10 +123,8 @@ inline ModConst make_mod_const(u64 q) {  // host only
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-#define HX_OPAQUE(v) asm("" : "+v"(v))
 HX_HD u32 mul_hi32(u32 a, u32 b) { return __umulhi(a, b); }
 #else
-#define HX_OPAQUE(v) (void)0
 HX_HD u32 mul_hi32(u32 a, u32 b) { return (u32)(((u64)a * b) >> 32); }
 #endif
 
@@ -134,6 +146,7 @@ HX_HD u64 mul_add_lazy2(u64 acc, u64 D, u64 W, u64 W63, u64 neg_two_q) {
   const u32 a0 = (u32)D, a1 = (u32)(D >> 32);
   const u32 b0 = (u32)W63, b1 = (u32)(W63 >> 32);
   u64 S = (u64)a1 * b0 + (EXACT ? mul_hi32(a0, b0) : 0u);
+  if (EXACT) HX_OPAQUE(S);  // keeps hi(a0*b0) the first mad's addend (else: a separate 64-bit add)
   S = (u64)a0 * b1 + S;
   const u64 Q = (u64)a1 * b1 + (S >> 32);
   const u32 w0 = (u32)W, w1 = (u32)(W >> 32);
@@ -192,11 +205,25 @@ struct Strict {  // any q < 2^62; tables hold floor(W * 2^64 / q); plain values
   static constexpr bool kLazy = false;
   static constexpr bool kSmall = false;
   static constexpr bool kFp = false;
+  static constexpr bool kH60 = false;
 };
 struct Lazy {  // q < 2^56; tables hold floor(W * 2^63 / q); doubled values
   static constexpr bool kLazy = true;
   static constexpr bool kSmall = false;
   static constexpr bool kFp = false;
+  static constexpr bool kH60 = false;
+};
+// 2^56 <= q < 2^60 (where SEAL's and OpenFHE's 60-bit primes live): the reference's Harvey
+// invariants -- forward values in [0,4q), inverse values in [0,2q), one conditional
+// subtraction per butterfly -- held on DOUBLED values (D = 2x < 8q < 2^63) like the Lazy
+// policy's, so that the product is its carry-free v_mad_u64_u32 chain with a 63-bit Shoup
+// factor (exact quotient: T2 in [0,4q)) and the conditional subtraction a sign test:
+// 19 (forward) / 20 (inverse) instructions per butterfly against Strict's 23.
+struct Harvey60 {
+  static constexpr bool kLazy = false;
+  static constexpr bool kSmall = false;
+  static constexpr bool kFp = false;
+  static constexpr bool kH60 = true;
 };
 // q < 2^30 (the reference's 32-bit path, hexl/ntt/ntt-internal.cpp:218-226,
 // :279-287): every value of the Strict invariants is below 4q < 2^32, so the
@@ -207,6 +234,7 @@ struct Small {
   static constexpr bool kLazy = false;
   static constexpr bool kSmall = true;
   static constexpr bool kFp = false;
+  static constexpr bool kH60 = false;
 };
 
 // 2^30 <= q < 2^50 (the moduli the reference sends to its IFMA-52 / FP64-assisted
@@ -235,6 +263,7 @@ struct Fp64 {
   static constexpr bool kLazy = false;
   static constexpr bool kSmall = false;
   static constexpr bool kFp = true;
+  static constexpr bool kH60 = false;
 };
 constexpr int kFpFwdRun = 7;
 constexpr int kFpInvRun = 3;
@@ -304,7 +333,7 @@ HX_HD u32 csub32(u32 x, u32 m) {
 template <class A>
 HX_HD u64 to_internal(u64 x, const ModConst& m) {
   if (A::kFp) return fp_double_to_bits(fp_reduce(fp_from_u64(x), m));  // x < 4q < 2^52
-  return A::kLazy ? x << 1 : x;
+  return (A::kLazy || A::kH60) ? x << 1 : x;
 }
 // Fp64: full reduction of an internal value (a no-op for the integer policies)
 template <class A>
@@ -321,6 +350,11 @@ HX_HD void fwd_butterfly(u64& x, u64& y, u64 W, u64 Wp, const ModConst& m) {
   if (A::kLazy) {
     const u64 xs = mul_add_lazy2<false>(x, y, W, Wp, m.neg_two_q);
     y = (x << 1) + m.six_q - xs;
+    x = xs;
+  } else if (A::kH60) {  // doubled: x, y < 8q -> < 8q
+    const u64 tx = csub_neg(x, m.neg_four_q);                       // < 4q
+    const u64 xs = mul_add_lazy2<true>(tx, y, W, Wp, m.neg_two_q);  // tx + T2, T2 < 4q
+    y = (tx << 1) + m.four_q - xs;                                  // tx + 4q - T2
     x = xs;
   } else if (A::kSmall) {
     const u32 tx = csub32((u32)x, (u32)m.two_q);
@@ -350,6 +384,10 @@ HX_HD u64 fwd_finish(u64 x, const ModConst& m, bool canonical) {
     if (canonical) r2 = csub_neg(r2, m.neg_two_q);
     return r2 >> 1;
   }
+  if (A::kH60) {  // doubled value < 8q
+    if (canonical) x = csub_neg(csub_neg(x, m.neg_four_q), m.neg_two_q);
+    return x >> 1;
+  }
   if (A::kSmall) return canonical ? csub32(csub32((u32)x, (u32)m.two_q), (u32)m.q) : x;
   return canonical ? csub(csub(x, m.two_q), m.q) : x;
 }
@@ -366,6 +404,10 @@ HX_HD void inv_butterfly(u64& x, u64& y, u64 W, u64 Wp, const ModConst& m, int k
     const u64 d = x + (m.two_q << (k + 2)) - y;
     x = BOUND ? csub_neg(s, m.neg_two_q << 2) : s;
     y = mul_add_lazy2<false>(0, d, W, Wp, m.neg_two_q);
+  } else if (A::kH60) {  // doubled: x, y < 4q -> < 4q
+    const u64 d = x + m.four_q - y;  // < 8q
+    x = csub_neg(s, m.neg_four_q);
+    y = mul_add_lazy2<true>(0, d, W, Wp, m.neg_two_q);
   } else if (A::kSmall) {
     const u32 d = (u32)x + (u32)m.two_q - (u32)y;
     x = csub32((u32)s, (u32)m.two_q);
@@ -389,6 +431,10 @@ HX_HD void inv_butterfly_last(u64& x, u64& y, u64 n1, u64 n1p, u64 n1w, u64 n1wp
     const u64 d = x + (m.two_q << (k + 2)) - y;
     x = mul_add_lazy2<true>(0, s, n1, n1p, m.neg_two_q);
     y = mul_add_lazy2<true>(0, d, n1w, n1wp, m.neg_two_q);
+  } else if (A::kH60) {  // s, d < 8q < 2^63; doubled results in [0,4q)
+    const u64 d = x + m.four_q - y;
+    x = mul_add_lazy2<true>(0, s, n1, n1p, m.neg_two_q);
+    y = mul_add_lazy2<true>(0, d, n1w, n1wp, m.neg_two_q);
   } else if (A::kSmall) {
     const u32 d = (u32)x + (u32)m.two_q - (u32)y;
     x = mul_small((u32)s, (u32)n1, (u32)n1p, (u32)m.q);
@@ -404,7 +450,7 @@ HX_HD void inv_butterfly_last(u64& x, u64& y, u64 n1, u64 n1p, u64 n1w, u64 n1wp
 template <class A>
 HX_HD u64 inv_finish(u64 v, const ModConst& m, bool canonical) {
   if (A::kFp) return fp_canonical(fp_bits_to_double(v), m);
-  if (A::kLazy) {
+  if (A::kLazy || A::kH60) {
     if (canonical) v = csub_neg(v, m.neg_two_q);
     return v >> 1;
   }

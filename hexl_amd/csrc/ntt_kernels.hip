@@ -42,7 +42,7 @@
 //     Bound by VALU issue (integer multiplies), not by HBM: see DESIGN.md.
 //
 // Values stay lazy as in the reference's Harvey butterflies
-// (hexl/ntt/ntt-default.hpp:28-42, :112-125); see modarith.h for the four
+// (hexl/ntt/ntt-default.hpp:28-42, :112-125); see modarith.h for the five
 // arithmetic policies.  Below the kernels: fused_pass (both passes in one
 // persistent launch: measured slower, opt-in), the multi-plan variants
 // (polynomials of several moduli in one launch: RNS limbs, KeySwitch), and the
@@ -475,7 +475,11 @@ __device__ __forceinline__ const PlanDev* multi_plan(const MultiCtx& mc, u32 pol
 }
 template <class A>
 constexpr int policy_id() {
-  return A::kSmall ? kPolicySmall : A::kFp ? kPolicyFp64 : A::kLazy ? kPolicyLazy : kPolicyStrict;
+  return A::kSmall ? kPolicySmall
+         : A::kFp  ? kPolicyFp64
+         : A::kLazy ? kPolicyLazy
+         : A::kH60  ? kPolicyHarvey60
+                    : kPolicyStrict;
 }
 
 template <bool FWD, int R, class A, bool LAST>
@@ -1442,7 +1446,7 @@ static u32 env_u32(const char* name, u32 dflt) {
 // Process-wide tuning state: defaults from the environment, changeable at run time
 // through hexl_amd_set_tuning (tests compare the plans in one process).
 struct Tuning {
-  std::atomic<u32> plan, fused_window, fused_min_batch, fused_wg_per_cu, fp64, tile13, mixed_chunk;
+  std::atomic<u32> plan, fused_window, fused_min_batch, fused_wg_per_cu, fp64, tile13, mixed_chunk, h60;
   Tuning() {
     const char* e = getenv("HEXL_AMD_PLAN");
     plan = (e && strcmp(e, "tiled") == 0)   ? kPlanTiled
@@ -1458,6 +1462,8 @@ struct Tuning {
     fused_wg_per_cu = env_u32("HEXL_AMD_FUSED_WG_PER_CU", 0);
     const char* f = getenv("HEXL_AMD_FP64");
     fp64 = (f && f[0] == '0') ? 0 : (f && f[0] == '2') ? 2 : 1;
+    const char* h = getenv("HEXL_AMD_H60");
+    h60 = (h && h[0] == '0') ? 0 : 1;
     const char* t13 = getenv("HEXL_AMD_TILE13");
     tile13 = (t13 && t13[0] == '0') ? 0 : (t13 && t13[0] == '1') ? 1 : 2;
   }
@@ -1475,6 +1481,7 @@ int set_tuning(const char* key, u64 value) {
   else if (strcmp(key, "fused_wg_per_cu") == 0) t.fused_wg_per_cu = (u32)value;
   else if (strcmp(key, "fp64") == 0 && value <= 2) t.fp64 = (u32)value;
   else if (strcmp(key, "tile13") == 0 && value <= 2) t.tile13 = (u32)value;
+  else if (strcmp(key, "h60") == 0 && value <= 1) t.h60 = (u32)value;
   else return -1;
   return 0;
 }
@@ -1739,9 +1746,11 @@ template <bool FWD, class A>
 static hipError_t transform_impl(const NttTables& t, u64* result, const u64* operand, u64 batch,
                                  u64 out_mf, hipStream_t st) {
   const Plan p = make_plan((int)t.log_n, true, batch);
-  if (plan_mode() == kPlanFused && p.n_strided == 1 && p.bottom == 11 && !p.top_tile &&
-      p.strided[0] >= 4 && batch >= fused_min_batch() && batch < (1ull << 23))
-    return launch_fused<FWD, A>(p.strided[0], t, result, operand, batch, out_mf == 1 ? 2 : 1, st);
+  if constexpr (!A::kH60) {  // (fused_pass is not instantiated for the Harvey60 policy)
+    if (plan_mode() == kPlanFused && p.n_strided == 1 && p.bottom == 11 && !p.top_tile &&
+        p.strided[0] >= 4 && batch >= fused_min_batch() && batch < (1ull << 23))
+      return launch_fused<FWD, A>(p.strided[0], t, result, operand, batch, out_mf == 1 ? 2 : 1, st);
+  }
   if constexpr (A::kLazy || A::kFp) {  // the policies mixed_pass is instantiated for
     if (plan_mode() == kPlanMixed && t.log_n == 16 && batch >= 2 * (u64)tuning().mixed_chunk.load() &&
         batch < (1ull << 24))
@@ -1758,6 +1767,8 @@ hipError_t ntt_forward_launch(const NttTables& t, u64* result, const u64* operan
     case kPolicySmall: return transform_impl<true, Small>(t, result, operand, batch, out_mf, st);
     case kPolicyFp64: return transform_impl<true, Fp64>(t, result, operand, batch, out_mf, st);
     case kPolicyLazy: return transform_impl<true, Lazy>(t, result, operand, batch, out_mf, st);
+    case kPolicyHarvey60:
+      return transform_impl<true, Harvey60>(t, result, operand, batch, out_mf, st);
     default: return transform_impl<true, Strict>(t, result, operand, batch, out_mf, st);
   }
 }
@@ -1769,6 +1780,8 @@ hipError_t ntt_inverse_launch(const NttTables& t, u64* result, const u64* operan
     case kPolicySmall: return transform_impl<false, Small>(t, result, operand, batch, out_mf, st);
     case kPolicyFp64: return transform_impl<false, Fp64>(t, result, operand, batch, out_mf, st);
     case kPolicyLazy: return transform_impl<false, Lazy>(t, result, operand, batch, out_mf, st);
+    case kPolicyHarvey60:
+      return transform_impl<false, Harvey60>(t, result, operand, batch, out_mf, st);
     default: return transform_impl<false, Strict>(t, result, operand, batch, out_mf, st);
   }
 }
@@ -1792,7 +1805,7 @@ hipError_t ntt_multi_launch(bool forward, const NttTables* const* tabs, u32 num_
   const NttTables& t0 = *tabs[0];
   if (t0.log_n < 12 || t0.log_n > 17) return hipErrorNotSupported;  // one strided + one bottom pass
   MultiCtx mc{};
-  bool have[4] = {false, false, false, false};
+  bool have[kNumPolicies] = {};
   for (u32 k = 0; k < num_plans; ++k) {
     if (tabs[k]->log_n != t0.log_n || !tabs[k]->dev) return hipErrorNotSupported;
     mc.p[k] = tabs[k]->dev;
@@ -1810,6 +1823,8 @@ hipError_t ntt_multi_launch(bool forward, const NttTables* const* tabs, u32 num_
     e = multi_impl<Fp64>(forward, t0, mc, polys, result, operand, out_mf, st);
   if (have[kPolicyLazy] && e == hipSuccess)
     e = multi_impl<Lazy>(forward, t0, mc, polys, result, operand, out_mf, st);
+  if (have[kPolicyHarvey60] && e == hipSuccess)
+    e = multi_impl<Harvey60>(forward, t0, mc, polys, result, operand, out_mf, st);
   if (have[kPolicyStrict] && e == hipSuccess)
     e = multi_impl<Strict>(forward, t0, mc, polys, result, operand, out_mf, st);
   return e;
@@ -1824,6 +1839,8 @@ int choose_policy(u64 q) {
   if (q < kSmallModulusBound && !(fp && tuning().fp64.load() == 2)) return kPolicySmall;
   if (q < kFp64ModulusBound && fp) return kPolicyFp64;
   if (q < kLazyModulusBound) return kPolicyLazy;
+  // HEXL_AMD_H60=0: 2^56 <= q < 2^60 on the Strict policy (A/B runs)
+  if (q < kHarvey60ModulusBound && tuning().h60.load() != 0) return kPolicyHarvey60;
   return kPolicyStrict;
 }
 

@@ -47,7 +47,7 @@ template <class A>
 static void check(u64 n, u64 q, const std::vector<int>& inv_runs, u64 in_mf_f, u64 in_mf_i) {
   int L = 0;
   while ((1ull << L) < n) ++L;
-  const u64 shoup = A::kSmall ? 32 : A::kLazy ? 63 : 64;
+  const u64 shoup = A::kSmall ? 32 : (A::kLazy || A::kH60) ? 63 : 64;
   std::vector<u64> R(n), Rp(n), Ri_stage(n), Rip_stage(n);
   ho_ntt_tables(n, q, ho_minimal_primitive_root(2 * n, q), R.data(), Rp.data(), Ri_stage.data(),
                 Rip_stage.data());
@@ -60,7 +60,7 @@ static void check(u64 n, u64 q, const std::vector<int>& inv_runs, u64 in_mf_f, u
   }
   const ModConst m = make_mod_const(q);
   ++g_cases;
-  const u64 lim = A::kLazy ? (1ull << 63) : ~0ull;
+  const u64 lim = (A::kLazy || A::kH60) ? (1ull << 63) : ~0ull;
 
   for (int canonical = 0; canonical < 2; ++canonical) {
     // ---------------- forward
@@ -83,6 +83,8 @@ static void check(u64 n, u64 q, const std::vector<int>& inv_runs, u64 in_mf_f, u
           if (A::kLazy)
             EXPECT(a < (8 + 6 * (u64)(s + 1)) * q && b < (8 + 6 * (u64)(s + 1)) * q,
                    "fwd lazy bound: stage %d", s);
+          else if (A::kH60)  // Harvey's [0,4q) on doubled values
+            EXPECT(a < 8 * q && b < 8 * q, "fwd harvey60 bound: stage %d", s);
           else
             EXPECT(a < 4 * q && b < 4 * q, "fwd strict bound: stage %d", s);
         }
@@ -147,7 +149,7 @@ static void check(u64 n, u64 q, const std::vector<int>& inv_runs, u64 in_mf_f, u
           EXPECT(x[i] < 8 * q, "inv run exit bound");
         }
       } else if (stage >= 0) {
-        for (u64 i = 0; i < n; ++i) EXPECT(x[i] < 2 * q, "inv strict bound");
+        for (u64 i = 0; i < n; ++i) EXPECT(x[i] < (A::kH60 ? 4 : 2) * q, "inv strict bound");
       }
     }
     EXPECT(stage == -1, "runs do not cover the network");
@@ -389,6 +391,19 @@ int main() {
     for (size_t pi = 0; pi < got; ++pi) check<Strict>(4096, primes[pi], run_sets[0], 4, 2);
     const size_t got2 = ho_generate_primes(primes, 1, 61, 1, 4096);
     for (size_t pi = 0; pi < got2; ++pi) check<Strict>(4096, primes[pi], run_sets[0], 4, 2);
+  }
+  // Harvey60 policy: 2^56 <= q < 2^60, both ends of the range and SEAL-style 60-bit primes
+  {
+    const Case h_cases[] = {{16, 56}, {4096, 56}, {4096, 57}, {8192, 58}, {65536, 59}, {131072, 59}};
+    for (const Case& c : h_cases) {
+      size_t got = ho_generate_primes(primes, 2, c.bits, 1, c.n);
+      got += ho_generate_primes(primes + got, 2, c.bits, 0, c.n);  // walking down from 2^(bits+1)
+      for (size_t pi = 0; pi < got; ++pi) {
+        check<Harvey60>(c.n, primes[pi], run_sets[0], 4, 2);
+        check<Harvey60>(c.n, primes[pi], run_sets[1], 1, 1);
+        check<Harvey60>(c.n, primes[pi], run_sets[3], 2, 2);
+      }
+    }
   }
   // Fp64 policy: moduli from 2^30 up to just below 2^50, including the survey's 50-bit
   // prime of BASELINE configs[1]; run layouts of the kernels (tile rounds 2|3|3|3 with one

@@ -381,14 +381,17 @@ def test_ntt_config4_full_size_one_gpu(hx, ho):
                                              (1 << 16, 49, False), (1 << 20, 49, False),
                                              (1 << 12, 49, False), (1 << 16, 50, True),
                                              (1 << 16, 55, False), (1 << 16, 56, True),
+                                             (1 << 16, 59, False), (1 << 20, 59, False),
+                                             (1 << 12, 59, False), (1 << 16, 60, True),
                                              (1 << 17, 61, False), (1 << 20, 61, False)])
 def test_ntt_policy_boundaries(hx, ho, n, bits, small_end):
-    """Moduli at the edges of the four arithmetic policies: just below 2^30 (Small) and
+    """Moduli at the edges of the five arithmetic policies: just below 2^30 (Small) and
     just above it (Fp64), just below 2^50 (Fp64: exact integers in doubles, 7-stage
     forward runs reach 7.9 q < 2^53) and just above it (Lazy), just below 2^56 (Lazy:
     with input_mod_factor 4 at N = 2^20 the doubled values reach (8 + 6*20) q = 128 q,
-    just under 2^63) and just above it (Strict), just below 2^62 (the largest moduli the
-    API admits).  All (in, out) factors."""
+    just under 2^63) and just above it (Harvey60), just below 2^60 (Harvey60: doubled values
+    up to 8 q, just under 2^63) and just above it (Strict), just below 2^62 (the largest
+    moduli the API admits).  All (in, out) factors."""
     q = ho.generate_primes(1, bits, small_end, n)[0]
     lo, hi = 1 << bits, 1 << (bits + 1)
     assert lo < q < hi and ((q - lo) < (hi - lo) // 8 if small_end else (hi - q) < (hi - lo) // 8)
@@ -445,6 +448,40 @@ def test_ntt_fp64_policy_matches_integer_policy(hx, n, batch):
         fp.ComputeInverse(b, x, in_mf, 1)
         assert torch.equal(a, b)
         fp.ComputeInverse(x, x, in_mf, 2)  # in place, lazy output range
+        assert int(x.min()) >= 0 and int(x.max()) < 2 * q and torch.equal(x % q, a)
+
+
+@pytest.mark.parametrize("n,batch,bits,small_end", [(4096, 64, 59, False), (65536, 64, 59, False),
+                                                    (1 << 17, 3, 56, True), (1 << 13, 5, 58, True),
+                                                    (1 << 14, 200, 59, False), (64, 7, 57, True)])
+def test_ntt_harvey60_policy_matches_strict_policy(hx, n, batch, bits, small_end):
+    """2^56 <= q < 2^60 (SEAL's and OpenFHE's 60-bit primes): the Harvey60 arithmetic policy
+    (Harvey ranges on doubled values, carry-free products) against the Strict policy on the
+    same inputs, bit for bit -- plans built with the policy switched on and off."""
+    import torch
+    q = hx.GeneratePrimes(1, bits, small_end, n)[0]
+    try:
+        hx.set_tuning("h60", 0)
+        strict = hx.NTT(n, q)
+        hx.set_tuning("h60", 1)
+        h60 = hx.NTT(n, q)
+    finally:
+        hx.set_tuning("h60", 1)
+    x = torch.empty((batch, n), dtype=torch.int64, device="cuda")
+    for in_mf in (1, 2, 4):
+        hx.fill_splitmix(x, n, batch, 81, in_mf * q)
+        a, b = torch.empty_like(x), torch.empty_like(x)
+        strict.ComputeForward(a, x, in_mf, 1)
+        h60.ComputeForward(b, x, in_mf, 1)
+        assert torch.equal(a, b)
+        h60.ComputeForward(b, x, in_mf, 4)
+        assert int(b.min()) >= 0 and int(b.max()) < 4 * q and torch.equal(b % q, a)
+    for in_mf in (1, 2):
+        hx.fill_splitmix(x, n, batch, 82, in_mf * q)
+        strict.ComputeInverse(a, x, in_mf, 1)
+        h60.ComputeInverse(b, x, in_mf, 1)
+        assert torch.equal(a, b)
+        h60.ComputeInverse(x, x, in_mf, 2)  # in place, lazy output range
         assert int(x.min()) >= 0 and int(x.max()) < 2 * q and torch.equal(x % q, a)
 
 

@@ -851,10 +851,12 @@ static int ntt_mapped(bool forward, const std::vector<const hexl_amd_ntt*>& plan
 }
 
 // Device buffers throughout; T targets that share moduli and keys.  `keys`: host array of
-// D device pointers.  Twelve launches whatever T, D and C are (degree >= 8192): inverse
-// NTT of the targets (2), gather (1), lazy forward NTT of all product operands (2),
-// multiply-accumulate (1), inverse NTT of the last components (2), rounding (1), forward
-// NTT of the corrections (2), finish (1).
+// D device pointers.  At most eleven launches whatever T, D and C are (degree >= 4096;
+// seven where the transforms are one kernel, N = 8192 and N = 16384 with enough polynomials):
+// inverse NTT of the targets (1-2), lazy forward NTT of all product operands, reading the
+// coefficient-form targets through a source map and reducing them on load (1-2),
+// multiply-accumulate (1), inverse NTT of the last components (1-2), rounding (1), forward
+// NTT of the corrections (1-2), finish (1).
 static int key_switch_device(u64* result, const u64* t_target_iter, u64 T, u64 n, u64 D, u64 K,
                              u64 R, u64 C, const u64* moduli, const u64* const* keys,
                              const u64* msf, hipStream_t st) {
@@ -908,15 +910,35 @@ static int key_switch_device(u64* result, const u64* t_target_iter, u64 T, u64 n
     m.shift[i] = ceil_log - 2;
     m.mu[i] = (u64)((((unsigned __int128)(1ull << (ceil_log + 62 - 64))) << 64) / q);
   }
-  e = ks_gather_launch(ntt_buf, t_target, dims, g, st);
-  if (e != hipSuccess) return hip_fail(e, "KeySwitch gather");
   {
+    // The D^2 product operands of a target, ordered by RNS index i: target polynomial j
+    // (coefficient form) reduced to q_i where moduli[j] is larger, for every j != i (i < D)
+    // or every j (i == D).  The first pass of their forward transform reads them straight
+    // from t_target through the source map (MultiMap); only where the multi-plan launch
+    // does not apply (small degrees) are they gathered into ntt_buf first.
     MultiMap map{};
     map.inner = 1;
     map.period = (u32)(D * D);
-    for (u64 s = 0; s < D * D; ++s)
-      map.plan_tab[s] = (uint8_t)(s < D * (D - 1) ? s / (D - 1) : D);
-    if (int rc = ntt_mapped(true, plan, map, T * D * D, ntt_buf, ntt_buf, n, 4, st)) return rc;
+    map.src_stride = (u32)D;
+    for (u64 s = 0; s < D * D; ++s) {
+      const u64 i = s < D * (D - 1) ? s / (D - 1) : D;
+      const u64 r = s - i * (D - 1);
+      const u64 j = i < D ? (r < i ? r : r + 1) : s - D * (D - 1);
+      map.plan_tab[s] = (uint8_t)i;
+      map.src_tab[s] = (uint8_t)(j | (((g.reduce_mask[i] >> j) & 1) ? 0x80 : 0));
+    }
+    std::vector<const NttTables*> tabs(plan.size());
+    for (size_t k = 0; k < plan.size(); ++k) tabs[k] = &plan[k]->t;
+    e = ntt_multi_launch(true, tabs.data(), (u32)tabs.size(), map, T * D * D, ntt_buf, t_target,
+                         4, st);
+    if (e == hipErrorNotSupported) {
+      e = ks_gather_launch(ntt_buf, t_target, dims, g, st);
+      if (e != hipSuccess) return hip_fail(e, "KeySwitch gather");
+      map.src_stride = 0;
+      if (int rc = ntt_mapped(true, plan, map, T * D * D, ntt_buf, ntt_buf, n, 4, st)) return rc;
+    } else if (e != hipSuccess) {
+      return hip_fail(e, "KeySwitch multi-plan NTT");
+    }
   }
   e = ks_mac_launch(prod, t_target_iter, ntt_buf, dims, m, st);
   if (e != hipSuccess) return hip_fail(e, "KeySwitch multiply-accumulate");

@@ -101,9 +101,18 @@ constexpr int kMaxMultiPeriod = 1024;
 //   plan = plan_tab[(polynomial / inner) % period]
 // (RNS limbs: inner = polynomials per modulus, period = number of moduli, identity table;
 // KeySwitch: inner = 1, period = polynomials per target, table = modulus of each).
+// Optionally the INPUT of a polynomial lives elsewhere (KeySwitch: the D^2 product operands
+// of a target are its D coefficient-form polynomials, each reduced to the key modulus where
+// that is smaller -- key-switch-internal.cpp:77-89 -- and the first pass of the transform
+// reads them straight from there instead of from a gathered copy): with src_stride != 0
+// (inner must be 1) polynomial p reads
+//   operand[(p / period) * src_stride + (src_tab[p % period] & 0x7f)]
+// and reduces every word modulo its own modulus first when bit 7 of the entry is set.
 struct MultiMap {
   u32 inner, period;
   uint8_t plan_tab[kMaxMultiPeriod];
+  u32 src_stride;
+  uint8_t src_tab[kMaxMultiPeriod];
 };
 
 // One transform over `polys` polynomials of several moduli (all plans: same degree in

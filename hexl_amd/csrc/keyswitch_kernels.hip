@@ -15,11 +15,9 @@
 
 namespace hexl_amd {
 
-// x mod q for any 64-bit x: single-word Barrett, floor(2^64 / q)
-// (eltwise-reduce-mod.cpp:32-55 with input_mod_factor == modulus)
+// x mod q for any 64-bit x (modarith.h)
 __device__ __forceinline__ u64 full_reduce(u64 x, u64 q, u64 barrett) {
-  if (x < q) return x;
-  return csub(x - __umul64hi(x, barrett) * q, q);
+  return reduce_any(x, q, barrett);
 }
 
 // Work decomposition of every kernel: blockIdx.x strides over the n coefficients,

@@ -92,6 +92,7 @@ struct ModConst {
   u64 two_q;
   u64 neg_q;  // 2^64 - q (Strict policy)
   u64 neg_two_q;  // 2^64 - 2q
+  u64 barrett;    // floor(2^64 / q): single-word Barrett factor (reduce_any)
   // Harvey60 policy only:
   u64 four_q;
   u64 neg_four_q;  // 2^64 - 4q
@@ -110,6 +111,7 @@ inline ModConst make_mod_const(u64 q) {  // host only
   m.two_q = q << 1;
   m.neg_q = 0 - q;
   m.neg_two_q = 0 - (q << 1);
+  m.barrett = (u64)((((unsigned __int128)1) << 64) / q);
   m.four_q = q << 2;  // only meaningful (and only read) for q < 2^60
   m.neg_four_q = 0 - (q << 2);
   m.six_q = 6 * q;  // only meaningful (and only read) for q < 2^56
@@ -120,6 +122,13 @@ inline ModConst make_mod_const(u64 q) {  // host only
   m.qd = (double)q;  // exact for q < 2^53; only read for q < 2^50
   m.qinv = 1.0 / m.qd;
   return m;
+}
+
+// x mod q for ANY 64-bit x: single-word Barrett with floor(2^64 / q)
+// (hexl/eltwise/eltwise-reduce-mod.cpp:32-55 with input_mod_factor == modulus)
+HX_HD u64 reduce_any(u64 x, u64 q, u64 barrett) {
+  if (x < q) return x;
+  return csub(x - mul_hi64(x, barrett) * q, q);
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -87,6 +87,9 @@ extern "C" int hexl_amd_debug_set_phase_buf(void* buf) {
 // [0,q).  Bit 2: this pass starts the network (its input is the caller's data).
 constexpr u32 kFinishMask = 3;
 constexpr u32 kFirstPass = 4;
+// Bit 3 (with bit 2): the input words are arbitrary 64-bit values and are reduced modulo q
+// on load (multi-plan launches with a source map, see MultiMap).
+constexpr u32 kReduceFirst = 8;
 
 // Global access as wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte
 // offset: `global_load/store v, v_off, s[base]`, no 64-bit vector address math and
@@ -406,6 +409,10 @@ __device__ __forceinline__ void strided_body(u64* out, const u64* in,
   for (int e = 0; e < E; ++e) x[e] = ld_global<LDK>(&in[vbase + ((u64)e << log_s)]);
   if (FWD) __builtin_amdgcn_s_setprio(0);
   if (flags & kFirstPass) {
+    if (flags & kReduceFirst) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) x[e] = reduce_any(x[e], m.q, m.barrett);
+    }
 #pragma unroll
     for (int e = 0; e < E; ++e) x[e] = to_internal<A>(x[e], m);
   }
@@ -473,6 +480,18 @@ __device__ __forceinline__ const PlanDev* multi_plan(const MultiCtx& mc, u32 pol
   const u32 pol = __builtin_amdgcn_readfirstlane((u32)mc.policy[k]);
   return pol == (u32)want ? mc.p[k] : nullptr;
 }
+// Source map of a multi-plan launch (MultiMap): where polynomial `poly` of the FIRST pass
+// reads its input, as an adjusted `in` pointer (the bodies index by output position), and
+// whether its words are reduced on load.
+__device__ __forceinline__ const u64* multi_source(const MultiCtx& mc, u32 poly, u32 log_n,
+                                                   const u64* in, u32& flags) {
+  if (mc.map.src_stride == 0 || !(flags & kFirstPass)) return in;
+  const u32 s = poly % mc.map.period, grp = poly / mc.map.period;
+  const u32 e = __builtin_amdgcn_readfirstlane((u32)mc.map.src_tab[s]);
+  const u32 src = grp * mc.map.src_stride + (e & 0x7f);
+  if (e & 0x80) flags |= kReduceFirst;
+  return in + (((long long)src - (long long)poly) << log_n);
+}
 template <class A>
 constexpr int policy_id() {
   return A::kSmall ? kPolicySmall
@@ -494,6 +513,7 @@ strided_pass_multi(u64* out, const u64* in, MultiCtx mc, u32 log_n, u32 a0, u32 
   if (!pd) return;
   const ModConst m = pd->mod;
   const InvLast il = pd->il;
+  in = multi_source(mc, poly, log_n, in, flags);
   strided_body<FWD, R, A, LAST, kStream, kStream>(out, in, FWD ? pd->fwd : pd->inv, m, log_n, a0,
                                                   flags, bid, il);
 }
@@ -796,7 +816,7 @@ __device__ __forceinline__ constexpr u32 xfer_dp(int i) {
 // smaller than / not a multiple of the tile); otherwise every access is in range.
 template <bool ROUND0, int S, int CB, int TL, bool GUARD, class A, int LDK>
 __device__ __forceinline__ void fetch_tile(u64* x, const u64* in, u32 tid, const TileGeom& g,
-                                           u64 total, bool first, const ModConst& m) {
+                                           u64 total, u32 flags, const ModConst& m) {
   constexpr int kRE = re_of(S), kE = el_of(S);
 #pragma unroll
   for (int i = 0; i < kE; ++i) {
@@ -812,7 +832,11 @@ __device__ __forceinline__ void fetch_tile(u64* x, const u64* in, u32 tid, const
       x[i] = load_global<LDK>(src, tile_byte_offset<CB>(g, p0));
 #endif
   }
-  if (first) {
+  if (flags & kFirstPass) {
+    if (flags & kReduceFirst) {
+#pragma unroll
+      for (int i = 0; i < kE; ++i) x[i] = reduce_any(x[i], m.q, m.barrett);
+    }
 #pragma unroll
     for (int i = 0; i < kE; ++i) x[i] = to_internal<A>(x[i], m);
   }
@@ -877,7 +901,7 @@ __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
     {  // round 0 straight from global memory; its twiddles are requested first
       TwT<A> wv[kE];
       round_twiddles<S, CB, TL, 0>(wv, tw, tid, g);
-      fetch_tile<true, S, CB, TL, GUARD, A, LDK>(x, in, tid, g, total, first, m);  // round-0 set
+      fetch_tile<true, S, CB, TL, GUARD, A, LDK>(x, in, tid, g, total, flags, m);  // round-0 set
       __builtin_amdgcn_s_setprio(0);
       if constexpr (RD::pre_fwd(1)) round_twiddles<S, CB, TL, 1>(wn, tw, tid, g);
       HX_PROFILE_WAIT_VMEM();
@@ -911,7 +935,7 @@ __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
     // round are requested first
     TwT<A> wtop[kE], w0[kE];
     if constexpr (NR > 1) round_twiddles<S, CB, TL, NR - 1>(wtop, tw, tid, g);
-    fetch_tile<false, S, CB, TL, GUARD, A, LDK>(x, in, tid, g, total, first, m);
+    fetch_tile<false, S, CB, TL, GUARD, A, LDK>(x, in, tid, g, total, flags, m);
     __builtin_amdgcn_s_setprio(0);
     {
       const u32 a0 = lds_slot(xfer_p0<false, S, CB, TL>(tid, 0)) << 3;
@@ -956,6 +980,7 @@ tile_pass_multi(u64* out, const u64* in, MultiCtx mc, u32 log_n, u32 flags, u64 
   if (!pd) return;
   const ModConst m = pd->mod;
   const InvLast il = pd->il;
+  in = multi_source(mc, poly, log_n, in, flags);
   tile_body<FWD, S, 0, TL, false, A, LAST, FWD ? kStream : kPlain, FWD ? kStream : kPlain>(
       lds, out, in, FWD ? pd->fwd : pd->inv, m, log_n, flags, total, il, blockIdx.x);
 }
@@ -1317,7 +1342,7 @@ static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2
   ScopedKernelTimer timer(FWD ? "ntt_fwd_tile_pass_bottom" : "ntt_inv_tile_pass_bottom", st);
   if (mc) {  // several moduli: the shapes N >= 4096 use
     if constexpr (TL >= 11) {
-      if (log_n < (u32)TL || (S != 11 && S != 12) || S > TL) return hipErrorNotSupported;
+      if (log_n < (u32)TL || S < 11 || S > 14 || S > TL) return hipErrorNotSupported;
       const bool last = !FWD && (u32)S == log_n;
 #define HX_LAUNCH_BM(T, LST)                                                                \
   hipLaunchKernelGGL((tile_pass_multi<FWD, T, TL, A, LST>), dim3(grid), dim3(1 << (TL - re_of(T))), \
@@ -1328,9 +1353,21 @@ static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2
         } else {
           return hipErrorNotSupported;
         }
-      } else {
+      } else if (S == 12) {
         if constexpr (TL == 12) {
           if (last) HX_LAUNCH_BM(12, !FWD); else HX_LAUNCH_BM(12, false);
+        } else {
+          return hipErrorNotSupported;
+        }
+      } else if (S == 13) {  // N = 8192 as one kernel (64 KiB tile)
+        if constexpr (TL == 13) {
+          if (last) HX_LAUNCH_BM(13, !FWD); else HX_LAUNCH_BM(13, false);
+        } else {
+          return hipErrorNotSupported;
+        }
+      } else {  // N = 16384 as one kernel (128 KiB tile)
+        if constexpr (TL == 14) {
+          if (last) HX_LAUNCH_BM(14, !FWD); else HX_LAUNCH_BM(14, false);
         } else {
           return hipErrorNotSupported;
         }
@@ -1789,7 +1826,8 @@ hipError_t ntt_inverse_launch(const NttTables& t, u64* result, const u64* operan
 template <class A>
 static hipError_t multi_impl(bool forward, const NttTables& t0, const MultiCtx& mc, u64 polys,
                              u64* result, const u64* operand, u64 out_mf, hipStream_t st) {
-  Plan p = make_plan((int)t0.log_n, /*allow_tile13=*/false);  // the multi-plan kernels: 11 / 12 stages
+  // the multi-plan kernels: 11 / 12 bottom stages, or the whole of N = 8192 / 16384
+  Plan p = make_plan((int)t0.log_n, /*allow_tile13=*/true, polys);
   if (plan_mode() == kPlanTiled) return hipErrorNotSupported;
   return forward ? forward_seq<A>(t0, p, result, operand, polys, out_mf, st, &mc)
                  : inverse_seq<A>(t0, p, result, operand, polys, out_mf, st, &mc);
@@ -1800,7 +1838,7 @@ hipError_t ntt_multi_launch(bool forward, const NttTables* const* tabs, u32 num_
                             u64 out_mf, hipStream_t st) {
   if (num_plans == 0 || polys == 0) return hipSuccess;
   if (num_plans > (u32)kMaxMultiPlans || polys >= (1ull << 31) || map.inner == 0 ||
-      map.period == 0 || map.period > (u32)kMaxMultiPeriod)
+      map.period == 0 || map.period > (u32)kMaxMultiPeriod || (map.src_stride && map.inner != 1))
     return hipErrorNotSupported;
   const NttTables& t0 = *tabs[0];
   if (t0.log_n < 12 || t0.log_n > 17) return hipErrorNotSupported;  // one strided + one bottom pass

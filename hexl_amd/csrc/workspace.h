@@ -22,7 +22,7 @@ hipError_t stream_workspace(WorkspacePurpose purpose, hipStream_t stream, size_t
                             void** out);
 
 // Held while a multi-launch sequence that uses a stream workspace is being ENQUEUED
-// (KeySwitch: twelve launches over one scratch buffer): two host threads that issue such
+// (KeySwitch: up to eleven launches over one scratch buffer): two host threads that issue such
 // sequences on the same stream would otherwise interleave their launches -- stream order
 // then serialises the kernels, but of two half-finished sequences over one buffer -- or
 // free the buffer the other is still enqueuing against.  Keyed like the buffers by

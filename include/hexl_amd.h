@@ -260,7 +260,7 @@ int hexl_amd_key_switch(uint64_t* result, const uint64_t* t_target_iter_ptr,
                         const uint64_t* modswitch_factors, void* stream);
 /* Many ciphertexts with the same keys and moduli in one call -- the loop SEAL runs around
  * KeySwitch (one call per ciphertext, key-switch-internal.cpp:25-201 each time) as ONE
- * sequence of twelve launches: t_target_iter_ptr holds num_targets targets back to back
+ * sequence of at most eleven launches: t_target_iter_ptr holds num_targets targets back to back
  * (each decomp_modulus_size x n), result num_targets results back to back (each
  * key_component_count x decomp_modulus_size x n, accumulated into).  Every per-modulus
  * transform of every target runs in one multi-plan NTT launch.  num_targets *

@@ -993,7 +993,7 @@ def test_key_switch_random_vs_oracle(hx, ho, n, D, K, C, bits):
 @pytest.mark.parametrize("n,D,K,C,T,bits", [(4096, 3, 4, 2, 5, 50), (8192, 4, 5, 2, 3, 54),
                                             (64, 2, 3, 2, 4, 40), (16384, 7, 8, 2, 2, 45)])
 def test_key_switch_batch_vs_oracle(hx, ho, n, D, K, C, T, bits):
-    """Many ciphertexts with the same keys in one call (one sequence of twelve launches, the
+    """Many ciphertexts with the same keys in one call (one sequence of at most eleven launches, the
     per-modulus transforms of all targets in multi-plan NTT launches) against the oracle
     run target by target; moduli of mixed size, hence of mixed arithmetic policy."""
     rng = np.random.default_rng(n + D + T)
@@ -1053,7 +1053,7 @@ def test_key_switch_two_streams_do_not_share_scratch(hx, ho):
 
 def test_key_switch_two_threads_one_stream(hx, ho):
     """Two host threads issuing KeySwitch on the SAME stream (both on the default stream):
-    each call's twelve launches must stay together on the stream, or the two calls run over
+    each call's launches must stay together on the stream, or the two calls run over
     each other's scratch (the sequence lock of workspace.h)."""
     import threading
     import torch

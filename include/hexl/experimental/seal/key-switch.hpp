@@ -21,7 +21,7 @@ void KeySwitch(uint64_t* result, const uint64_t* t_target_iter_ptr, uint64_t n,
 
 /// Additive extension (not in the reference): `num_targets` ciphertexts with the same keys
 /// and moduli in one call -- targets and results back to back in the layouts above, all
-/// DEVICE memory.  One sequence of twelve launches whatever the sizes (hexl_amd_key_switch_batch).
+/// DEVICE memory.  One sequence of at most eleven launches whatever the sizes (hexl_amd_key_switch_batch).
 void KeySwitchBatch(uint64_t* result, const uint64_t* t_target_iter_ptr, uint64_t num_targets,
                     uint64_t n, uint64_t decomp_modulus_size, uint64_t key_modulus_size,
                     uint64_t rns_modulus_size, uint64_t key_component_count,

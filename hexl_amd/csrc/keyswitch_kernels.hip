@@ -52,35 +52,70 @@ ks_gather_kernel(u64* ntt_buf, const u64* t_target, KsDims d, KsGatherAll g) {
 }
 
 // :94-130 multiply with the keys, accumulate in 128 bits, reduce once.
-// blockIdx.y = RNS index i, blockIdx.z = target * C + key component k.
+// blockIdx.y = RNS index i, blockIdx.z = (tile of kMacTargets targets) * ceil(C / 2) + pair
+// of key components.  A thread applies the key words of its coefficient -- for two key
+// components -- to kMacTargets targets: the keys (D * C * (D + 1) polynomials, the largest
+// operand of the whole KeySwitch) are read once per tile of targets instead of once per
+// target, and a target's operands once per pair of components instead of once per component.
+constexpr int kMacTargets = 4;
 __global__ void __launch_bounds__(256)
 ks_mac_kernel(u64* prod, const u64* t_target_iter, const u64* ntt_buf, KsDims d, KsMacAll m) {
   const u32 D = d.decomp, i = blockIdx.y;
-  const u32 tgt = blockIdx.z / d.components, k = blockIdx.z - tgt * d.components;
+  const u32 pairs = (d.components + 1) >> 1;
+  const u32 tile = blockIdx.z / pairs, k0 = (blockIdx.z - tile * pairs) * 2;
+  const bool two = k0 + 1 < d.components;
+  const u32 t0 = tile * kMacTargets;
+  const u32 nt = d.targets - t0 < (u32)kMacTargets ? d.targets - t0 : (u32)kMacTargets;
   const u64 n = d.n;
-  const u64 key_off = ((u64)k * d.key_moduli + m.key_index[i]) * n;
-  u64* dst = prod + (((u64)i * d.targets + tgt) * d.components + k) * n;
-  const u64* own = t_target_iter + (u64)tgt * D * n;    // NTT-form operands (j == i)
-  const u64* buf = ntt_buf + ((u64)tgt * D * D + (i < D ? (u64)i * (D - 1) : (u64)D * (D - 1))) * n;
+  const u64 key_off0 = ((u64)k0 * d.key_moduli + m.key_index[i]) * n;
+  const u64 key_off1 = key_off0 + (two ? (u64)d.key_moduli * n : 0);
+  const u64 buf_off = i < D ? (u64)i * (D - 1) : (u64)D * (D - 1);  // first operand of index i
   const u64 q = m.q[i], barrett = m.barrett[i], two64 = m.two64_mod_q[i], mu = m.mu[i];
   const u32 shift = m.shift[i];
   const u64 stride = (u64)gridDim.x * 256;
   for (u64 l = (u64)blockIdx.x * 256 + threadIdx.x; l < n; l += stride) {
-    u64 lo = 0, hi = 0;
+    u64 lo[2][kMacTargets], hi[2][kMacTargets];
+#pragma unroll
+    for (int t = 0; t < kMacTargets; ++t) lo[0][t] = hi[0][t] = lo[1][t] = hi[1][t] = 0;
     for (u32 j = 0; j < D; ++j) {
-      const u64 a = (j == i) ? own[(u64)j * n + l] : buf[(u64)(j < i ? j : (i < D ? j - 1 : j)) * n + l];
-      const u64 b = m.keys[j][key_off + l];
-      const u64 plo = a * b, phi = __umul64hi(a, b);
-      lo += plo;
-      hi += phi + (lo < plo);
+      const u64 b0 = m.keys[j][key_off0 + l];
+      const u64 b1 = m.keys[j][key_off1 + l];
+      // operand j of RNS index i: the target's own NTT-form polynomial (j == i) or the
+      // transformed product operand
+      const u64 slot = (j == i) ? 0 : buf_off + (j < i ? j : (i < D ? j - 1 : j));
+#pragma unroll
+      for (int t = 0; t < kMacTargets; ++t) {
+        if ((u32)t < nt) {
+          const u64 tgt = t0 + t;
+          const u64 a = (j == i) ? t_target_iter[(tgt * D + j) * n + l]
+                                 : ntt_buf[(tgt * D * D + slot) * n + l];
+          u64 plo = a * b0, phi = __umul64hi(a, b0);
+          lo[0][t] += plo;
+          hi[0][t] += phi + (lo[0][t] < plo);
+          plo = a * b1;
+          phi = __umul64hi(a, b1);
+          lo[1][t] += plo;
+          hi[1][t] += phi + (lo[1][t] < plo);
+        }
+      }
     }
-    // (hi * 2^64 + lo) mod q exactly (BarrettReduce128, util/gcc.hpp:20-28)
-    const u64 r1 = full_reduce(hi, q, barrett);
-    const u64 r2 = full_reduce(lo, q, barrett);
-    const u64 plo = r1 * two64, phi = __umul64hi(r1, two64);
-    const u64 c1 = shift ? ((plo >> shift) | (phi << (64 - shift))) : plo;
-    const u64 r = csub(plo - __umul64hi(c1, mu) * q, q);
-    dst[l] = csub(r + r2, q);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (c == 0 || two) {
+#pragma unroll
+        for (int t = 0; t < kMacTargets; ++t) {
+          if ((u32)t < nt) {
+            // (hi * 2^64 + lo) mod q exactly (BarrettReduce128, util/gcc.hpp:20-28)
+            const u64 r1 = full_reduce(hi[c][t], q, barrett);
+            const u64 r2 = full_reduce(lo[c][t], q, barrett);
+            const u64 plo = r1 * two64, phi = __umul64hi(r1, two64);
+            const u64 c1 = shift ? ((plo >> shift) | (phi << (64 - shift))) : plo;
+            const u64 r = csub(plo - __umul64hi(c1, mu) * q, q);
+            prod[(((u64)i * d.targets + t0 + t) * d.components + k0 + c) * n + l] = csub(r + r2, q);
+          }
+        }
+      }
+    }
   }
 }
 
@@ -134,7 +169,9 @@ hipError_t ks_gather_launch(u64* ntt_buf, const u64* t_target, const KsDims& d,
 }
 hipError_t ks_mac_launch(u64* prod, const u64* t_target_iter, const u64* ntt_buf, const KsDims& d,
                          const KsMacAll& m, hipStream_t st) {
-  hipLaunchKernelGGL(ks_mac_kernel, dim3(ks_grid(d.n), d.decomp + 1, d.targets * d.components),
+  hipLaunchKernelGGL(ks_mac_kernel,
+                     dim3(ks_grid(d.n), d.decomp + 1,
+                          ((d.targets + kMacTargets - 1) / kMacTargets) * ((d.components + 1) / 2)),
                      dim3(256), 0, st, prod, t_target_iter, ntt_buf, d, m);
   return hipGetLastError();
 }

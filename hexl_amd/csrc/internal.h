@@ -28,8 +28,11 @@ constexpr u64 kSmallModulusBound = 1ull << 30;
 constexpr u64 kFp64ModulusBound = 1ull << 50;
 
 // Moduli in [kLazyModulusBound, kHarvey60ModulusBound) use the Harvey60 policy (Harvey ranges
-// on doubled values; 63-bit Shoup factors like Lazy).
-constexpr u64 kHarvey60ModulusBound = 1ull << 60;
+// on doubled values; 63-bit Shoup factors like Lazy).  Its products need the high word of
+// a doubled value (< 8q) to stay <= 2^31, i.e. 8q <= 2^63 + 2^31: the bound sits 2^28 above
+// 2^60, which takes in the smallest primes above 2^60 -- what GeneratePrimes(., 60, true, .)
+// returns, the reference's "61-bit" test and benchmark moduli (BASELINE configs[4]).
+constexpr u64 kHarvey60ModulusBound = (1ull << 60) + (1ull << 28);
 
 enum ArithPolicy : int {
   kPolicySmall = 0,

@@ -222,12 +222,15 @@ struct Lazy {  // q < 2^56; tables hold floor(W * 2^63 / q); doubled values
   static constexpr bool kFp = false;
   static constexpr bool kH60 = false;
 };
-// 2^56 <= q < 2^60 (where SEAL's and OpenFHE's 60-bit primes live): the reference's Harvey
-// invariants -- forward values in [0,4q), inverse values in [0,2q), one conditional
-// subtraction per butterfly -- held on DOUBLED values (D = 2x < 8q < 2^63) like the Lazy
-// policy's, so that the product is its carry-free v_mad_u64_u32 chain with a 63-bit Shoup
-// factor (exact quotient: T2 in [0,4q)) and the conditional subtraction a sign test:
-// 19 (forward) / 20 (inverse) instructions per butterfly against Strict's 23.
+// 2^56 <= q < 2^60 + 2^28 (where SEAL's and OpenFHE's 60-bit primes live, and the smallest
+// primes above 2^60 that the reference's tests and benchmarks generate): the reference's
+// Harvey invariants -- forward values in [0,4q), inverse values in [0,2q), one conditional
+// subtraction per butterfly -- held on DOUBLED values (D = 2x < 8q) like the Lazy policy's,
+// so that the product is its carry-free v_mad_u64_u32 chain with a 63-bit Shoup factor
+// (exact quotient: T2 < 3q + q D / 2^63 < 4q) and the conditional subtraction a sign test
+// (4q < 2^63): 19 (forward) / 20 (inverse) instructions per butterfly against Strict's 23.
+// The chain's middle column a1*b0 + a0*b1 + hi(a0*b0) stays below 2^64 as long as
+// a1 = D >> 32 <= 2^31 (b1 < 2^31): 8q <= 2^63 + 2^31, hence the bound.
 struct Harvey60 {
   static constexpr bool kLazy = false;
   static constexpr bool kSmall = false;

@@ -1877,7 +1877,7 @@ int choose_policy(u64 q) {
   if (q < kSmallModulusBound && !(fp && tuning().fp64.load() == 2)) return kPolicySmall;
   if (q < kFp64ModulusBound && fp) return kPolicyFp64;
   if (q < kLazyModulusBound) return kPolicyLazy;
-  // HEXL_AMD_H60=0: 2^56 <= q < 2^60 on the Strict policy (A/B runs)
+  // HEXL_AMD_H60=0: 2^56 <= q < 2^60 + 2^28 on the Strict policy (A/B runs)
   if (q < kHarvey60ModulusBound && tuning().h60.load() != 0) return kPolicyHarvey60;
   return kPolicyStrict;
 }

@@ -342,7 +342,7 @@ int hexl_amd_profile_get(int i, const char** name, float* ms);
  *   "fp64"             1 (default) = plans for 2^30 <= q < 2^50 use the Fp64 arithmetic
  *                      policy (exact integers in doubles), 0 = the integer Lazy policy;
  *                      read when a plan is created
- *   "h60"              1 (default) = plans for 2^56 <= q < 2^60 use the Harvey60 arithmetic
+ *   "h60"              1 (default) = plans for 2^56 <= q < 2^60 + 2^28 use the Harvey60 arithmetic
  *                      policy (Harvey ranges on doubled values, 19/20-instruction
  *                      butterflies), 0 = the Strict policy; read when a plan is created
  *   "tile13"           which degrees above 4096 run as ONE kernel on an LDS tile holding the

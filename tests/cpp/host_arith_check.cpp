@@ -60,7 +60,8 @@ static void check(u64 n, u64 q, const std::vector<int>& inv_runs, u64 in_mf_f, u
   }
   const ModConst m = make_mod_const(q);
   ++g_cases;
-  const u64 lim = (A::kLazy || A::kH60) ? (1ull << 63) : ~0ull;
+  // doubled values: below 2^63 (Lazy), high word <= 2^31 (Harvey60)
+  const u64 lim = A::kLazy ? (1ull << 63) : A::kH60 ? (1ull << 63) + (1ull << 32) : ~0ull;
 
   for (int canonical = 0; canonical < 2; ++canonical) {
     // ---------------- forward
@@ -392,12 +393,14 @@ int main() {
     const size_t got2 = ho_generate_primes(primes, 1, 61, 1, 4096);
     for (size_t pi = 0; pi < got2; ++pi) check<Strict>(4096, primes[pi], run_sets[0], 4, 2);
   }
-  // Harvey60 policy: 2^56 <= q < 2^60, both ends of the range and SEAL-style 60-bit primes
+  // Harvey60 policy: 2^56 <= q < 2^60 + 2^28, both ends of the range, SEAL-style 60-bit primes
   {
-    const Case h_cases[] = {{16, 56}, {4096, 56}, {4096, 57}, {8192, 58}, {65536, 59}, {131072, 59}};
+    // ({., 60}: only the primes just above 2^60 -- upwards from 2^60 -- are inside the range)
+    const Case h_cases[] = {{16, 56}, {4096, 56}, {4096, 57}, {8192, 58}, {65536, 59}, {131072, 59},
+                            {4096, 60}, {131072, 60}};
     for (const Case& c : h_cases) {
       size_t got = ho_generate_primes(primes, 2, c.bits, 1, c.n);
-      got += ho_generate_primes(primes + got, 2, c.bits, 0, c.n);  // walking down from 2^(bits+1)
+      if (c.bits < 60) got += ho_generate_primes(primes + got, 2, c.bits, 0, c.n);  // down from 2^(bits+1)
       for (size_t pi = 0; pi < got; ++pi) {
         check<Harvey60>(c.n, primes[pi], run_sets[0], 4, 2);
         check<Harvey60>(c.n, primes[pi], run_sets[1], 1, 1);

@@ -383,15 +383,17 @@ def test_ntt_config4_full_size_one_gpu(hx, ho):
                                              (1 << 16, 55, False), (1 << 16, 56, True),
                                              (1 << 16, 59, False), (1 << 20, 59, False),
                                              (1 << 12, 59, False), (1 << 16, 60, True),
+                                             (1 << 17, 60, True), (1 << 16, 60, False),
                                              (1 << 17, 61, False), (1 << 20, 61, False)])
 def test_ntt_policy_boundaries(hx, ho, n, bits, small_end):
     """Moduli at the edges of the five arithmetic policies: just below 2^30 (Small) and
     just above it (Fp64), just below 2^50 (Fp64: exact integers in doubles, 7-stage
     forward runs reach 7.9 q < 2^53) and just above it (Lazy), just below 2^56 (Lazy:
     with input_mod_factor 4 at N = 2^20 the doubled values reach (8 + 6*20) q = 128 q,
-    just under 2^63) and just above it (Harvey60), just below 2^60 (Harvey60: doubled values
-    up to 8 q, just under 2^63) and just above it (Strict), just below 2^62 (the largest
-    moduli the API admits).  All (in, out) factors."""
+    just under 2^63) and just above it (Harvey60), just below 2^60 and just above it
+    (Harvey60 up to 2^60 + 2^28: doubled values up to 8 q <= 2^63 + 2^31, the high word
+    at most 2^31), just below 2^61 and just below 2^62 (Strict; the largest moduli the
+    API admits).  All (in, out) factors."""
     q = ho.generate_primes(1, bits, small_end, n)[0]
     lo, hi = 1 << bits, 1 << (bits + 1)
     assert lo < q < hi and ((q - lo) < (hi - lo) // 8 if small_end else (hi - q) < (hi - lo) // 8)
@@ -453,9 +455,11 @@ def test_ntt_fp64_policy_matches_integer_policy(hx, n, batch):
 
 @pytest.mark.parametrize("n,batch,bits,small_end", [(4096, 64, 59, False), (65536, 64, 59, False),
                                                     (1 << 17, 3, 56, True), (1 << 13, 5, 58, True),
-                                                    (1 << 14, 200, 59, False), (64, 7, 57, True)])
+                                                    (1 << 14, 200, 59, False), (64, 7, 57, True),
+                                                    (1 << 17, 8, 60, True), (4096, 33, 60, True)])
 def test_ntt_harvey60_policy_matches_strict_policy(hx, n, batch, bits, small_end):
-    """2^56 <= q < 2^60 (SEAL's and OpenFHE's 60-bit primes): the Harvey60 arithmetic policy
+    """2^56 <= q < 2^60 + 2^28 (SEAL's and OpenFHE's 60-bit primes, and the smallest primes
+    above 2^60 the reference's own tests generate): the Harvey60 arithmetic policy
     (Harvey ranges on doubled values, carry-free products) against the Strict policy on the
     same inputs, bit for bit -- plans built with the policy switched on and off."""
     import torch

@@ -188,6 +188,25 @@ def secondary_configs(hx, torch):
     cfg5["ntt_fwd"] = rate(16 * e, event_timed(torch, lambda: ntt.ComputeForward(r, a, 1, 1), 5))
     cfg5["ntt_inv"] = rate(16 * e, event_timed(torch, lambda: ntt.ComputeInverse(r, a, 1, 1), 5))
     out["config5"] = cfg5
+    del a, c, r
+    # the headline shape under the other arithmetic policies (moduli of other sizes)
+    n, b = N, 4096
+    x = torch.empty((b, n), dtype=torch.int64, device="cuda")
+    other = {}
+    for label, bits in (("30-bit prime (Small policy)", 29), ("50-bit prime (Fp64 policy)", 49),
+                        ("60-bit prime (Harvey60 policy)", 59), ("62-bit prime (Strict policy)", 61)):
+        q = hx.GeneratePrimes(1, bits, False, n)[0]
+        ntt = hx.NTT(n, q)
+        hx.fill_splitmix(x, n, b, 1, q)
+
+        def step():
+            ntt.ComputeForward(x, x, 1, 1)
+            ntt.ComputeInverse(x, x, 1, 1)
+        for _ in range(12):  # the first passes over a fresh buffer run slower
+            step()
+        sec = event_timed(torch, step, 10)
+        other[label] = {"q": q, "ms_per_step": sec * 1e3, "NTT_per_s": 2 * b / sec}
+    out["headline_shape_other_moduli"] = other
     return out
 
 

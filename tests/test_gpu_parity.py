@@ -1113,10 +1113,10 @@ def test_key_switch_rejects_bad_arguments(hx, ho):
 
 
 # ---------------------------------------------------------------- maximum degree
-@pytest.mark.parametrize("log_n,bits", [(18, 54), (19, 61), (20, 54), (20, 29)])
+@pytest.mark.parametrize("log_n,bits", [(18, 54), (19, 61), (20, 54), (20, 29), (19, 49), (18, 59)])
 def test_ntt_maximum_degrees(hx, ho, log_n, bits):
     """N up to 2^20 = NTT::MaxDegreeBits() (hexl/include/hexl/ntt/ntt.hpp:197): plans with two
-    strided passes in front of the tile pass, all three arithmetic policies."""
+    strided passes in front of the tile pass, all five arithmetic policies."""
     n = 1 << log_n
     q = ho.generate_primes(1, bits, True, n)[0]
     x = ho.fill_splitmix(n, log_n * 31 + bits, q)

@@ -18,8 +18,13 @@ OBJ = os.path.join(HERE, "lib", "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-CORE_SOURCES = ["ntt_kernels.hip", "eltwise_kernels.hip", "keyswitch_kernels.hip", "capi.cpp",
-                "number_theory.cpp", "workspace.cpp"]
+# ntt_kernels.hip is compiled once per arithmetic policy (-DHEXL_AMD_TU=0..4: the kernels of
+# that policy) plus once for the dispatch and the process-wide state (-DHEXL_AMD_TU=-1): the
+# template instantiations are disjoint between policies and compile in parallel.
+NTT_UNITS = [("ntt_kernels.hip", f"-DHEXL_AMD_TU={tu}", f"ntt_kernels.tu{tu if tu >= 0 else 'd'}")
+             for tu in (2, 3, 4, 1, 0, -1)]  # the slowest units first
+CORE_SOURCES = NTT_UNITS + ["eltwise_kernels.hip", "keyswitch_kernels.hip", "capi.cpp",
+                            "number_theory.cpp", "workspace.cpp"]
 SHIM_SOURCES = ["hexl_shim.cpp"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-command-line-argument",
           f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
@@ -40,12 +45,14 @@ def _headers():
     return hs
 
 
-def _compile(src):
-    obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+def _compile(unit):
+    """unit: a source file name, or (source, extra flag, object base name)"""
+    src, flag, base = unit if isinstance(unit, tuple) else (unit, None, os.path.basename(unit))
+    obj = os.path.join(OBJ, base + ".o")
     path = os.path.join(CSRC, src)
     if _newer(obj, [path] + _headers()):
         return obj
-    cmd = [HIPCC, f"--offload-arch={ARCH}"] + COMMON + ["-c", path, "-o", obj]
+    cmd = [HIPCC, f"--offload-arch={ARCH}"] + COMMON + ([flag] if flag else []) + ["-c", path, "-o", obj]
     if src.endswith(".cpp"):
         cmd.insert(1, "-x")
         cmd.insert(2, "c++")
@@ -61,7 +68,7 @@ def _compile(src):
 def build(verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     srcs = CORE_SOURCES + [s for s in SHIM_SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
         objs = dict(zip(srcs, ex.map(_compile, srcs)))
     core = os.path.join(LIB, "libhexl_amd.so")
     core_objs = [objs[s] for s in CORE_SOURCES]

@@ -59,9 +59,28 @@
 #include "modarith.h"
 #include "workspace.h"
 
+// Translation units.  Compiled as it is this file holds everything.  hexl_amd/build.py
+// compiles it several times in parallel instead, with -DHEXL_AMD_TU=<p>: p = 0..4 builds the
+// kernels and launch code of ONE arithmetic policy (ArithPolicy value) behind two entry
+// points, p = -1 the dispatch over them plus the process-wide state (tuning, profiling
+// sink).  The template instantiations are what takes the compile time, and they are
+// disjoint between policies.
+#ifndef HEXL_AMD_TU
+#define HX_TU_POLICY(p) 1
+#define HX_TU_DISPATCH 1
+#else
+#define HX_TU_POLICY(p) (HEXL_AMD_TU == (p))
+#define HX_TU_DISPATCH (HEXL_AMD_TU < 0)
+#if defined(HEXL_AMD_PHASE_PROFILE) || defined(HEXL_AMD_FUSED_STATS)
+#error "developer builds with device-side diagnostics are single translation units"
+#endif
+#endif
+
 namespace hexl_amd {
 
+#if HX_TU_DISPATCH
 thread_local ProfileSink* g_profile = nullptr;
+#endif
 
 // Developer diagnostic (tools/phase_profile.py): per-wave s_memtime stamps at the
 // phase boundaries of tile_pass.  Compiled out of the product build.
@@ -1505,7 +1524,9 @@ struct Tuning {
     tile13 = (t13 && t13[0] == '0') ? 0 : (t13 && t13[0] == '1') ? 1 : 2;
   }
 };
-static Tuning& tuning() {
+Tuning& tuning();  // one per process: defined by the dispatch unit
+#if HX_TU_DISPATCH
+Tuning& tuning() {
   static Tuning t;
   return t;
 }
@@ -1522,6 +1543,7 @@ int set_tuning(const char* key, u64 value) {
   else return -1;
   return 0;
 }
+#endif  // HX_TU_DISPATCH
 static PlanMode plan_mode() { return (PlanMode)tuning().plan.load(); }
 static bool plan_strided_requested() { return plan_mode() != kPlanTiled; }
 static u32 fused_window() { return tuning().fused_window.load(); }
@@ -1797,32 +1819,6 @@ static hipError_t transform_impl(const NttTables& t, u64* result, const u64* ope
              : inverse_seq<A>(t, p, result, operand, batch, out_mf, st);
 }
 
-hipError_t ntt_forward_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
-                              u64 out_mf, hipStream_t st) {
-  if (batch == 0) return hipSuccess;
-  switch (t.policy) {
-    case kPolicySmall: return transform_impl<true, Small>(t, result, operand, batch, out_mf, st);
-    case kPolicyFp64: return transform_impl<true, Fp64>(t, result, operand, batch, out_mf, st);
-    case kPolicyLazy: return transform_impl<true, Lazy>(t, result, operand, batch, out_mf, st);
-    case kPolicyHarvey60:
-      return transform_impl<true, Harvey60>(t, result, operand, batch, out_mf, st);
-    default: return transform_impl<true, Strict>(t, result, operand, batch, out_mf, st);
-  }
-}
-
-hipError_t ntt_inverse_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
-                              u64 out_mf, hipStream_t st) {
-  if (batch == 0) return hipSuccess;
-  switch (t.policy) {
-    case kPolicySmall: return transform_impl<false, Small>(t, result, operand, batch, out_mf, st);
-    case kPolicyFp64: return transform_impl<false, Fp64>(t, result, operand, batch, out_mf, st);
-    case kPolicyLazy: return transform_impl<false, Lazy>(t, result, operand, batch, out_mf, st);
-    case kPolicyHarvey60:
-      return transform_impl<false, Harvey60>(t, result, operand, batch, out_mf, st);
-    default: return transform_impl<false, Strict>(t, result, operand, batch, out_mf, st);
-  }
-}
-
 template <class A>
 static hipError_t multi_impl(bool forward, const NttTables& t0, const MultiCtx& mc, u64 polys,
                              u64* result, const u64* operand, u64 out_mf, hipStream_t st) {
@@ -1833,6 +1829,75 @@ static hipError_t multi_impl(bool forward, const NttTables& t0, const MultiCtx& 
                  : inverse_seq<A>(t0, p, result, operand, polys, out_mf, st, &mc);
 }
 
+// Entry points of one arithmetic policy (see "Translation units" at the top).
+#define HX_POLICY_ENTRY_DECL(NAME)                                                              \
+  hipError_t transform_entry_##NAME(bool forward, const NttTables& t, u64* result,              \
+                                    const u64* operand, u64 batch, u64 out_mf, hipStream_t st); \
+  hipError_t multi_entry_##NAME(bool forward, const NttTables& t0, const MultiCtx& mc, u64 polys, \
+                                u64* result, const u64* operand, u64 out_mf, hipStream_t st);
+HX_POLICY_ENTRY_DECL(small)
+HX_POLICY_ENTRY_DECL(fp64)
+HX_POLICY_ENTRY_DECL(lazy)
+HX_POLICY_ENTRY_DECL(strict)
+HX_POLICY_ENTRY_DECL(harvey60)
+#undef HX_POLICY_ENTRY_DECL
+
+#define HX_POLICY_ENTRY_DEF(NAME, A)                                                            \
+  hipError_t transform_entry_##NAME(bool forward, const NttTables& t, u64* result,              \
+                                    const u64* operand, u64 batch, u64 out_mf, hipStream_t st) { \
+    return forward ? transform_impl<true, A>(t, result, operand, batch, out_mf, st)             \
+                   : transform_impl<false, A>(t, result, operand, batch, out_mf, st);           \
+  }                                                                                             \
+  hipError_t multi_entry_##NAME(bool forward, const NttTables& t0, const MultiCtx& mc, u64 polys, \
+                                u64* result, const u64* operand, u64 out_mf, hipStream_t st) {  \
+    return multi_impl<A>(forward, t0, mc, polys, result, operand, out_mf, st);                  \
+  }
+#if HX_TU_POLICY(0)
+HX_POLICY_ENTRY_DEF(small, Small)
+#endif
+#if HX_TU_POLICY(1)
+HX_POLICY_ENTRY_DEF(fp64, Fp64)
+#endif
+#if HX_TU_POLICY(2)
+HX_POLICY_ENTRY_DEF(lazy, Lazy)
+#endif
+#if HX_TU_POLICY(3)
+HX_POLICY_ENTRY_DEF(strict, Strict)
+#endif
+#if HX_TU_POLICY(4)
+HX_POLICY_ENTRY_DEF(harvey60, Harvey60)
+#endif
+#undef HX_POLICY_ENTRY_DEF
+static_assert(kPolicySmall == 0 && kPolicyFp64 == 1 && kPolicyLazy == 2 && kPolicyStrict == 3 &&
+                  kPolicyHarvey60 == 4,
+              "the HX_TU_POLICY numbers above are the ArithPolicy values");
+
+#if HX_TU_DISPATCH
+static hipError_t transform_dispatch(bool forward, const NttTables& t, u64* result,
+                                     const u64* operand, u64 batch, u64 out_mf, hipStream_t st) {
+  if (batch == 0) return hipSuccess;
+  switch (t.policy) {
+    case kPolicySmall: return transform_entry_small(forward, t, result, operand, batch, out_mf, st);
+    case kPolicyFp64: return transform_entry_fp64(forward, t, result, operand, batch, out_mf, st);
+    case kPolicyLazy: return transform_entry_lazy(forward, t, result, operand, batch, out_mf, st);
+    case kPolicyHarvey60:
+      return transform_entry_harvey60(forward, t, result, operand, batch, out_mf, st);
+    default: return transform_entry_strict(forward, t, result, operand, batch, out_mf, st);
+  }
+}
+
+hipError_t ntt_forward_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
+                              u64 out_mf, hipStream_t st) {
+  return transform_dispatch(true, t, result, operand, batch, out_mf, st);
+}
+
+hipError_t ntt_inverse_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
+                              u64 out_mf, hipStream_t st) {
+  return transform_dispatch(false, t, result, operand, batch, out_mf, st);
+}
+#endif  // HX_TU_DISPATCH
+
+#if HX_TU_DISPATCH
 hipError_t ntt_multi_launch(bool forward, const NttTables* const* tabs, u32 num_plans,
                             const MultiMap& map, u64 polys, u64* result, const u64* operand,
                             u64 out_mf, hipStream_t st) {
@@ -1856,15 +1921,15 @@ hipError_t ntt_multi_launch(bool forward, const NttTables* const* tabs, u32 num_
   }
   hipError_t e = hipSuccess;
   if (have[kPolicySmall] && e == hipSuccess)
-    e = multi_impl<Small>(forward, t0, mc, polys, result, operand, out_mf, st);
+    e = multi_entry_small(forward, t0, mc, polys, result, operand, out_mf, st);
   if (have[kPolicyFp64] && e == hipSuccess)
-    e = multi_impl<Fp64>(forward, t0, mc, polys, result, operand, out_mf, st);
+    e = multi_entry_fp64(forward, t0, mc, polys, result, operand, out_mf, st);
   if (have[kPolicyLazy] && e == hipSuccess)
-    e = multi_impl<Lazy>(forward, t0, mc, polys, result, operand, out_mf, st);
+    e = multi_entry_lazy(forward, t0, mc, polys, result, operand, out_mf, st);
   if (have[kPolicyHarvey60] && e == hipSuccess)
-    e = multi_impl<Harvey60>(forward, t0, mc, polys, result, operand, out_mf, st);
+    e = multi_entry_harvey60(forward, t0, mc, polys, result, operand, out_mf, st);
   if (have[kPolicyStrict] && e == hipSuccess)
-    e = multi_impl<Strict>(forward, t0, mc, polys, result, operand, out_mf, st);
+    e = multi_entry_strict(forward, t0, mc, polys, result, operand, out_mf, st);
   return e;
 }
 
@@ -1881,5 +1946,7 @@ int choose_policy(u64 q) {
   if (q < kHarvey60ModulusBound && tuning().h60.load() != 0) return kPolicyHarvey60;
   return kPolicyStrict;
 }
+
+#endif  // HX_TU_DISPATCH
 
 }  // namespace hexl_amd

@@ -207,6 +207,26 @@ def secondary_configs(hx, torch):
         sec = event_timed(torch, step, 10)
         other[label] = {"q": q, "ms_per_step": sec * 1e3, "NTT_per_s": 2 * b / sec}
     out["headline_shape_other_moduli"] = other
+    del x
+    # configs[3] on ONE GPU: the 8 RNS primes x 4096 polynomials (16 GiB) through the
+    # multi-modulus entry point (one launch sequence over all primes)
+    primes = [18014398510661633, 18014398512365569, 18014398514200577, 18014398514987009,
+              18014398515511297, 18014398516559873, 18014398521016321, 18014398524424193]
+    b = 4096
+    plans = [hx.NTT(n, p) for p in primes]
+    x = torch.empty((len(primes), b, n), dtype=torch.int64, device="cuda")
+    for k, p in enumerate(primes):
+        hx.fill_splitmix(x[k], n, b, 1 + k * b, p)
+
+    def rns_step():
+        hx.ComputeForwardRNS(plans, x, x, 1, 1)
+        hx.ComputeInverseRNS(plans, x, x, 1, 1)
+    for _ in range(6):
+        rns_step()
+    sec = event_timed(torch, rns_step, 5)
+    out["config4_on_one_gpu"] = {
+        "shape": f"N={n}, 8 primes (55-bit) x {b} polynomials, hexl_amd_ntt_forward_rns/_inverse_rns",
+        "ms_per_step": sec * 1e3, "NTT_per_s": 2 * len(primes) * b / sec}
     return out
 
 

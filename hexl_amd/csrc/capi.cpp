@@ -387,8 +387,10 @@ static int ntt_run_rns(const hexl_amd_ntt* const* plans, uint64_t num_plans, uin
   if (num_plans == 0 || batch_per_plan == 0) return HEXL_AMD_OK;
   if (int rc = check_ntt_args(plans[0], result, operand, forward, in_mf, out_mf)) return rc;
   // One launch sequence over all moduli where the shapes allow it (degree 2^12 .. 2^17),
-  // in groups of kMaxMultiPlans; otherwise plan by plan.
-  if (num_plans > 1) {
+  // in groups of kMaxMultiPlans; otherwise plan by plan.  With many polynomials per modulus
+  // the launches no longer matter and the single-plan kernels are ~5 % faster (their plan is
+  // in the kernel arguments): plan by plan from 2^24 coefficients per modulus.
+  if (num_plans > 1 && batch_per_plan * plans[0]->n < (1ull << 24)) {
     DeviceScope scope(plans[0]->device);
     if (scope.err != hipSuccess) return hip_fail(scope.err, "hipSetDevice");
     bool multi_ok = true;

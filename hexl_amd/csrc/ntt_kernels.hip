@@ -57,6 +57,8 @@
 
 #include "internal.h"
 #include "modarith.h"
+#include <cstddef>
+
 #include "workspace.h"
 
 // Translation units.  Compiled as it is this file holds everything.  hexl_amd/build.py
@@ -395,7 +397,11 @@ constexpr int strided_min_waves() { return R >= 5 ? 4 : 6; }
 // LAST (inverse only): the pass contains the root stage of the transform (a0 == 0).
 // LDK / STK: access kinds of the loads and stores (see ld_global).
 // The data pointers are not __restrict__: transforms run in place (out == in).
-template <bool FWD, int R, class A, bool LAST, int LDK, int STK>
+// DATA_FIRST (the multi-plan kernels): the data loads are issued before anything that
+// depends on the plan (twiddle table pointer, modulus constants), which those kernels fetch
+// from device memory through a chain of scalar loads -- the chain then resolves under the
+// data loads' latency instead of in front of it.
+template <bool FWD, int R, class A, bool LAST, int LDK, int STK, bool DATA_FIRST = false>
 __device__ __forceinline__ void strided_body(u64* out, const u64* in,
                                              const ulonglong2* __restrict__ tw, const ModConst& m,
                                              u32 log_n, u32 a0, u32 flags, u32 bid,
@@ -418,7 +424,7 @@ __device__ __forceinline__ void strided_body(u64* out, const u64* in,
   const u32 node = (1u << a0) + h;
   const TwT<A>* __restrict__ twa = reinterpret_cast<const TwT<A>*>(tw);
   TwT<A> wv[E];
-  if constexpr (R < 5) load_twiddles<R>(wv, twa, node);
+  if constexpr (R < 5 && !DATA_FIRST) load_twiddles<R>(wv, twa, node);
 
   u64 x[E];
   // loads go out at raised priority (forward: 0.70 -> 0.68 ms; the inverse pass
@@ -427,6 +433,7 @@ __device__ __forceinline__ void strided_body(u64* out, const u64* in,
 #pragma unroll
   for (int e = 0; e < E; ++e) x[e] = ld_global<LDK>(&in[vbase + ((u64)e << log_s)]);
   if (FWD) __builtin_amdgcn_s_setprio(0);
+  if constexpr (R < 5 && DATA_FIRST) load_twiddles<R>(wv, twa, node);
   if (flags & kFirstPass) {
     if (flags & kReduceFirst) {
 #pragma unroll
@@ -484,19 +491,43 @@ strided_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModCons
 // parameters are read from its device-resident copy instead of kernel arguments.
 struct MultiCtx {
   const PlanDev* p[kMaxMultiPlans];
+  // The twiddle tables of each plan, once more: as kernel-argument pointers the compiler
+  // knows them to be global memory and serves wave-uniform twiddles with scalar loads;
+  // fetched from the plan's device copy they were generic pointers, every twiddle a
+  // flat_load into VGPRs (the multi-plan tile pass 17-32 % slower than the single-plan one).
+  const ulonglong2* tw_fwd[kMaxMultiPlans];
+  const ulonglong2* tw_inv[kMaxMultiPlans];
   uint8_t policy[kMaxMultiPlans];  // ArithPolicy of each plan
+  u32 one_policy;  // every plan is of one arithmetic policy (the usual case): no workgroup leaves
   MultiMap map;
 };
 // The plan of polynomial `poly`, or nullptr when it is not of policy `want` (a launch
 // sequence serves one arithmetic policy; workgroups of the others leave at once).
-__device__ __forceinline__ const PlanDev* multi_plan(const MultiCtx& mc, u32 poly, int want) {
+// Entry `idx` of a byte table that lives in the kernel arguments, fetched as the aligned
+// dword that holds it: a SCALAR load (there is no scalar byte load on gfx950; as a byte
+// access it becomes a vector load + wait + readfirstlane, ~1 us in front of everything the
+// workgroup does -- two of them in a row made the multi-plan tile pass 17-32 % slower than
+// the single-plan one).  The tables are 4-byte aligned inside their structs.
+__device__ __forceinline__ u32 kernarg_byte(const uint8_t* tab, u32 idx) {
+  idx = __builtin_amdgcn_readfirstlane(idx);
+  const u32 w = reinterpret_cast<const u32*>(tab)[idx >> 2];
+  return (w >> ((idx & 3) * 8)) & 0xffu;
+}
+static_assert(offsetof(MultiMap, plan_tab) % 4 == 0 && offsetof(MultiMap, src_tab) % 4 == 0 &&
+                  offsetof(MultiCtx, policy) % 4 == 0 && offsetof(MultiCtx, map) % 4 == 0,
+              "byte tables must be dword aligned for kernarg_byte");
+__device__ __forceinline__ const PlanDev* multi_plan(const MultiCtx& mc, u32 poly, int want,
+                                                     u32& plan_index) {
   // (the plan index goes through readfirstlane so that the pointer is fetched with a
   // cleanly aligned scalar load: left to itself the compiler derived its address from
   // the byte address of policy[k], base + k plus an offset of 7 k, for an s_load whose
   // base must be dword aligned -- an aperture violation for k % 4 != 0)
-  const u32 k = __builtin_amdgcn_readfirstlane(
-      (u32)mc.map.plan_tab[(poly / mc.map.inner) % mc.map.period]);
-  const u32 pol = __builtin_amdgcn_readfirstlane((u32)mc.policy[k]);
+  const u32 k = kernarg_byte(mc.map.plan_tab, (poly / mc.map.inner) % mc.map.period);
+  plan_index = k;
+  // (with one policy in the launch the check -- one more scalar load in front of the data
+  // loads -- is skipped)
+  if (mc.one_policy) return mc.p[k];
+  const u32 pol = kernarg_byte(mc.policy, k);
   return pol == (u32)want ? mc.p[k] : nullptr;
 }
 // Source map of a multi-plan launch (MultiMap): where polynomial `poly` of the FIRST pass
@@ -506,7 +537,7 @@ __device__ __forceinline__ const u64* multi_source(const MultiCtx& mc, u32 poly,
                                                    const u64* in, u32& flags) {
   if (mc.map.src_stride == 0 || !(flags & kFirstPass)) return in;
   const u32 s = poly % mc.map.period, grp = poly / mc.map.period;
-  const u32 e = __builtin_amdgcn_readfirstlane((u32)mc.map.src_tab[s]);
+  const u32 e = kernarg_byte(mc.map.src_tab, s);
   const u32 src = grp * mc.map.src_stride + (e & 0x7f);
   if (e & 0x80) flags |= kReduceFirst;
   return in + (((long long)src - (long long)poly) << log_n);
@@ -528,13 +559,14 @@ strided_pass_multi(u64* out, const u64* in, MultiCtx mc, u32 log_n, u32 a0, u32 
   if ((u64)bid * 256 + threadIdx.x >= items) return;
   // a workgroup's 4 waves lie in one polynomial (>= 256 columns per polynomial: N >= 2^13)
   const u32 poly = (bid * 4u) >> (log_n - R - 6);
-  const PlanDev* __restrict__ pd = multi_plan(mc, poly, policy_id<A>());
+  u32 k;
+  const PlanDev* __restrict__ pd = multi_plan(mc, poly, policy_id<A>(), k);
   if (!pd) return;
   const ModConst m = pd->mod;
   const InvLast il = pd->il;
   in = multi_source(mc, poly, log_n, in, flags);
-  strided_body<FWD, R, A, LAST, kStream, kStream>(out, in, FWD ? pd->fwd : pd->inv, m, log_n, a0,
-                                                  flags, bid, il);
+  strided_body<FWD, R, A, LAST, kStream, kStream, true>(out, in, FWD ? mc.tw_fwd[k] : mc.tw_inv[k], m,
+                                                        log_n, a0, flags, bid, il);
 }
 
 // ---------------------------------------------------------------------------
@@ -833,7 +865,8 @@ __device__ __forceinline__ constexpr u32 xfer_dp(int i) {
 
 // GUARD: the batch may end inside the tile (only possible for CB == 0 and a batch
 // smaller than / not a multiple of the tile); otherwise every access is in range.
-template <bool ROUND0, int S, int CB, int TL, bool GUARD, class A, int LDK>
+// CONVERT == false: only the loads (fetch_convert follows once the plan constants are there).
+template <bool ROUND0, int S, int CB, int TL, bool GUARD, class A, int LDK, bool CONVERT = true>
 __device__ __forceinline__ void fetch_tile(u64* x, const u64* in, u32 tid, const TileGeom& g,
                                            u64 total, u32 flags, const ModConst& m) {
   constexpr int kRE = re_of(S), kE = el_of(S);
@@ -851,6 +884,19 @@ __device__ __forceinline__ void fetch_tile(u64* x, const u64* in, u32 tid, const
       x[i] = load_global<LDK>(src, tile_byte_offset<CB>(g, p0));
 #endif
   }
+  if constexpr (!CONVERT) return;
+  if (flags & kFirstPass) {
+    if (flags & kReduceFirst) {
+#pragma unroll
+      for (int i = 0; i < kE; ++i) x[i] = reduce_any(x[i], m.q, m.barrett);
+    }
+#pragma unroll
+    for (int i = 0; i < kE; ++i) x[i] = to_internal<A>(x[i], m);
+  }
+}
+template <int S, class A>
+__device__ __forceinline__ void fetch_convert(u64* x, u32 flags, const ModConst& m) {
+  constexpr int kE = el_of(S);
   if (flags & kFirstPass) {
     if (flags & kReduceFirst) {
 #pragma unroll
@@ -894,7 +940,8 @@ constexpr int min_waves() { return S >= 14 ? 4 : (S >= 10 || CB > 0) ? 8 : 6; }
 // tile_body: the work of one workgroup on tile `bid`; `lds` = 2^TL words of LDS.
 // LDK / STK: access kinds of the global loads and stores (see ld_global).  The data
 // pointers are not __restrict__: transforms run in place (out == in).
-template <bool FWD, int S, int CB, int TL, bool GUARD, class A, bool LAST, int LDK, int STK>
+template <bool FWD, int S, int CB, int TL, bool GUARD, class A, bool LAST, int LDK, int STK,
+          bool DATA_FIRST = false>
 __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
                                           const ulonglong2* __restrict__ tw_raw, const ModConst& m,
                                           u32 log_n, u32 flags, u64 total, const InvLast& il,
@@ -919,8 +966,14 @@ __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
     TwT<A> wn[kE];  // twiddles of round 1 when requested ahead
     {  // round 0 straight from global memory; its twiddles are requested first
       TwT<A> wv[kE];
-      round_twiddles<S, CB, TL, 0>(wv, tw, tid, g);
-      fetch_tile<true, S, CB, TL, GUARD, A, LDK>(x, in, tid, g, total, flags, m);  // round-0 set
+      if constexpr (DATA_FIRST) {  // see strided_body
+        fetch_tile<true, S, CB, TL, GUARD, A, LDK, false>(x, in, tid, g, total, flags, m);
+        round_twiddles<S, CB, TL, 0>(wv, tw, tid, g);
+        fetch_convert<S, A>(x, flags, m);
+      } else {
+        round_twiddles<S, CB, TL, 0>(wv, tw, tid, g);
+        fetch_tile<true, S, CB, TL, GUARD, A, LDK>(x, in, tid, g, total, flags, m);  // round-0 set
+      }
       __builtin_amdgcn_s_setprio(0);
       if constexpr (RD::pre_fwd(1)) round_twiddles<S, CB, TL, 1>(wn, tw, tid, g);
       HX_PROFILE_WAIT_VMEM();
@@ -953,8 +1006,14 @@ __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
     // copy-in of the run this wave owns in the deepest round; the twiddles of that
     // round are requested first
     TwT<A> wtop[kE], w0[kE];
-    if constexpr (NR > 1) round_twiddles<S, CB, TL, NR - 1>(wtop, tw, tid, g);
-    fetch_tile<false, S, CB, TL, GUARD, A, LDK>(x, in, tid, g, total, flags, m);
+    if constexpr (DATA_FIRST) {
+      fetch_tile<false, S, CB, TL, GUARD, A, LDK, false>(x, in, tid, g, total, flags, m);
+      if constexpr (NR > 1) round_twiddles<S, CB, TL, NR - 1>(wtop, tw, tid, g);
+      fetch_convert<S, A>(x, flags, m);
+    } else {
+      if constexpr (NR > 1) round_twiddles<S, CB, TL, NR - 1>(wtop, tw, tid, g);
+      fetch_tile<false, S, CB, TL, GUARD, A, LDK>(x, in, tid, g, total, flags, m);
+    }
     __builtin_amdgcn_s_setprio(0);
     {
       const u32 a0 = lds_slot(xfer_p0<false, S, CB, TL>(tid, 0)) << 3;
@@ -995,13 +1054,14 @@ __global__ void __launch_bounds__(1 << (TL - re_of(S)), (min_waves<S, 0>()))
 tile_pass_multi(u64* out, const u64* in, MultiCtx mc, u32 log_n, u32 flags, u64 total) {
   __shared__ u64 lds[1 << TL];
   const u32 poly = (u32)(((u64)blockIdx.x << TL) >> log_n);
-  const PlanDev* __restrict__ pd = multi_plan(mc, poly, policy_id<A>());
+  u32 k;
+  const PlanDev* __restrict__ pd = multi_plan(mc, poly, policy_id<A>(), k);
   if (!pd) return;
   const ModConst m = pd->mod;
   const InvLast il = pd->il;
   in = multi_source(mc, poly, log_n, in, flags);
-  tile_body<FWD, S, 0, TL, false, A, LAST, FWD ? kStream : kPlain, FWD ? kStream : kPlain>(
-      lds, out, in, FWD ? pd->fwd : pd->inv, m, log_n, flags, total, il, blockIdx.x);
+  tile_body<FWD, S, 0, TL, false, A, LAST, FWD ? kStream : kPlain, FWD ? kStream : kPlain, true>(
+      lds, out, in, FWD ? mc.tw_fwd[k] : mc.tw_inv[k], m, log_n, flags, total, il, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -1912,6 +1972,8 @@ hipError_t ntt_multi_launch(bool forward, const NttTables* const* tabs, u32 num_
   for (u32 k = 0; k < num_plans; ++k) {
     if (tabs[k]->log_n != t0.log_n || !tabs[k]->dev) return hipErrorNotSupported;
     mc.p[k] = tabs[k]->dev;
+    mc.tw_fwd[k] = tabs[k]->fwd;
+    mc.tw_inv[k] = tabs[k]->inv;
     mc.policy[k] = (uint8_t)tabs[k]->policy;
   }
   mc.map = map;
@@ -1919,6 +1981,9 @@ hipError_t ntt_multi_launch(bool forward, const NttTables* const* tabs, u32 num_
     if (map.plan_tab[i] >= num_plans) return hipErrorInvalidValue;
     have[tabs[map.plan_tab[i]]->policy] = true;
   }
+  int policies = 0;
+  for (int i = 0; i < kNumPolicies; ++i) policies += have[i] ? 1 : 0;
+  mc.one_policy = policies == 1 ? 1u : 0u;
   hipError_t e = hipSuccess;
   if (have[kPolicySmall] && e == hipSuccess)
     e = multi_entry_small(forward, t0, mc, polys, result, operand, out_mf, st);

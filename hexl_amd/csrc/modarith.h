@@ -130,6 +130,12 @@ HX_HD u64 reduce_any(u64 x, u64 q, u64 barrett) {
   if (x < q) return x;
   return csub(x - mul_hi64(x, barrett) * q, q);
 }
+// The same without the early exit (for x < q the quotient estimate is 0 anyway): straight-line
+// code for the transforms' load paths, where a divergent branch per element would cut the
+// kernel into basic blocks.
+HX_HD u64 reduce_any_straight(u64 x, u64 q, u64 barrett) {
+  return csub(x - mul_hi64(x, barrett) * q, q);
+}
 
 #if defined(__HIP_DEVICE_COMPILE__)
 HX_HD u32 mul_hi32(u32 a, u32 b) { return __umulhi(a, b); }

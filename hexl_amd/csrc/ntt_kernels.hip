@@ -200,12 +200,38 @@ __device__ __forceinline__ void fp_bound_all(u64* x, const ModConst& m) {
 // before the first butterfly so that their latencies overlap (left to itself
 // the compiler issues one load + one full wait per stage).  wv[2^v + g] is the
 // twiddle of group g at depth v.
-template <int R, class T>
+// The tables are read through the CONSTANT address space (they are never written while a
+// transform runs): a wave-uniform index is then a scalar load whatever the compiler can or
+// cannot prove about aliasing stores (in the multi-plan kernels with 12- and 13-stage tiles
+// it could not, and every twiddle came through the vector memory path into VGPRs).
+typedef const __attribute__((address_space(4))) u64 ConstWord;
+typedef const __attribute__((address_space(4))) double ConstDouble;
+__device__ __forceinline__ ulonglong2 load_twiddle(const ulonglong2* tw, u32 i) {
+  const ConstWord* c = (const ConstWord*)(unsigned long long)tw;
+  ulonglong2 w;
+  w.x = c[2 * (u64)i];
+  w.y = c[2 * (u64)i + 1];
+  return w;
+}
+__device__ __forceinline__ double load_twiddle(const double* tw, u32 i) {
+  const ConstDouble* c = (const ConstDouble*)(unsigned long long)tw;
+  return c[i];
+}
+// CTW: through the constant address space (the multi-plan kernels).  The single-plan kernels
+// keep the plain form -- their table pointer is a __restrict__ kernel argument, which gets
+// them scalar loads already, and the constant-space form costs the 11-stage forward tile
+// pass a spilled register pair (0.93 -> 0.95 ms).
+template <int R, bool CTW = false, class T>
 __device__ __forceinline__ void load_twiddles(T* wv, const T* __restrict__ tw, u32 node) {
 #pragma unroll
   for (int v = 0; v < R; ++v)
 #pragma unroll
-    for (int g = 0; g < (1 << v); ++g) wv[(1 << v) + g] = tw[(node << v) + g];
+    for (int g = 0; g < (1 << v); ++g) {
+      if constexpr (CTW)
+        wv[(1 << v) + g] = load_twiddle(tw, (node << v) + g);
+      else
+        wv[(1 << v) + g] = tw[(node << v) + g];
+    }
 }
 
 // R forward stages on x[0 .. 2^R): stage v pairs elements 2^(R-1-v) apart.
@@ -401,7 +427,8 @@ constexpr int strided_min_waves() { return R >= 5 ? 4 : 6; }
 // depends on the plan (twiddle table pointer, modulus constants), which those kernels fetch
 // from device memory through a chain of scalar loads -- the chain then resolves under the
 // data loads' latency instead of in front of it.
-template <bool FWD, int R, class A, bool LAST, int LDK, int STK, bool DATA_FIRST = false>
+template <bool FWD, int R, class A, bool LAST, int LDK, int STK, bool DATA_FIRST = false,
+          bool CTW = false>
 __device__ __forceinline__ void strided_body(u64* out, const u64* in,
                                              const ulonglong2* __restrict__ tw, const ModConst& m,
                                              u32 log_n, u32 a0, u32 flags, u32 bid,
@@ -424,7 +451,7 @@ __device__ __forceinline__ void strided_body(u64* out, const u64* in,
   const u32 node = (1u << a0) + h;
   const TwT<A>* __restrict__ twa = reinterpret_cast<const TwT<A>*>(tw);
   TwT<A> wv[E];
-  if constexpr (R < 5 && !DATA_FIRST) load_twiddles<R>(wv, twa, node);
+  if constexpr (R < 5 && !DATA_FIRST) load_twiddles<R, CTW>(wv, twa, node);
 
   u64 x[E];
   // loads go out at raised priority (forward: 0.70 -> 0.68 ms; the inverse pass
@@ -433,11 +460,11 @@ __device__ __forceinline__ void strided_body(u64* out, const u64* in,
 #pragma unroll
   for (int e = 0; e < E; ++e) x[e] = ld_global<LDK>(&in[vbase + ((u64)e << log_s)]);
   if (FWD) __builtin_amdgcn_s_setprio(0);
-  if constexpr (R < 5 && DATA_FIRST) load_twiddles<R>(wv, twa, node);
+  if constexpr (R < 5 && DATA_FIRST) load_twiddles<R, CTW>(wv, twa, node);
   if (flags & kFirstPass) {
     if (flags & kReduceFirst) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) x[e] = reduce_any(x[e], m.q, m.barrett);
+      for (int e = 0; e < E; ++e) x[e] = reduce_any_straight(x[e], m.q, m.barrett);
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) x[e] = to_internal<A>(x[e], m);
@@ -565,8 +592,8 @@ strided_pass_multi(u64* out, const u64* in, MultiCtx mc, u32 log_n, u32 a0, u32 
   const ModConst m = pd->mod;
   const InvLast il = pd->il;
   in = multi_source(mc, poly, log_n, in, flags);
-  strided_body<FWD, R, A, LAST, kStream, kStream, true>(out, in, FWD ? mc.tw_fwd[k] : mc.tw_inv[k], m,
-                                                        log_n, a0, flags, bid, il);
+  strided_body<FWD, R, A, LAST, kStream, kStream, true, true>(
+      out, in, FWD ? mc.tw_fwd[k] : mc.tw_inv[k], m, log_n, a0, flags, bid, il);
 }
 
 // ---------------------------------------------------------------------------
@@ -679,7 +706,7 @@ __device__ __forceinline__ u64 tile_uniform_offset(const TileGeom& g, u32 dp) {
 // Twiddles of round j for every sub-run this thread owns in that round, all
 // requested before the round's first butterfly.  Wave-uniform twiddles (gap >= 64)
 // come through scalar loads (no VGPR cost), the others through per-lane loads.
-template <int S, int CB, int TL, int j, class T>
+template <int S, int CB, int TL, int j, bool CTW = false, class T>
 __device__ __forceinline__ void round_twiddles(T* wv, const T* __restrict__ tw, u32 tid,
                                                const TileGeom& g) {
   constexpr int kRE = re_of(S), kE = el_of(S);
@@ -695,7 +722,7 @@ __device__ __forceinline__ void round_twiddles(T* wv, const T* __restrict__ tw, 
 #ifndef HX_EXP_NO_SCALAR_TW  // developer experiment: per-lane loads for every twiddle
     if (w >= 6) node = __builtin_amdgcn_readfirstlane(node);  // uniform across the wave
 #endif
-    load_twiddles<r>(wv + (s << r), tw, node);
+    load_twiddles<r, CTW>(wv + (s << r), tw, node);
   }
 }
 
@@ -773,7 +800,7 @@ __device__ __forceinline__ void handover() {
 
 // forward rounds J .. NR-1: LDS -> registers -> subtree -> same LDS slots.
 // `pre` holds the twiddles of round J when Rounds::pre_fwd(J).
-template <int S, int CB, int TL, int J, class A>
+template <int S, int CB, int TL, int J, class A, bool CTW = false>
 __device__ __forceinline__ void fwd_mid_rounds(u64* x, u64* lds, const TwT<A>* tw, u32 tid,
                                                const TileGeom& g, const ModConst& m,
                                                const InvLast& il, const TwT<A>* pre) {
@@ -783,23 +810,23 @@ __device__ __forceinline__ void fwd_mid_rounds(u64* x, u64* lds, const TwT<A>* t
     TwT<A> wv[kE], wn[kE];
     const TwT<A>* w = pre;
     if constexpr (!RD::pre_fwd(J)) {
-      round_twiddles<S, CB, TL, J>(wv, tw, tid, g);
+      round_twiddles<S, CB, TL, J, CTW>(wv, tw, tid, g);
       w = wv;
     }
     lds_load_round<S, CB, TL, J>(x, lds, tid);
-    if constexpr (RD::pre_fwd(J + 1)) round_twiddles<S, CB, TL, J + 1>(wn, tw, tid, g);
+    if constexpr (RD::pre_fwd(J + 1)) round_twiddles<S, CB, TL, J + 1, CTW>(wn, tw, tid, g);
     round_compute<S, CB, J, A, true, false>(x, w, m, il);
     lds_store_round<S, CB, TL, J>(x, lds, tid);
     handover<RD::w(J), RD::r(J) == kRE>();
     HX_STAMP(3 + J);
-    fwd_mid_rounds<S, CB, TL, J + 1, A>(x, lds, tw, tid, g, m, il, wn);
+    fwd_mid_rounds<S, CB, TL, J + 1, A, CTW>(x, lds, tw, tid, g, m, il, wn);
   }
 }
 
 // inverse rounds J .. 1 (deepest first).  `pre` holds the twiddles of round J when
 // J == NR-1 or Rounds::pre_inv(J); `pre0` receives those of round 0 when
 // Rounds::pre_inv(0).
-template <int S, int CB, int TL, int J, class A>
+template <int S, int CB, int TL, int J, class A, bool CTW = false>
 __device__ __forceinline__ void inv_mid_rounds(u64* x, u64* lds, const TwT<A>* tw, u32 tid,
                                                const TileGeom& g, const ModConst& m,
                                                const InvLast& il, const TwT<A>* pre,
@@ -810,16 +837,16 @@ __device__ __forceinline__ void inv_mid_rounds(u64* x, u64* lds, const TwT<A>* t
     TwT<A> wv[kE], wn[kE];
     const TwT<A>* w = pre;
     if constexpr (J != RD::NR - 1 && !RD::pre_inv(J)) {
-      round_twiddles<S, CB, TL, J>(wv, tw, tid, g);
+      round_twiddles<S, CB, TL, J, CTW>(wv, tw, tid, g);
       w = wv;
     }
     lds_load_round<S, CB, TL, J>(x, lds, tid);
-    if constexpr (RD::pre_inv(J - 1)) round_twiddles<S, CB, TL, J - 1>(J == 1 ? pre0 : wn, tw, tid, g);
+    if constexpr (RD::pre_inv(J - 1)) round_twiddles<S, CB, TL, J - 1, CTW>(J == 1 ? pre0 : wn, tw, tid, g);
     round_compute<S, CB, J, A, false, false>(x, w, m, il);
     lds_store_round<S, CB, TL, J>(x, lds, tid);
     // the next (shallower) round J-1 regroups across waves iff its gap exceeds a wave
     handover<RD::w(J - 1), RD::r(J - 1) == kRE>();
-    inv_mid_rounds<S, CB, TL, J - 1, A>(x, lds, tw, tid, g, m, il, wn, pre0);
+    inv_mid_rounds<S, CB, TL, J - 1, A, CTW>(x, lds, tw, tid, g, m, il, wn, pre0);
   }
 }
 
@@ -888,7 +915,7 @@ __device__ __forceinline__ void fetch_tile(u64* x, const u64* in, u32 tid, const
   if (flags & kFirstPass) {
     if (flags & kReduceFirst) {
 #pragma unroll
-      for (int i = 0; i < kE; ++i) x[i] = reduce_any(x[i], m.q, m.barrett);
+      for (int i = 0; i < kE; ++i) x[i] = reduce_any_straight(x[i], m.q, m.barrett);
     }
 #pragma unroll
     for (int i = 0; i < kE; ++i) x[i] = to_internal<A>(x[i], m);
@@ -900,7 +927,7 @@ __device__ __forceinline__ void fetch_convert(u64* x, u32 flags, const ModConst&
   if (flags & kFirstPass) {
     if (flags & kReduceFirst) {
 #pragma unroll
-      for (int i = 0; i < kE; ++i) x[i] = reduce_any(x[i], m.q, m.barrett);
+      for (int i = 0; i < kE; ++i) x[i] = reduce_any_straight(x[i], m.q, m.barrett);
     }
 #pragma unroll
     for (int i = 0; i < kE; ++i) x[i] = to_internal<A>(x[i], m);
@@ -941,7 +968,7 @@ constexpr int min_waves() { return S >= 14 ? 4 : (S >= 10 || CB > 0) ? 8 : 6; }
 // LDK / STK: access kinds of the global loads and stores (see ld_global).  The data
 // pointers are not __restrict__: transforms run in place (out == in).
 template <bool FWD, int S, int CB, int TL, bool GUARD, class A, bool LAST, int LDK, int STK,
-          bool DATA_FIRST = false>
+          bool DATA_FIRST = false, bool CTW = false>
 __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
                                           const ulonglong2* __restrict__ tw_raw, const ModConst& m,
                                           u32 log_n, u32 flags, u64 total, const InvLast& il,
@@ -968,14 +995,14 @@ __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
       TwT<A> wv[kE];
       if constexpr (DATA_FIRST) {  // see strided_body
         fetch_tile<true, S, CB, TL, GUARD, A, LDK, false>(x, in, tid, g, total, flags, m);
-        round_twiddles<S, CB, TL, 0>(wv, tw, tid, g);
+        round_twiddles<S, CB, TL, 0, CTW>(wv, tw, tid, g);
         fetch_convert<S, A>(x, flags, m);
       } else {
-        round_twiddles<S, CB, TL, 0>(wv, tw, tid, g);
+        round_twiddles<S, CB, TL, 0, CTW>(wv, tw, tid, g);
         fetch_tile<true, S, CB, TL, GUARD, A, LDK>(x, in, tid, g, total, flags, m);  // round-0 set
       }
       __builtin_amdgcn_s_setprio(0);
-      if constexpr (RD::pre_fwd(1)) round_twiddles<S, CB, TL, 1>(wn, tw, tid, g);
+      if constexpr (RD::pre_fwd(1)) round_twiddles<S, CB, TL, 1, CTW>(wn, tw, tid, g);
       HX_PROFILE_WAIT_VMEM();
       HX_STAMP(1);
       round_compute<S, CB, 0, A, true, false>(x, wv, m, il);
@@ -984,7 +1011,7 @@ __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
       handover<RD::w(0), RD::r(0) == kRE>();
       HX_STAMP(3);
     }
-    fwd_mid_rounds<S, CB, TL, 1, A>(x, lds, tw, tid, g, m, il, wn);
+    fwd_mid_rounds<S, CB, TL, 1, A, CTW>(x, lds, tw, tid, g, m, il, wn);
     // copy-out of the run this wave owns after the last round (w = CB <= 6):
     // 512 tile-contiguous elements, 64 per access; final reduction fused
     {
@@ -1008,10 +1035,10 @@ __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
     TwT<A> wtop[kE], w0[kE];
     if constexpr (DATA_FIRST) {
       fetch_tile<false, S, CB, TL, GUARD, A, LDK, false>(x, in, tid, g, total, flags, m);
-      if constexpr (NR > 1) round_twiddles<S, CB, TL, NR - 1>(wtop, tw, tid, g);
+      if constexpr (NR > 1) round_twiddles<S, CB, TL, NR - 1, CTW>(wtop, tw, tid, g);
       fetch_convert<S, A>(x, flags, m);
     } else {
-      if constexpr (NR > 1) round_twiddles<S, CB, TL, NR - 1>(wtop, tw, tid, g);
+      if constexpr (NR > 1) round_twiddles<S, CB, TL, NR - 1, CTW>(wtop, tw, tid, g);
       fetch_tile<false, S, CB, TL, GUARD, A, LDK>(x, in, tid, g, total, flags, m);
     }
     __builtin_amdgcn_s_setprio(0);
@@ -1021,9 +1048,9 @@ __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
       for (int i = 0; i < kE; ++i) lds_at(lds, a0 ^ (lds_slot(xfer_dp<false, S, CB>(i)) << 3)) = x[i];
     }
     handover<RD::w(NR - 1), RD::r(NR - 1) == kRE>();
-    inv_mid_rounds<S, CB, TL, NR - 1, A>(x, lds, tw, tid, g, m, il, wtop, w0);
+    inv_mid_rounds<S, CB, TL, NR - 1, A, CTW>(x, lds, tw, tid, g, m, il, wtop, w0);
     {
-      if constexpr (!RD::pre_inv(0)) round_twiddles<S, CB, TL, 0>(w0, tw, tid, g);
+      if constexpr (!RD::pre_inv(0)) round_twiddles<S, CB, TL, 0, CTW>(w0, tw, tid, g);
       lds_load_round<S, CB, TL, 0>(x, lds, tid);
       round_compute<S, CB, 0, A, false, LAST>(x, w0, m, il);
 #pragma unroll
@@ -1060,7 +1087,9 @@ tile_pass_multi(u64* out, const u64* in, MultiCtx mc, u32 log_n, u32 flags, u64 
   const ModConst m = pd->mod;
   const InvLast il = pd->il;
   in = multi_source(mc, poly, log_n, in, flags);
-  tile_body<FWD, S, 0, TL, false, A, LAST, FWD ? kStream : kPlain, FWD ? kStream : kPlain, true>(
+  // (data-first only for the small tiles: with 16 elements per thread it costs registers)
+  tile_body<FWD, S, 0, TL, false, A, LAST, FWD ? kStream : kPlain, FWD ? kStream : kPlain, (S <= 12),
+            true>(
       lds, out, in, FWD ? mc.tw_fwd[k] : mc.tw_inv[k], m, log_n, flags, total, il, blockIdx.x);
 }
 

@@ -9,7 +9,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hexl_amd as hx  # noqa: E402
 
-n, b = 65536, 4096
+n, b = 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 primes = [18014398510661633, 18014398512365569, 18014398514200577, 18014398514987009,
           18014398515511297, 18014398516559873, 18014398521016321, 18014398524424193]
 plans = [hx.NTT(n, p) for p in primes]
@@ -51,7 +51,7 @@ def one_slice():
 
 
 for rep in range(2):
-    print("multi-modulus entry point : %.2f ms per step over 8 x 4096" % timed(rns), flush=True)
+    print("multi-modulus entry point : %.2f ms per step over 8 x %d polynomials" % (timed(rns), b), flush=True)
     print("loop of single-modulus calls: %.2f ms" % timed(loop), flush=True)
     print("the same 16 launches on one 2 GiB slice: %.2f ms" % timed(one_slice), flush=True)
 

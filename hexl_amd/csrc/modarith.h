@@ -143,6 +143,23 @@ HX_HD u32 mul_hi32(u32 a, u32 b) { return __umulhi(a, b); }
 HX_HD u32 mul_hi32(u32 a, u32 b) { return (u32)(((u64)a * b) >> 32); }
 #endif
 
+// S >> 32 as a 64-bit value (the addend of the quotient's last mad).  The mad that produced S
+// left its high word in the ODD register of an aligned pair and the addend wants it in the
+// EVEN one with a zero above: left to the compiler that is one v_mov into a pair whose upper
+// half is a shared zero register, or -- under register pressure, 36 of the 44 butterflies of
+// the 11-stage forward tile pass -- two (move down, clear up).  v_pk_mov_b32 builds the pair
+// in ONE instruction with the zero as an inline constant: D.lo = S0[op_sel[0]] = S.hi,
+// D.hi = S1[op_sel[1]] = 0.
+HX_HD u64 high_word(u64 S) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HEXL_AMD_NO_PK_MOV)
+  u64 r;
+  asm("v_pk_mov_b32 %0, %1, 0 op_sel:[1,0]" : "=v"(r) : "v"(S));
+  return r;
+#else
+  return S >> 32;
+#endif
+}
+
 // Lazy-policy product on doubled values.  D = 2x < 2^63, W < q < 2^56,
 // W63 = floor(W * 2^63 / q).  Returns  acc + T2  (mod 2^64) where
 //   T2 = D*W - Q*2q,   Q ~ floor(D * W63 / 2^64).
@@ -163,7 +180,7 @@ HX_HD u64 mul_add_lazy2(u64 acc, u64 D, u64 W, u64 W63, u64 neg_two_q) {
   u64 S = (u64)a1 * b0 + (EXACT ? mul_hi32(a0, b0) : 0u);
   if (EXACT) HX_OPAQUE(S);  // keeps hi(a0*b0) the first mad's addend (else: a separate 64-bit add)
   S = (u64)a0 * b1 + S;
-  const u64 Q = (u64)a1 * b1 + (S >> 32);
+  const u64 Q = (u64)a1 * b1 + high_word(S);
   const u32 w0 = (u32)W, w1 = (u32)(W >> 32);
   const u32 q0 = (u32)Q, q1 = (u32)(Q >> 32);
   const u32 n0 = (u32)neg_two_q, n1 = (u32)(neg_two_q >> 32);
@@ -387,6 +404,23 @@ HX_HD void fwd_butterfly(u64& x, u64& y, u64 W, u64 Wp, const ModConst& m) {
   }
 }
 
+// Lazy policy: a doubled value D < 2^(b+8), b = floor(log2 q) >= 32 (the Lazy policy serves
+// 2^32 <= q < 2^56, choose_policy), brought to [0,4q).  The quotient D / 2q fits in 7 bits and is
+// estimated from the top 8 bits of D with one 32-bit multiply: Qe = hi32((D >> b) *
+// floor(2^(31+b) / q)) is floor(D / 2q) or one less.  D >> b is a 32-bit shift of the high
+// word; D - Qe*2q is one mad for the low product and the carry into the high word plus a
+// 32-bit multiply-add for Qe * hi32(-2q): 5 instructions.
+HX_HD u64 lazy_estimate_reduce(u64 D, const ModConst& m) {
+  const u32 s = (u32)(D >> 32) >> (m.fin_shift - 32);
+  const u32 qe = mul_hi32(s, m.fin_mul);
+  const u32 n0 = (u32)m.neg_two_q, n1 = (u32)(m.neg_two_q >> 32);
+  const u64 lo = (u64)qe * n0 + D;
+  u32 t = qe * n1;
+  HX_OPAQUE(t);  // v_mul_lo_u32 + v_add_u32 (left alone: a second 64-bit mad between two moves)
+  const u32 hi = (u32)(lo >> 32) + t;
+  return ((u64)hi << 32) | (u32)lo;
+}
+
 // End of the forward network: bring a value to [0,q) (canonical) or leave it in
 // the reference's lazy range [0,4q).
 // Lazy: D = 2x < 2^(b+8) with b = floor(log2 q) (x < 55q); the quotient x/q fits
@@ -397,8 +431,7 @@ template <class A>
 HX_HD u64 fwd_finish(u64 x, const ModConst& m, bool canonical) {
   if (A::kFp) return fp_canonical(fp_bits_to_double(x), m);  // also a legal lazy output
   if (A::kLazy) {
-    const u32 qe = mul_hi32((u32)(x >> m.fin_shift), m.fin_mul);
-    u64 r2 = x + (u64)qe * m.neg_two_q;
+    u64 r2 = lazy_estimate_reduce(x, m);
     if (canonical) r2 = csub_neg(r2, m.neg_two_q);
     return r2 >> 1;
   }
@@ -485,8 +518,7 @@ HX_HD u64 inv_ladder(u64 x, const ModConst& m) {
   static_assert(LZ <= 4, "lazy run too long");
   if (LZ == 0) return x;
   if (LZ == 1) return csub_neg(x, m.neg_two_q << 2);
-  const u32 qe = mul_hi32((u32)(x >> m.fin_shift), m.fin_mul);
-  return x + (u64)qe * m.neg_two_q;
+  return lazy_estimate_reduce(x, m);
 }
 
 }  // namespace hexl_amd

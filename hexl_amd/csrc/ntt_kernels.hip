@@ -419,6 +419,32 @@ __device__ __forceinline__ void inv_subtree5_streamed(u64* x, const TwT<A>* __re
 template <int R>
 constexpr int strided_min_waves() { return R >= 5 ? 4 : 6; }
 
+// End of a strided pass: finish (FIN: 0 = more passes follow, 1 = lazy output range,
+// 2 = canonical) and store the E rows of the column.
+template <bool FWD, int FIN, int E, class A, int STK>
+__device__ __forceinline__ void strided_store(u64* out, u64* x, u64 base, u32 log_s,
+                                              const ModConst& m) {
+  // (row offsets and base + lane are recomputed here from opaque copies: shared with the
+  // loads' they stay live in 2 x 32 SGPRs and a VGPR pair across the whole kernel)
+  asm volatile("" : "+s"(log_s));
+  // (the lane index from v_mbcnt: not even threadIdx has to survive the arithmetic)
+  const u32 lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const u64 vbase = base + lane;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    u64 v = x[e];
+    if constexpr (A::kFp) {
+      // every pass hands over fully reduced values; the last one canonical residues
+      if (FWD) v = fp_pass_end(fp_bits_to_double(v), m, FIN != 0);
+      else if (FIN) v = inv_finish<A>(v, m, FIN == 2);
+    } else if (FIN) {
+      v = FWD ? fwd_finish<A>(v, m, FIN == 2) : inv_finish<A>(v, m, FIN == 2);
+    }
+    st_global<STK>(&out[vbase + ((u64)e << log_s)], v);
+    if (E > 8 && (e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // The work of one 256-thread workgroup `bid` of the pass (4 waves x 64 columns).
 // LAST (inverse only): the pass contains the root stage of the transform (a0 == 0).
 // LDK / STK: access kinds of the loads and stores (see ld_global).
@@ -475,26 +501,21 @@ __device__ __forceinline__ void strided_body(u64* out, const u64* in,
       fwd_subtree<R, A>(x, wv, m);
     else
       fwd_subtree5_streamed<A>(x, twa, node, m);
-    if constexpr (A::kFp) {
-      // every pass hands over fully reduced values; the last one canonical residues
-#pragma unroll
-      for (int e = 0; e < E; ++e) x[e] = fp_pass_end(fp_bits_to_double(x[e]), m, finish != 0);
-    } else if (finish) {
-#pragma unroll
-      for (int e = 0; e < E; ++e) x[e] = fwd_finish<A>(x[e], m, finish == 2);
-    }
   } else {
     if constexpr (R < 5)
       inv_subtree<R, A, LAST>(x, wv, m, il);
     else
       inv_subtree5_streamed<A, LAST>(x, twa, node, m, il);
-    if (finish) {
-#pragma unroll
-      for (int e = 0; e < E; ++e) x[e] = inv_finish<A>(x[e], m, finish == 2);
-    }
   }
-#pragma unroll
-  for (int e = 0; e < E; ++e) st_global<STK>(&out[vbase + ((u64)e << log_s)], x[e]);
+  // The finish kind is uniform: three straight-line store loops behind scalar branches, each
+  // element finished right in front of its store (a select per element costs 3 instructions
+  // of the 13; finishing all 32 elements first keeps 64 VGPRs live beside the temporaries).
+  if (finish == 2)
+    strided_store<FWD, 2, E, A, STK>(out, x, base, log_s, m);
+  else if (finish)
+    strided_store<FWD, 1, E, A, STK>(out, x, base, log_s, m);
+  else
+    strided_store<FWD, 0, E, A, STK>(out, x, base, log_s, m);
 }
 
 template <bool FWD, int R, class A, bool LAST>
@@ -947,6 +968,28 @@ __device__ __forceinline__ void store_elem(u64* out, u32 tid, int i, u64 v,
 #endif
 }
 
+// End of a forward tile pass: the 512-element run this wave owns after the last round goes
+// from LDS to global memory, 64 elements per access, with the final reduction fused.
+// FIN: 0 = more passes follow, 1 = lazy output range, 2 = canonical.
+template <int FIN, int S, int CB, int TL, bool GUARD, class A, int STK>
+__device__ __forceinline__ void fwd_copy_out(u64* lds, u64* out, u32 tid, const TileGeom& g,
+                                             u64 total, const ModConst& m) {
+  constexpr int kE = el_of(S);
+  u64 v[kE];
+  u32 a0 = lds_slot(xfer_p0<false, S, CB, TL>(tid, 0)) << 3;
+  HX_OPAQUE(a0);  // one v_xor per access (else: the swizzle redone and shifted per element)
+#pragma unroll
+  for (int i = 0; i < kE; ++i) v[i] = lds_at(lds, a0 ^ (lds_slot(xfer_dp<false, S, CB>(i)) << 3));
+#pragma unroll
+  for (int i = 0; i < kE; ++i) {
+    if (FIN)
+      v[i] = fwd_finish<A>(v[i], m, FIN == 2);
+    else
+      v[i] = fp_bound<A>(v[i], m);  // Fp64: every pass hands over fully reduced values
+    store_elem<false, S, CB, TL, GUARD, STK>(out, tid, i, v[i], g, total);
+  }
+}
+
 // One workgroup per tile; the hardware refills a CU's slots as workgroups retire.
 // (Three persistent variants were built and measured in round 1 -- register
 // prefetch at 8 and at 6 waves per SIMD, LDS-direct DMA prefetch -- all slower, see
@@ -1014,18 +1057,14 @@ __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
     fwd_mid_rounds<S, CB, TL, 1, A, CTW>(x, lds, tw, tid, g, m, il, wn);
     // copy-out of the run this wave owns after the last round (w = CB <= 6):
     // 512 tile-contiguous elements, 64 per access; final reduction fused
-    {
-      const u32 a0 = lds_slot(xfer_p0<false, S, CB, TL>(tid, 0)) << 3;
-#pragma unroll
-      for (int i = 0; i < kE; ++i) {
-        u64 v = lds_at(lds, a0 ^ (lds_slot(xfer_dp<false, S, CB>(i)) << 3));
-        if (finish)
-          v = fwd_finish<A>(v, m, finish == 2);
-        else
-          v = fp_bound<A>(v, m);  // Fp64: every pass hands over fully reduced values
-        store_elem<false, S, CB, TL, GUARD, STK>(out, tid, i, v, g, total);
-      }
-    }
+    // (the finish kind is uniform: three straight-line copies of the copy-out behind scalar
+    // branches instead of a branch and a select per element, with all LDS reads up front)
+    if (finish == 2)
+      fwd_copy_out<2, S, CB, TL, GUARD, A, STK>(lds, out, tid, g, total, m);
+    else if (finish)
+      fwd_copy_out<1, S, CB, TL, GUARD, A, STK>(lds, out, tid, g, total, m);
+    else
+      fwd_copy_out<0, S, CB, TL, GUARD, A, STK>(lds, out, tid, g, total, m);
     HX_STAMP(8);
     HX_PROFILE_WAIT_VMEM();
     HX_STAMP(9);
@@ -1053,12 +1092,15 @@ __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
       if constexpr (!RD::pre_inv(0)) round_twiddles<S, CB, TL, 0, CTW>(w0, tw, tid, g);
       lds_load_round<S, CB, TL, 0>(x, lds, tid);
       round_compute<S, CB, 0, A, false, LAST>(x, w0, m, il);
+      if (finish == 2) {
 #pragma unroll
-      for (int i = 0; i < kE; ++i) {
-        u64 v = x[i];
-        if (finish) v = inv_finish<A>(v, m, finish == 2);
-        store_elem<true, S, CB, TL, GUARD, STK>(out, tid, i, v, g, total);
+        for (int i = 0; i < kE; ++i) x[i] = inv_finish<A>(x[i], m, true);
+      } else if (finish) {
+#pragma unroll
+        for (int i = 0; i < kE; ++i) x[i] = inv_finish<A>(x[i], m, false);
       }
+#pragma unroll
+      for (int i = 0; i < kE; ++i) store_elem<true, S, CB, TL, GUARD, STK>(out, tid, i, x[i], g, total);
     }
   }
 }
@@ -2035,7 +2077,9 @@ int choose_policy(u64 q) {
   // HEXL_AMD_FP64=2: Fp64 also below 2^30 (A/B against the 32-bit Small policy)
   if (q < kSmallModulusBound && !(fp && tuning().fp64.load() == 2)) return kPolicySmall;
   if (q < kFp64ModulusBound && fp) return kPolicyFp64;
-  if (q < kLazyModulusBound) return kPolicyLazy;
+  // (the Lazy policy's quotient estimates shift the HIGH word of a value: q >= 2^32; with the
+  // Fp64 policy switched off the moduli between 2^30 and 2^32 take the Harvey60 policy)
+  if (q >= (1ull << 32) && q < kLazyModulusBound) return kPolicyLazy;
   // HEXL_AMD_H60=0: 2^56 <= q < 2^60 + 2^28 on the Strict policy (A/B runs)
   if (q < kHarvey60ModulusBound && tuning().h60.load() != 0) return kPolicyHarvey60;
   return kPolicyStrict;

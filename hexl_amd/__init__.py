@@ -110,6 +110,22 @@ def _load():
     sig("hexl_amd_profile_stop", ci, C.POINTER(ci))
     sig("hexl_amd_profile_get", ci, ci, C.POINTER(C.c_char_p), C.POINTER(C.c_float))
     sig("hexl_amd_set_tuning", ci, C.c_char_p, u64)
+    sig("hexl_amd_ntt_forward_map", ci, C.POINTER(vp), u64, C.POINTER(C.c_uint8), u64, u64, p64, p64,
+        u64, u64, u64, vp)
+    sig("hexl_amd_ntt_inverse_map", ci, C.POINTER(vp), u64, C.POINTER(C.c_uint8), u64, u64, p64, p64,
+        u64, u64, u64, vp)
+    sig("hexl_amd_ntt_forward_indexed", ci, C.POINTER(vp), u64, C.POINTER(C.c_uint32), p64, p64, u64,
+        u64, u64, vp)
+    sig("hexl_amd_ntt_inverse_indexed", ci, C.POINTER(vp), u64, C.POINTER(C.c_uint32), p64, p64, u64,
+        u64, u64, vp)
+    sig("hexl_amd_host_alloc", ci, C.POINTER(vp), u64)
+    sig("hexl_amd_host_free", ci, vp)
+    sig("hexl_amd_host_register", ci, vp, u64)
+    sig("hexl_amd_host_unregister", ci, vp)
+    sig("hexl_amd_pointer_kind", ci, vp)
+    sig("hexl_amd_check_bounds", ci, p64, u64, u64, C.POINTER(u64))
+    sig("hexl_amd_release_stream_workspaces", ci, vp)
+    sig("hexl_amd_release_workspaces", ci)
     return lib
 
 
@@ -135,6 +151,11 @@ C_ABI_SYMBOLS = [
     "hexl_amd_generate_primes", "hexl_amd_ntt_check_arguments", "hexl_amd_fill_splitmix",
     "hexl_amd_profile_start", "hexl_amd_profile_stop", "hexl_amd_profile_get",
     "hexl_amd_set_tuning",
+    "hexl_amd_ntt_forward_map", "hexl_amd_ntt_inverse_map", "hexl_amd_ntt_forward_indexed",
+    "hexl_amd_ntt_inverse_indexed", "hexl_amd_release_stream_workspaces",
+    "hexl_amd_release_workspaces", "hexl_amd_host_alloc", "hexl_amd_host_free",
+    "hexl_amd_host_register", "hexl_amd_host_unregister", "hexl_amd_pointer_kind",
+    "hexl_amd_check_bounds",
 ]
 
 
@@ -352,6 +373,58 @@ def ComputeInverseRNS(plans, result, operand, input_mod_factor, output_mod_facto
          output_mod_factor)
 
 
+def _map(fn, plans, plan_of_slot, inner, result, operand, in_mf, out_mf):
+    k = len(plans)
+    n = plans[0].GetDegree()
+    if operand.numel() % n or result.numel() != operand.numel():
+        raise HexlAmdError("operand must hold whole polynomials")
+    arr = (C.c_void_p * k)(*[p._h for p in plans])
+    tab = (C.c_uint8 * len(plan_of_slot))(*plan_of_slot)
+    dev = plans[0].GetDevice()
+    _check(fn(arr, k, tab, len(plan_of_slot), inner, _ptr(result, 0, dev), _ptr(operand, 0, dev),
+              operand.numel() // n, in_mf, out_mf, _stream()))
+
+
+def ComputeForwardMap(plans, plan_of_slot, inner, result, operand, input_mod_factor,
+                      output_mod_factor):
+    """Polynomial i uses plans[plan_of_slot[(i // inner) % len(plan_of_slot)]]: inner = 1 and
+    plan_of_slot = range(k) is SEAL's [ciphertext][component][modulus][N] layout."""
+    _map(lib.hexl_amd_ntt_forward_map, plans, plan_of_slot, inner, result, operand,
+         input_mod_factor, output_mod_factor)
+
+
+def ComputeInverseMap(plans, plan_of_slot, inner, result, operand, input_mod_factor,
+                      output_mod_factor):
+    _map(lib.hexl_amd_ntt_inverse_map, plans, plan_of_slot, inner, result, operand,
+         input_mod_factor, output_mod_factor)
+
+
+def _indexed(fn, plans, prime_index, result, operand, in_mf, out_mf):
+    k = len(plans)
+    n = plans[0].GetDegree()
+    polys = operand.numel() // n
+    if operand.numel() % n or result.numel() != operand.numel() or len(prime_index) != polys:
+        raise HexlAmdError("one prime index per polynomial")
+    arr = (C.c_void_p * k)(*[p._h for p in plans])
+    idx = (C.c_uint32 * polys)(*[int(v) for v in prime_index])
+    dev = plans[0].GetDevice()
+    _check(fn(arr, k, idx, _ptr(result, 0, dev), _ptr(operand, 0, dev), polys, in_mf, out_mf,
+              _stream()))
+
+
+def ComputeForwardIndexed(plans, prime_index, result, operand, input_mod_factor,
+                          output_mod_factor):
+    """Polynomial i uses plans[prime_index[i]]."""
+    _indexed(lib.hexl_amd_ntt_forward_indexed, plans, prime_index, result, operand,
+             input_mod_factor, output_mod_factor)
+
+
+def ComputeInverseIndexed(plans, prime_index, result, operand, input_mod_factor,
+                          output_mod_factor):
+    _indexed(lib.hexl_amd_ntt_inverse_indexed, plans, prime_index, result, operand,
+             input_mod_factor, output_mod_factor)
+
+
 # ----------------------------------------------------------------------------
 # Eltwise -- hexl/include/hexl/eltwise/*.hpp
 # ----------------------------------------------------------------------------
@@ -486,11 +559,18 @@ def profile_stop():
 PLAN_FUSED, PLAN_SPLIT, PLAN_TILED, PLAN_MIXED = 0, 1, 2, 3
 
 
+def has_experiments():
+    """True when the loaded library was built with -DHEXL_AMD_EXPERIMENTS (the measured-and-
+    not-adopted plans: fused, tiled, mixed; tools/build_variant.sh exp -DHEXL_AMD_EXPERIMENTS,
+    HEXL_AMD_LIB=tools/libhexl_amd_exp.so)."""
+    return lib.hexl_amd_set_tuning(b"experiments", 1) == 0
+
+
 def set_tuning(key, value):
     """Tuning / diagnostic knobs of the transform launch logic (include/hexl_amd.h):
-    "plan" (PLAN_FUSED / PLAN_SPLIT / PLAN_TILED / PLAN_MIXED), "fused_window",
-    "fused_min_batch", "fused_wg_per_cu", "mixed_chunk", "tile13", "fp64" and "h60" (both read at plan
-    creation).  Results never depend on them."""
+    "tile13", "fp64" and "h60" (both read at plan creation); in experiments builds also "plan"
+    (PLAN_FUSED / PLAN_SPLIT / PLAN_TILED / PLAN_MIXED), "fused_window", "fused_min_batch",
+    "fused_wg_per_cu", "mixed_chunk".  Results never depend on them."""
     _check(lib.hexl_amd_set_tuning(key.encode(), int(value)))
 
 

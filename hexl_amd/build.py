@@ -81,6 +81,16 @@ def build(verbose=False):
         cmd = [HIPCC, "-shared", "-fPIC", "-o", shim] + shim_objs + [
             f"-L{LIB}", "-lhexl_amd", "-Wl,-rpath,$ORIGIN"]
         subprocess.check_call(cmd)
+    # the debug flavour of the shim (the reference's CMake builds `hexl_debug` from the same
+    # sources with HEXL_DEBUG, hexl/CMakeLists.txt:68-72): element-wise bound checks that throw
+    if shim_objs:
+        dbg = os.path.join(LIB, "libhexl_debug.so")
+        shim_src = os.path.join(CSRC, SHIM_SOURCES[0])
+        if not _newer(dbg, [shim_src, core] + _headers()):
+            cmd = [HIPCC, "-x", "c++"] + COMMON + ["-DHEXL_DEBUG", "-I/opt/rocm/include",
+                   "-D__HIP_PLATFORM_AMD__", "-shared", shim_src, "-o", dbg, f"-L{LIB}",
+                   "-lhexl_amd", "-Wl,-rpath,$ORIGIN"]
+            subprocess.check_call(cmd)
     if verbose:
         print("built", core, "and", shim if shim_objs else "(no shim yet)")
     return core

@@ -80,6 +80,15 @@ struct Staging {
   ~Staging() {
     if (stream) (void)hipStreamSynchronize(stream);
     if (stream2) (void)hipStreamSynchronize(stream2);
+    // the composites' scratch keyed by these streams (KeySwitch through host pointers)
+    if (device >= 0 && (stream || stream2)) {
+      int cur = -1;
+      if (hipGetDevice(&cur) == hipSuccess && (cur == device || hipSetDevice(device) == hipSuccess)) {
+        if (stream) release_stream_workspaces(stream);
+        if (stream2) release_stream_workspaces(stream2);
+        if (cur != device && cur >= 0) (void)hipSetDevice(cur);
+      }
+    }
     if (buf) (void)hipFree(buf);
     if (stream) (void)hipStreamDestroy(stream);
     if (stream2) (void)hipStreamDestroy(stream2);
@@ -91,6 +100,8 @@ struct Staging {
         if (hipSetDevice(device) == hipSuccess) {
           if (stream) (void)hipStreamSynchronize(stream);
           if (stream2) (void)hipStreamSynchronize(stream2);
+          if (stream) release_stream_workspaces(stream);
+          if (stream2) release_stream_workspaces(stream2);
           if (buf) (void)hipFree(buf);
           if (stream) (void)hipStreamDestroy(stream);
           if (stream2) (void)hipStreamDestroy(stream2);
@@ -144,7 +155,11 @@ int hexl_amd_device_count(int* count) {
   return HEXL_AMD_OK;
 }
 
-int hexl_amd_pointer_is_device(const void* p) {
+// 0 = ordinary host memory (or unknown), 1 = device / managed memory, 2 = pinned host memory
+// mapped into the device's address space (hipHostMalloc / hipHostRegister: kernels can read
+// and write it over the link).  *dev_alias: the address kernels use (kinds 1 and 2).
+static int pointer_kind(const void* p, void** dev_alias) {
+  if (dev_alias) *dev_alias = nullptr;
   if (!p) return 0;
   hipPointerAttribute_t attr;
   hipError_t e = hipPointerGetAttributes(&attr, p);
@@ -152,7 +167,76 @@ int hexl_amd_pointer_is_device(const void* p) {
     (void)hipGetLastError();  // unregistered host memory reports an error: clear it
     return 0;
   }
-  return (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged) ? 1 : 0;
+  if (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged) {
+    if (dev_alias) *dev_alias = const_cast<void*>(p);
+    return 1;
+  }
+  if (attr.type == hipMemoryTypeHost && attr.devicePointer) {
+    if (dev_alias) {
+      // (attr.devicePointer is the alias of the address that was asked about)
+      *dev_alias = attr.devicePointer;
+    }
+    return 2;
+  }
+  return 0;
+}
+
+int hexl_amd_pointer_is_device(const void* p) { return pointer_kind(p, nullptr) == 1 ? 1 : 0; }
+int hexl_amd_pointer_kind(const void* p) { return pointer_kind(p, nullptr); }
+
+int hexl_amd_host_alloc(void** p, uint64_t bytes) {
+  if (!p) return fail(HEXL_AMD_ERR_INVALID_ARG, "p == nullptr");
+  *p = nullptr;
+  if (bytes == 0) return HEXL_AMD_OK;
+  HX_HIP(hipHostMalloc(p, (size_t)bytes, hipHostMallocMapped | hipHostMallocPortable));
+  return HEXL_AMD_OK;
+}
+int hexl_amd_host_free(void* p) {
+  if (!p) return HEXL_AMD_OK;
+  HX_HIP(hipHostFree(p));
+  return HEXL_AMD_OK;
+}
+int hexl_amd_host_register(void* p, uint64_t bytes) {
+  if (!p || bytes == 0) return fail(HEXL_AMD_ERR_INVALID_ARG, "p == nullptr or bytes == 0");
+  HX_HIP(hipHostRegister(p, (size_t)bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+  return HEXL_AMD_OK;
+}
+int hexl_amd_host_unregister(void* p) {
+  if (!p) return HEXL_AMD_OK;
+  HX_HIP(hipHostUnregister(p));
+  return HEXL_AMD_OK;
+}
+
+int hexl_amd_check_bounds(const uint64_t* data, uint64_t n, uint64_t bound,
+                          uint64_t* violations) {
+  if (!violations) return fail(HEXL_AMD_ERR_INVALID_ARG, "violations == nullptr");
+  *violations = 0;
+  if (n == 0) return HEXL_AMD_OK;
+  if (!data) return fail(HEXL_AMD_ERR_INVALID_ARG, "data == nullptr");
+  void* alias = nullptr;
+  const int kind = pointer_kind(data, &alias);
+  if (kind == 0) {  // the caller's own host buffer: validating it is not computing on it
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < n; ++i) bad += data[i] >= bound;
+    *violations = bad;
+    return HEXL_AMD_OK;
+  }
+  int device = 0;
+  HX_HIP(hipGetDevice(&device));
+  if (int rc = g_staging.ensure(device, sizeof(unsigned long long))) return rc;
+  unsigned long long* counter = (unsigned long long*)g_staging.buf;
+  hipStream_t st = g_staging.stream;
+  // the data may still be being produced on another stream: the check is a debug aid and
+  // synchronises the device first
+  HX_HIP(hipDeviceSynchronize());
+  HX_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
+  hipError_t e = count_out_of_bounds_launch((const u64*)alias, n, bound, counter, st);
+  if (e != hipSuccess) return hip_fail(e, "bounds check launch");
+  unsigned long long bad = 0;
+  HX_HIP(hipMemcpyAsync(&bad, counter, sizeof bad, hipMemcpyDeviceToHost, st));
+  HX_HIP(hipStreamSynchronize(st));
+  *violations = bad;
+  return HEXL_AMD_OK;
 }
 
 int hexl_amd_ntt_check_arguments(uint64_t degree, uint64_t modulus) {
@@ -374,6 +458,139 @@ int hexl_amd_ntt_inverse(const hexl_amd_ntt* p, uint64_t* result, const uint64_t
   return ntt_run(p, result, operand, batch, false, in_mf, out_mf, stream);
 }
 
+// Polynomial i of `polys` uses plans[tab[(i / inner) % period]] (hexl_amd_ntt_*_map).
+static int ntt_run_map(const hexl_amd_ntt* const* plans, uint64_t num_plans, const uint8_t* tab,
+                       uint64_t period, uint64_t inner, uint64_t* result, const uint64_t* operand,
+                       uint64_t polys, bool forward, uint64_t in_mf, uint64_t out_mf,
+                       void* stream) {
+  if (!plans || num_plans == 0) return fail(HEXL_AMD_ERR_INVALID_ARG, "no plans");
+  if (!tab || period == 0 || inner == 0)
+    return fail(HEXL_AMD_ERR_INVALID_ARG, "plan_of_slot == nullptr, period == 0 or inner == 0");
+  for (uint64_t k = 0; k < num_plans; ++k) {
+    if (!plans[k]) return fail(HEXL_AMD_ERR_INVALID_ARG, "plans[%llu] == nullptr",
+                               (unsigned long long)k);
+    if (plans[k]->n != plans[0]->n || plans[k]->device != plans[0]->device)
+      return fail(HEXL_AMD_ERR_INVALID_ARG, "plans must share degree and device");
+  }
+  for (uint64_t s = 0; s < period; ++s)
+    if (tab[s] >= num_plans)
+      return fail(HEXL_AMD_ERR_INVALID_ARG, "plan_of_slot[%llu] = %u is not a plan index",
+                  (unsigned long long)s, (unsigned)tab[s]);
+  if (polys == 0) return HEXL_AMD_OK;
+  if (int rc = check_ntt_args(plans[0], result, operand, forward, in_mf, out_mf)) return rc;
+  const uint64_t n = plans[0]->n;
+  // One launch sequence for the whole batch where the multi-plan kernels cover the shape.
+  // Chunks of < 2^31 polynomials, cut at multiples of inner * period so that the map keeps
+  // its phase.
+  const uint64_t cycle = inner <= (1ull << 31) / period ? inner * period : 0;  // 0: too long
+  if (num_plans <= (uint64_t)kMaxMultiPlans && period <= (uint64_t)kMaxMultiPeriod &&
+      inner < (1ull << 31) && (polys < (1ull << 31) || (cycle && cycle < (1ull << 30)))) {
+    DeviceScope scope(plans[0]->device);
+    if (scope.err != hipSuccess) return hip_fail(scope.err, "hipSetDevice");
+    const NttTables* tabs[kMaxMultiPlans];
+    MultiMap map{};
+    map.inner = (u32)inner;
+    map.period = (u32)period;
+    for (uint64_t k = 0; k < num_plans; ++k) tabs[k] = &plans[k]->t;
+    for (uint64_t s = 0; s < period; ++s) map.plan_tab[s] = tab[s];
+    const uint64_t chunk = polys < (1ull << 31) ? polys : ((1ull << 31) - 1) / cycle * cycle;
+    bool refused = false;
+    for (uint64_t off = 0; off < polys && !refused; off += chunk) {
+      const uint64_t cnt = polys - off < chunk ? polys - off : chunk;
+      const hipError_t e = ntt_multi_launch(forward, tabs, (u32)num_plans, map, cnt,
+                                            result + off * n, operand + off * n, out_mf,
+                                            (hipStream_t)stream);
+      // (ntt_multi_launch validates the whole sequence -- every pass, every arithmetic
+      // policy -- before its first launch: "not supported" means nothing was enqueued, and
+      // the answer is the same for every chunk of the call)
+      if (e == hipErrorNotSupported && off == 0)
+        refused = true;
+      else if (e != hipSuccess)
+        return hip_fail(e, "multi-plan NTT launch");
+    }
+    if (!refused) return HEXL_AMD_OK;
+  }
+  // Run by run: maximal runs of consecutive polynomials that share a plan.
+  uint64_t start = 0;
+  while (start < polys) {
+    const uint8_t k = tab[(start / inner) % period];
+    uint64_t end = (start / inner + 1) * inner;
+    while (end < polys && tab[(end / inner) % period] == k) end += inner;
+    if (end > polys) end = polys;
+    if (int rc = ntt_run(plans[k], result + start * n, operand + start * n, end - start, forward,
+                         in_mf, out_mf, stream))
+      return rc;
+    start = end;
+  }
+  return HEXL_AMD_OK;
+}
+
+// prime_index[i] of polynomial i -> the (inner, period, table) form, or run by run.
+static int ntt_run_indexed(const hexl_amd_ntt* const* plans, uint64_t num_plans,
+                           const uint32_t* idx, uint64_t* result, const uint64_t* operand,
+                           uint64_t polys, bool forward, uint64_t in_mf, uint64_t out_mf,
+                           void* stream) {
+  if (!plans || num_plans == 0) return fail(HEXL_AMD_ERR_INVALID_ARG, "no plans");
+  if (polys == 0) return HEXL_AMD_OK;
+  if (!idx) return fail(HEXL_AMD_ERR_INVALID_ARG, "prime_index == nullptr");
+  for (uint64_t i = 0; i < polys; ++i)
+    if (idx[i] >= num_plans)
+      return fail(HEXL_AMD_ERR_INVALID_ARG, "prime_index[%llu] = %u is not a plan index",
+                  (unsigned long long)i, (unsigned)idx[i]);
+  // inner = gcd of the run lengths (the last run may be cut short by the end of the batch)
+  auto gcd = [](uint64_t a, uint64_t b) {
+    while (b) {
+      const uint64_t t = a % b;
+      a = b;
+      b = t;
+    }
+    return a;
+  };
+  // (every complete run -- all but the last, which the end of the batch may cut short -- is a
+  // whole number of slots; runs therefore start at multiples of inner and slots are uniform)
+  uint64_t inner = 0, run_start = 0;
+  for (uint64_t i = 1; i < polys; ++i)
+    if (idx[i] != idx[i - 1]) {
+      inner = gcd(inner, i - run_start);
+      run_start = i;
+    }
+  if (inner == 0) inner = polys;  // one run
+  const uint64_t slots = (polys + inner - 1) / inner;
+  // shortest period of the slot sequence
+  uint64_t period = 0;
+  const uint64_t max_period = slots < (uint64_t)kMaxMultiPeriod ? slots : (uint64_t)kMaxMultiPeriod;
+  for (uint64_t p = 1; p <= max_period && !period; ++p) {
+    bool ok = true;
+    for (uint64_t s = p; s < slots && ok; ++s) ok = idx[s * inner] == idx[(s - p) * inner];
+    if (ok) period = p;
+  }
+  if (period && num_plans <= 256) {
+    uint8_t tab[kMaxMultiPeriod];
+    for (uint64_t s = 0; s < period; ++s) tab[s] = (uint8_t)idx[s * inner];
+    return ntt_run_map(plans, num_plans, tab, period, inner, result, operand, polys, forward,
+                       in_mf, out_mf, stream);
+  }
+  // no periodic structure: run by run
+  for (uint64_t k = 0; k < num_plans; ++k) {
+    if (!plans[k]) return fail(HEXL_AMD_ERR_INVALID_ARG, "plans[%llu] == nullptr",
+                               (unsigned long long)k);
+    if (plans[k]->n != plans[0]->n || plans[k]->device != plans[0]->device)
+      return fail(HEXL_AMD_ERR_INVALID_ARG, "plans must share degree and device");
+  }
+  const uint64_t n = plans[0]->n;
+  for (uint64_t start = 0; start < polys;) {
+    uint64_t end = start + 1;
+    while (end < polys && idx[end] == idx[start]) ++end;
+    if (int rc = ntt_run(plans[idx[start]], result + start * n, operand + start * n, end - start,
+                         forward, in_mf, out_mf, stream))
+      return rc;
+    start = end;
+  }
+  return HEXL_AMD_OK;
+}
+
+// Prime-major blocks: polynomials [k * batch_per_plan, (k+1) * batch_per_plan) belong to
+// plans[k] -- the map form with inner = batch_per_plan and the identity table.
 static int ntt_run_rns(const hexl_amd_ntt* const* plans, uint64_t num_plans, uint64_t* result,
                        const uint64_t* operand, uint64_t batch_per_plan, bool forward,
                        uint64_t in_mf, uint64_t out_mf, void* stream) {
@@ -386,40 +603,22 @@ static int ntt_run_rns(const hexl_amd_ntt* const* plans, uint64_t num_plans, uin
   }
   if (num_plans == 0 || batch_per_plan == 0) return HEXL_AMD_OK;
   if (int rc = check_ntt_args(plans[0], result, operand, forward, in_mf, out_mf)) return rc;
-  // One launch sequence over all moduli where the shapes allow it (degree 2^12 .. 2^17),
-  // in groups of kMaxMultiPlans; otherwise plan by plan.  With many polynomials per modulus
-  // the launches no longer matter and the single-plan kernels are ~5 % faster (their plan is
-  // in the kernel arguments): plan by plan from 2^24 coefficients per modulus.
+  // One launch sequence over all moduli (groups of kMaxMultiPlans) through the map form.
+  // With many polynomials per modulus the launches no longer matter and the single-plan
+  // kernels are ~5 % faster (their plan is in the kernel arguments): plan by plan from 2^24
+  // coefficients per modulus.
   if (num_plans > 1 && batch_per_plan * plans[0]->n < (1ull << 24)) {
-    DeviceScope scope(plans[0]->device);
-    if (scope.err != hipSuccess) return hip_fail(scope.err, "hipSetDevice");
-    bool multi_ok = true;
-    uint64_t k = 0;
-    while (multi_ok && k < num_plans) {
+    uint8_t identity[kMaxMultiPlans];
+    for (int j = 0; j < kMaxMultiPlans; ++j) identity[j] = (uint8_t)j;
+    for (uint64_t k = 0; k < num_plans; k += (uint64_t)kMaxMultiPlans) {
       const uint64_t cnt = num_plans - k < (uint64_t)kMaxMultiPlans ? num_plans - k
                                                                      : (uint64_t)kMaxMultiPlans;
-      const NttTables* tabs[kMaxMultiPlans];
-      MultiMap map{};
-      map.inner = (u32)batch_per_plan;
-      map.period = (u32)cnt;
-      for (uint64_t j = 0; j < cnt; ++j) {
-        tabs[j] = &plans[k + j]->t;
-        map.plan_tab[j] = (uint8_t)j;
-      }
       const uint64_t off = k * batch_per_plan * plans[0]->n;
-      hipError_t e = batch_per_plan < (1ull << 31)
-                         ? ntt_multi_launch(forward, tabs, (u32)cnt, map, cnt * batch_per_plan,
-                                            result + off, operand + off, out_mf,
-                                            (hipStream_t)stream)
-                         : hipErrorNotSupported;
-      if (e == hipErrorNotSupported && k == 0) {
-        multi_ok = false;
-        break;
-      }
-      if (e != hipSuccess) return hip_fail(e, "multi-plan NTT launch");
-      k += cnt;
+      if (int rc = ntt_run_map(plans + k, cnt, identity, cnt, batch_per_plan, result + off,
+                               operand + off, cnt * batch_per_plan, forward, in_mf, out_mf, stream))
+        return rc;
     }
-    if (multi_ok) return HEXL_AMD_OK;
+    return HEXL_AMD_OK;
   }
   for (uint64_t k = 0; k < num_plans; ++k) {
     const uint64_t off = k * batch_per_plan * plans[k]->n;
@@ -428,6 +627,35 @@ static int ntt_run_rns(const hexl_amd_ntt* const* plans, uint64_t num_plans, uin
       return rc;
   }
   return HEXL_AMD_OK;
+}
+
+int hexl_amd_ntt_forward_map(const hexl_amd_ntt* const* plans, uint64_t num_plans,
+                             const uint8_t* plan_of_slot, uint64_t period, uint64_t inner,
+                             uint64_t* result, const uint64_t* operand, uint64_t polys,
+                             uint64_t in_mf, uint64_t out_mf, void* stream) {
+  return ntt_run_map(plans, num_plans, plan_of_slot, period, inner, result, operand, polys, true,
+                     in_mf, out_mf, stream);
+}
+int hexl_amd_ntt_inverse_map(const hexl_amd_ntt* const* plans, uint64_t num_plans,
+                             const uint8_t* plan_of_slot, uint64_t period, uint64_t inner,
+                             uint64_t* result, const uint64_t* operand, uint64_t polys,
+                             uint64_t in_mf, uint64_t out_mf, void* stream) {
+  return ntt_run_map(plans, num_plans, plan_of_slot, period, inner, result, operand, polys, false,
+                     in_mf, out_mf, stream);
+}
+int hexl_amd_ntt_forward_indexed(const hexl_amd_ntt* const* plans, uint64_t num_plans,
+                                 const uint32_t* prime_index, uint64_t* result,
+                                 const uint64_t* operand, uint64_t polys, uint64_t in_mf,
+                                 uint64_t out_mf, void* stream) {
+  return ntt_run_indexed(plans, num_plans, prime_index, result, operand, polys, true, in_mf,
+                         out_mf, stream);
+}
+int hexl_amd_ntt_inverse_indexed(const hexl_amd_ntt* const* plans, uint64_t num_plans,
+                                 const uint32_t* prime_index, uint64_t* result,
+                                 const uint64_t* operand, uint64_t polys, uint64_t in_mf,
+                                 uint64_t out_mf, void* stream) {
+  return ntt_run_indexed(plans, num_plans, prime_index, result, operand, polys, false, in_mf,
+                         out_mf, stream);
 }
 
 int hexl_amd_ntt_forward_rns(const hexl_amd_ntt* const* plans, uint64_t num_plans,
@@ -482,6 +710,34 @@ static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t*
     return forward ? ntt_forward_launch(p->t, d, d, polys, out_mf, st)
                    : ntt_inverse_launch(p->t, d, d, polys, out_mf, st);
   };
+  // Caller memory the kernels can address (pinned and mapped: hexl_amd_host_alloc /
+  // hexl_amd_host_register, the intel::hexl allocator built on them): a one-kernel transform
+  // reads the operand and writes the result straight over the link -- no staging copies, one
+  // launch, one synchronisation; a multi-pass transform reads the operand in its first pass
+  // (no H2D copy) and copies the result back.
+  void *op_dev = nullptr, *res_dev = nullptr;
+  const int op_kind = pointer_kind(operand, &op_dev), res_kind = pointer_kind(result, &res_dev);
+  if (op_kind == 2 && (bytes < host_pipeline_min_bytes() || batch < 4)) {
+    if (int rc = g_staging.ensure(p->device, 8)) return rc;  // (the stream)
+    hipStream_t st = g_staging.stream;
+    auto launch = [&](u64* dst) {
+      return forward ? ntt_forward_launch(p->t, dst, (const u64*)op_dev, batch, out_mf, st)
+                     : ntt_inverse_launch(p->t, dst, (const u64*)op_dev, batch, out_mf, st);
+    };
+    if (res_kind == 2 && ntt_is_single_kernel(p->t, batch)) {
+      hipError_t e = launch((u64*)res_dev);
+      if (e != hipSuccess) return hip_fail(e, "NTT launch");
+      HX_HIP(hipStreamSynchronize(st));
+      return HEXL_AMD_OK;
+    }
+    if (int rc = g_staging.ensure(p->device, bytes)) return rc;
+    u64* d = (u64*)g_staging.buf;
+    hipError_t e = launch(d);
+    if (e != hipSuccess) return hip_fail(e, "NTT launch");
+    HX_HIP(hipMemcpyAsync(result, d, bytes, hipMemcpyDeviceToHost, st));
+    HX_HIP(hipStreamSynchronize(st));
+    return HEXL_AMD_OK;
+  }
   if (bytes < host_pipeline_min_bytes() || batch < 4) {
     if (int rc = g_staging.ensure(p->device, bytes)) return rc;
     u64* d = (u64*)g_staging.buf;
@@ -678,6 +934,20 @@ static int eltwise_host_run(EltOp op, EltArgs g, uint64_t* result, const uint64_
   HX_HIP(hipGetDevice(&device));
   const size_t bytes = (size_t)n * sizeof(u64);
   const bool has_b = operand2 != nullptr;
+  {  // mapped caller memory: the streaming kernel runs straight on it (see ntt_run_host)
+    void *r = nullptr, *a = nullptr, *b = nullptr;
+    if (pointer_kind(result, &r) == 2 && pointer_kind(operand1, &a) == 2 &&
+        (!has_b || pointer_kind(operand2, &b) == 2)) {
+      if (int rc = g_staging.ensure(device, 8)) return rc;
+      g.result = (u64*)r;
+      g.a = (const u64*)a;
+      g.b = (const u64*)b;
+      hipError_t e = eltwise_launch(op, g, g_staging.stream);
+      if (e != hipSuccess) return hip_fail(e, "eltwise launch");
+      HX_HIP(hipStreamSynchronize(g_staging.stream));
+      return HEXL_AMD_OK;
+    }
+  }
   if (int rc = g_staging.ensure(device, bytes * (has_b ? 2 : 1))) return rc;
   u64* da = (u64*)g_staging.buf;
   u64* db = has_b ? da + n : nullptr;
@@ -1121,6 +1391,15 @@ int hexl_amd_profile_get(int i, const char** name, float* ms) {
   if (i < 0 || i >= (int)ps.ms.size()) return fail(HEXL_AMD_ERR_INVALID_ARG, "bad record index");
   if (name) *name = ps.records[i].name;
   if (ms) *ms = ps.ms[i];
+  return HEXL_AMD_OK;
+}
+
+int hexl_amd_release_stream_workspaces(void* stream) {
+  release_stream_workspaces((hipStream_t)stream);
+  return HEXL_AMD_OK;
+}
+int hexl_amd_release_workspaces(void) {
+  release_workspaces();
   return HEXL_AMD_OK;
 }
 

@@ -364,6 +364,27 @@ fill_splitmix_kernel(u64* data, u64 n, u64 total, u64 seed0, u64 bound) {
   }
 }
 
+// Debug contract (HEXL_CHECK_BOUNDS of the reference's debug builds, e.g.
+// hexl/ntt/ntt-internal.cpp:198, :261, hexl/eltwise/eltwise-mult-mod.cpp:31-33): the number
+// of words >= bound, added to *violations (one atomic per wave that found any).
+__global__ void __launch_bounds__(256)
+count_out_of_bounds_kernel(const u64* data, u64 n, u64 bound, unsigned long long* violations) {
+  const u64 stride = (u64)gridDim.x * 256;
+  unsigned long long bad = 0;
+  for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) bad += data[k] >= bound;
+  for (int off = 32; off > 0; off >>= 1) bad += __shfl_down(bad, off, 64);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(violations, bad);
+}
+
+hipError_t count_out_of_bounds_launch(const u64* data, u64 n, u64 bound,
+                                      unsigned long long* violations, hipStream_t st) {
+  unsigned grid = grid_for(n);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(count_out_of_bounds_kernel, dim3(grid), dim3(256), 0, st, data, n, bound,
+                     violations);
+  return hipGetLastError();
+}
+
 hipError_t fill_splitmix_launch(u64* data, u64 n, u64 batch, u64 seed0, u64 bound,
                                 hipStream_t st) {
   const u64 total = n * batch;

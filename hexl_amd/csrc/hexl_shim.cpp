@@ -11,6 +11,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "hexl/hexl.hpp"
 #include "hexl_amd.h"
@@ -26,9 +27,47 @@ void check(int rc) {
   if (rc != HEXL_AMD_OK) throw std::runtime_error(std::string("hexl: ") + hexl_amd_last_error());
 }
 
+// The debug contract.  The reference's debug library (libhexl_debug: HEXL_DEBUG) checks every
+// ELEMENT of an operand against its range and throws (HEXL_CHECK_BOUNDS,
+// hexl/include/hexl/util/check.hpp:32-35; hexl/ntt/ntt-internal.cpp:198, :261;
+// hexl/eltwise/eltwise-mult-mod.cpp:31-33, ...; exercised by test/test-ntt.cpp:20-94).  This
+// file compiled with -DHEXL_DEBUG is libhexl_debug.so: the same checks, through
+// hexl_amd_check_bounds -- a loop for the caller's host buffers, one reduction kernel for
+// device memory.  Scalar arguments (null pointers, mod factors, modulus ranges) are validated
+// by the C-ABI in every build.
+#ifdef HEXL_DEBUG
+void shim_check_bounds(const uint64_t* arg, uint64_t n, uint64_t bound, const char* what,
+                       const char* function) {
+  if (!arg || n == 0) return;  // (null / empty: reported by the operation itself)
+  uint64_t violations = 0;
+  check(hexl_amd_check_bounds(arg, n, bound, &violations));
+  HEXL_CHECK(violations == 0, violations << " value(s) of " << what << " in " << function
+                                         << " exceed bound " << bound);
+}
+#define HEXL_SHIM_CHECK_BOUNDS(arg, n, bound, what) \
+  shim_check_bounds(arg, n, bound, what, __FUNCTION__)
+#else
+#define HEXL_SHIM_CHECK_BOUNDS(arg, n, bound, what) \
+  {}
+#endif
+
 using Table = AlignedVector64<uint64_t>;
 
 }  // namespace
+
+// ---------------------------------------------------------------- device-mapped host memory
+void* DeviceMappedAllocate(size_t bytes) {
+  void* p = nullptr;
+  check(hexl_amd_host_alloc(&p, bytes));
+  return p;
+}
+void DeviceMappedFree(void* p) noexcept { (void)hexl_amd_host_free(p); }
+void RegisterHostMemory(void* p, size_t bytes) { check(hexl_amd_host_register(p, bytes)); }
+void UnregisterHostMemory(void* p) noexcept { (void)hexl_amd_host_unregister(p); }
+AllocatorStrategyPtr DeviceMappedStrategy() {
+  static AllocatorStrategyPtr s = std::make_shared<DeviceMappedAllocator>();
+  return s;
+}
 
 // ---------------------------------------------------------------- number theory
 uint64_t ReverseBits(uint64_t x, uint64_t bit_width) { return hexl_amd_reverse_bits(x, bit_width); }
@@ -150,6 +189,7 @@ bool NTT::CheckArguments(uint64_t degree, uint64_t modulus) {
 void NTT::ComputeForwardBatch(uint64_t* result, const uint64_t* operand, uint64_t batch,
                               uint64_t input_mod_factor, uint64_t output_mod_factor) {
   const State& s = state();
+  HEXL_SHIM_CHECK_BOUNDS(operand, s.degree * batch, s.q * input_mod_factor, "operand");
   if (hexl_amd_pointer_is_device(operand) && hexl_amd_pointer_is_device(result)) {
     check(hexl_amd_ntt_forward(s.plan, result, operand, batch, input_mod_factor,
                                output_mod_factor, nullptr));
@@ -162,6 +202,7 @@ void NTT::ComputeForwardBatch(uint64_t* result, const uint64_t* operand, uint64_
 void NTT::ComputeInverseBatch(uint64_t* result, const uint64_t* operand, uint64_t batch,
                               uint64_t input_mod_factor, uint64_t output_mod_factor) {
   const State& s = state();
+  HEXL_SHIM_CHECK_BOUNDS(operand, s.degree * batch, s.q * input_mod_factor, "operand");
   if (hexl_amd_pointer_is_device(operand) && hexl_amd_pointer_is_device(result)) {
     check(hexl_amd_ntt_inverse(s.plan, result, operand, batch, input_mod_factor,
                                output_mod_factor, nullptr));
@@ -179,6 +220,85 @@ void NTT::ComputeForward(uint64_t* result, const uint64_t* operand, uint64_t inp
 void NTT::ComputeInverse(uint64_t* result, const uint64_t* operand, uint64_t input_mod_factor,
                          uint64_t output_mod_factor) {
   ComputeInverseBatch(result, operand, 1, input_mod_factor, output_mod_factor);
+}
+
+// Extension: polynomials of several moduli in one call (hexl_amd_ntt_*_map / _indexed).
+const void* NTT::PlanHandle() const { return state().plan; }
+
+namespace {
+void compute_map(bool forward, const NTT* const* ntts, size_t num_ntts,
+                 const uint8_t* plan_of_slot, uint64_t period, uint64_t inner,
+                 const uint32_t* prime_index, uint64_t* result, const uint64_t* operand,
+                 uint64_t polys, uint64_t in_mf, uint64_t out_mf) {
+  if (!ntts || num_ntts == 0) throw std::invalid_argument("hexl: no NTT objects");
+  if (!prime_index && (!plan_of_slot || period == 0 || inner == 0))
+    throw std::invalid_argument("hexl: empty prime map");
+  std::vector<const hexl_amd_ntt*> plans(num_ntts);
+  for (size_t k = 0; k < num_ntts; ++k) {
+    if (!ntts[k]) throw std::invalid_argument("hexl: null NTT object");
+    plans[k] = static_cast<const hexl_amd_ntt*>(ntts[k]->PlanHandle());
+  }
+  const uint64_t n = ntts[0]->GetDegree();
+  auto which = [&](uint64_t i) -> uint64_t {
+    return prime_index ? prime_index[i] : plan_of_slot[(i / inner) % period];
+  };
+#ifdef HEXL_DEBUG
+  for (uint64_t i = 0; i < polys; ++i)
+    if (which(i) < num_ntts)
+      HEXL_SHIM_CHECK_BOUNDS(operand + i * n, n, ntts[which(i)]->GetModulus() * in_mf, "operand");
+#endif
+  if (hexl_amd_pointer_is_device(operand) && hexl_amd_pointer_is_device(result)) {
+    if (prime_index)
+      check((forward ? hexl_amd_ntt_forward_indexed : hexl_amd_ntt_inverse_indexed)(
+          plans.data(), num_ntts, prime_index, result, operand, polys, in_mf, out_mf, nullptr));
+    else
+      check((forward ? hexl_amd_ntt_forward_map : hexl_amd_ntt_inverse_map)(
+          plans.data(), num_ntts, plan_of_slot, period, inner, result, operand, polys, in_mf,
+          out_mf, nullptr));
+    return;
+  }
+  // host memory: run by run through the staged single-modulus path
+  for (uint64_t start = 0; start < polys;) {
+    const uint64_t k = which(start);
+    if (k >= num_ntts) throw std::invalid_argument("hexl: prime index out of range");
+    uint64_t end = start + 1;
+    while (end < polys && which(end) == k) ++end;
+    check((forward ? hexl_amd_ntt_forward_host : hexl_amd_ntt_inverse_host)(
+        plans[k], result + start * n, operand + start * n, end - start, in_mf, out_mf));
+    start = end;
+  }
+}
+}  // namespace
+
+void NTT::ComputeForwardMap(const NTT* const* ntts, size_t num_ntts, const uint8_t* plan_of_slot,
+                            uint64_t period, uint64_t inner, uint64_t* result,
+                            const uint64_t* operand, uint64_t polys, uint64_t input_mod_factor,
+                            uint64_t output_mod_factor) {
+  compute_map(true, ntts, num_ntts, plan_of_slot, period, inner, nullptr, result, operand, polys,
+              input_mod_factor, output_mod_factor);
+}
+void NTT::ComputeInverseMap(const NTT* const* ntts, size_t num_ntts, const uint8_t* plan_of_slot,
+                            uint64_t period, uint64_t inner, uint64_t* result,
+                            const uint64_t* operand, uint64_t polys, uint64_t input_mod_factor,
+                            uint64_t output_mod_factor) {
+  compute_map(false, ntts, num_ntts, plan_of_slot, period, inner, nullptr, result, operand, polys,
+              input_mod_factor, output_mod_factor);
+}
+void NTT::ComputeForwardIndexed(const NTT* const* ntts, size_t num_ntts,
+                                const uint32_t* prime_index, uint64_t* result,
+                                const uint64_t* operand, uint64_t polys,
+                                uint64_t input_mod_factor, uint64_t output_mod_factor) {
+  if (!prime_index) throw std::invalid_argument("hexl: prime_index == nullptr");
+  compute_map(true, ntts, num_ntts, nullptr, 0, 0, prime_index, result, operand, polys,
+              input_mod_factor, output_mod_factor);
+}
+void NTT::ComputeInverseIndexed(const NTT* const* ntts, size_t num_ntts,
+                                const uint32_t* prime_index, uint64_t* result,
+                                const uint64_t* operand, uint64_t polys,
+                                uint64_t input_mod_factor, uint64_t output_mod_factor) {
+  if (!prime_index) throw std::invalid_argument("hexl: prime_index == nullptr");
+  compute_map(false, ntts, num_ntts, nullptr, 0, 0, prime_index, result, operand, polys,
+              input_mod_factor, output_mod_factor);
 }
 
 uint64_t NTT::GetMinimalRootOfUnity() const { return state().w; }
@@ -209,6 +329,8 @@ bool on_device(const void* a, const void* b, const void* c) {
 
 void EltwiseAddMod(uint64_t* result, const uint64_t* operand1, const uint64_t* operand2,
                    uint64_t n, uint64_t modulus) {
+  HEXL_SHIM_CHECK_BOUNDS(operand1, n, modulus, "operand1");
+  HEXL_SHIM_CHECK_BOUNDS(operand2, n, modulus, "operand2");
   if (on_device(result, operand1, operand2))
     check(hexl_amd_eltwise_add_mod(result, operand1, operand2, n, modulus, nullptr));
   else
@@ -217,6 +339,7 @@ void EltwiseAddMod(uint64_t* result, const uint64_t* operand1, const uint64_t* o
 
 void EltwiseAddMod(uint64_t* result, const uint64_t* operand1, uint64_t operand2, uint64_t n,
                    uint64_t modulus) {
+  HEXL_SHIM_CHECK_BOUNDS(operand1, n, modulus, "operand1");
   if (on_device(result, operand1, nullptr))
     check(hexl_amd_eltwise_add_mod_scalar(result, operand1, operand2, n, modulus, nullptr));
   else
@@ -225,6 +348,8 @@ void EltwiseAddMod(uint64_t* result, const uint64_t* operand1, uint64_t operand2
 
 void EltwiseSubMod(uint64_t* result, const uint64_t* operand1, const uint64_t* operand2,
                    uint64_t n, uint64_t modulus) {
+  HEXL_SHIM_CHECK_BOUNDS(operand1, n, modulus, "operand1");
+  HEXL_SHIM_CHECK_BOUNDS(operand2, n, modulus, "operand2");
   if (on_device(result, operand1, operand2))
     check(hexl_amd_eltwise_sub_mod(result, operand1, operand2, n, modulus, nullptr));
   else
@@ -233,6 +358,7 @@ void EltwiseSubMod(uint64_t* result, const uint64_t* operand1, const uint64_t* o
 
 void EltwiseSubMod(uint64_t* result, const uint64_t* operand1, uint64_t operand2, uint64_t n,
                    uint64_t modulus) {
+  HEXL_SHIM_CHECK_BOUNDS(operand1, n, modulus, "operand1");
   if (on_device(result, operand1, nullptr))
     check(hexl_amd_eltwise_sub_mod_scalar(result, operand1, operand2, n, modulus, nullptr));
   else
@@ -241,6 +367,8 @@ void EltwiseSubMod(uint64_t* result, const uint64_t* operand1, uint64_t operand2
 
 void EltwiseMultMod(uint64_t* result, const uint64_t* operand1, const uint64_t* operand2,
                     uint64_t n, uint64_t modulus, uint64_t input_mod_factor) {
+  HEXL_SHIM_CHECK_BOUNDS(operand1, n, input_mod_factor * modulus, "operand1");
+  HEXL_SHIM_CHECK_BOUNDS(operand2, n, input_mod_factor * modulus, "operand2");
   if (on_device(result, operand1, operand2))
     check(hexl_amd_eltwise_mult_mod(result, operand1, operand2, n, modulus, input_mod_factor,
                                     nullptr));
@@ -251,6 +379,8 @@ void EltwiseMultMod(uint64_t* result, const uint64_t* operand1, const uint64_t* 
 
 void EltwiseFMAMod(uint64_t* result, const uint64_t* arg1, uint64_t arg2, const uint64_t* arg3,
                    uint64_t n, uint64_t modulus, uint64_t input_mod_factor) {
+  HEXL_SHIM_CHECK_BOUNDS(arg1, n, input_mod_factor * modulus, "arg1");
+  HEXL_SHIM_CHECK_BOUNDS(arg3, n, input_mod_factor * modulus, "arg3");
   if (on_device(result, arg1, arg3))
     check(hexl_amd_eltwise_fma_mod(result, arg1, arg2, arg3, n, modulus, input_mod_factor,
                                    nullptr));
@@ -260,6 +390,8 @@ void EltwiseFMAMod(uint64_t* result, const uint64_t* arg1, uint64_t arg2, const 
 
 void EltwiseReduceMod(uint64_t* result, const uint64_t* operand, uint64_t n, uint64_t modulus,
                       uint64_t input_mod_factor, uint64_t output_mod_factor) {
+  if (input_mod_factor != modulus)  // (input_mod_factor == modulus: any 64-bit input is legal)
+    HEXL_SHIM_CHECK_BOUNDS(operand, n, input_mod_factor * modulus, "operand");
   if (on_device(result, operand, nullptr))
     check(hexl_amd_eltwise_reduce_mod(result, operand, n, modulus, input_mod_factor,
                                       output_mod_factor, nullptr));

@@ -131,6 +131,11 @@ hipError_t ntt_forward_launch(const NttTables& t, u64* result, const u64* operan
 hipError_t ntt_inverse_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
                               u64 out_mf, hipStream_t st);
 
+// Whether a transform of `batch` polynomials under plan `t` is ONE kernel launch (degrees up
+// to 2^12, 2^13, and 2^14 from 192 polynomials): what the zero-copy host path can run straight
+// on caller memory.
+bool ntt_is_single_kernel(const NttTables& t, u64 batch);
+
 // Tuning / diagnostic knobs of the NTT launch logic (ntt_kernels.hip); 0 on success.
 int set_tuning(const char* key, u64 value);
 
@@ -212,6 +217,10 @@ hipError_t ks_round_launch(u64* tbuf, const u64* prod, const KsDims& d, const Ks
                            hipStream_t st);
 hipError_t ks_finish_launch(u64* result, const u64* prod, const u64* tbuf, const KsDims& d,
                             const KsFinish& f, hipStream_t st);
+
+// *violations += number of words of data[0, n) that are >= bound (debug contract)
+hipError_t count_out_of_bounds_launch(const u64* data, u64 n, u64 bound,
+                                      unsigned long long* violations, hipStream_t st);
 
 hipError_t fill_splitmix_launch(u64* data, u64 n, u64 batch, u64 seed0, u64 bound,
                                 hipStream_t st);

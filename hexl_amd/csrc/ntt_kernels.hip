@@ -1135,309 +1135,15 @@ tile_pass_multi(u64* out, const u64* in, MultiCtx mc, u32 log_n, u32 flags, u64 
       lds, out, in, FWD ? mc.tw_fwd[k] : mc.tw_inv[k], m, log_n, flags, total, il, blockIdx.x);
 }
 
-// ---------------------------------------------------------------------------
-// mixed_pass: workgroups of BOTH passes in one launch (N = 2^16, 4 + 12 stages)
-// ---------------------------------------------------------------------------
-// The strided pass is HBM-bound with most VALU slots idle, the tile pass VALU-bound
-// with HBM a quarter idle, and run one after the other they add up.  Two launches on
-// two streams do overlap but in whatever proportion the dispatcher happens to produce
-// (measured twice: no gain).  Here the proportion is fixed by construction: the batch
-// is cut into chunks, launch i holds the strided-pass workgroups of chunk i AND the
-// tile-pass workgroups of chunk i-1 (forward; the inverse has the roles swapped),
-// interleaved S,T,T along each XCD's block sequence, so every CU hosts both kinds all
-// the time.  No dependency inside a launch (different chunks; stream order separates
-// the two passes of a chunk), hence no control words and no spinning -- unlike
-// fused_pass.  Both bodies must live under ONE register allocation: the 4-stage strided
-// body (50 VGPRs) and the 12-stage tile body fit the 64-VGPR / 8-waves-per-SIMD budget,
-// which is why the split is 4 + 12 here and not the 5 + 11 of the two-launch plan.
-struct MixedSide {
-  u64* out;
-  const u64* in;
-  u32 flags;
-  u32 per_xcd;  // workgroups of this role per XCD (blocks / 8)
-};
-
-template <bool FWD, class A>
-__global__ void __launch_bounds__(512, 8)
-mixed_pass(MixedSide sd, MixedSide td, const ulonglong2* __restrict__ tw, ModConst m, u32 log_n,
-           u64 t_total, InvLast il) {
-  __shared__ u64 lds[1 << 12];
-  const u32 b = blockIdx.x, xcd = b & 7, j = b >> 3;
-  const u32 g = sd.per_xcd < (td.per_xcd >> 1) ? sd.per_xcd : (td.per_xcd >> 1);  // whole S,T,T groups
-  bool is_s;
-  u32 idx;
-  if (j < 3 * g) {
-    const u32 grp = j / 3, pos = j - 3 * grp;
-    is_s = pos == 0;
-    idx = is_s ? grp : 2 * grp + pos - 1;
-  } else {  // what is left of the longer role
-    const u32 r = j - 3 * g, s_left = sd.per_xcd - g;
-    is_s = r < s_left;
-    idx = is_s ? g + r : 2 * g + (r - s_left);
-  }
-  if (is_s) {
-    // XCD-contiguous order as in strided_pass; a 512-thread workgroup is two of its
-    // 256-thread work items (strided_body derives the wave index from bid and threadIdx)
-    const u32 bid = xcd * sd.per_xcd + idx;
-    strided_body<FWD, 4, A, !FWD, kStream, kStream>(sd.out, sd.in, tw, m, log_n, 0, sd.flags,
-                                                    bid * 2, il);
-  } else {
-    tile_body<FWD, 12, 0, 12, false, A, false, FWD ? kStream : kPlain, FWD ? kStream : kPlain>(
-        lds, td.out, td.in, tw, m, log_n, td.flags, t_total, il, idx * 8 + xcd);
-  }
-}
-
-// (Round-1 experiment, removed: `tile_stream`, a persistent variant of the bottom pass
-// with two LDS tile buffers per workgroup, the next tile prefetched by
-// `global_load ... lds` DMA (no VGPRs, permutation applied on the global side) and the
-// wait for it placed in front of the stores.  Bit-exact, but 1.17-1.21 ms against
-// 1.07 ms: two buffers cap occupancy at 5 waves/SIMD, and what a wave no longer waits
-// for HBM it waits for the VALU and the extra barrier instead.  A second persistent
-// variant prefetching the next tile into 16 spare VGPRs (6 waves/SIMD) measured
-// 1.25 ms against 1.04 ms.  See DESIGN.md.)
-
-// ---------------------------------------------------------------------------
-// fused_pass: both passes of a transform in ONE launch -- one HBM round trip
-// ---------------------------------------------------------------------------
-// Two launches move every polynomial through HBM twice (the whole transform then
-// sits at ~80 % of the achievable HBM rate with neither pass able to go faster).
-// fused_pass runs the strided pass and the tile pass of a polynomial inside one
-// persistent launch, a few microseconds apart and on CUs of the SAME XCD, so that
-// the intermediate polynomial is written to and read back from that XCD's 4 MiB L2
-// instead of HBM: the second phase's loads hit in L2, and its in-place stores
-// overwrite the still-dirty lines, so only the final values are ever evicted.
-//
-// Scheduling.  Workgroups are persistent and pull tickets.  A polynomial is a "slot"
-// of the XCD that first touches it; a slot has n1 phase-1 tasks (forward: strided
-// chunks of 256 columns; inverse: tiles) and n2 phase-2 tasks (forward: tiles;
-// inverse: strided chunks).  Phase 2 of a slot may start once all n1 phase-1 tasks
-// have signalled (all-to-all dependency: every tile needs every column chunk).
-//   * A workgroup identifies its XCD with s_getreg(HW_REG_XCC_ID) and only ever
-//     touches that XCD's ticket counter and slots, so both phases of a polynomial
-//     are executed by CUs that share one L2 -- by construction, not by assuming a
-//     dispatch order.  Polynomials are handed to XCDs on demand from one
-//     device-wide counter (dynamic balance; any placement of workgroups works).
-//   * Each XCD has ONE ticket counter over a software-pipelined task list: step s
-//     of the list is the n1 phase-1 tasks of slot s followed by the n2 phase-2 tasks
-//     of slot s - D (D = `window`).  A claim is a single atomic add; a phase-2
-//     ticket whose slot is not ready yet waits for it (and then starts the moment it
-//     is: the intermediate's residence time in L2 is a few microseconds, ~1-2 MiB
-//     per XCD).  (A first version with per-slot claim counters and a scan for ready
-//     slots was bit-exact but 3x slower than two launches: ~10 control accesses per
-//     claim on three hot words per XCD serialised the whole chip.)
-//   * No deadlock for any grid size or residency: a waiting ticket only ever waits
-//     for phase-1 tasks with SMALLER ticket numbers, which are held by workgroups
-//     that are already running and never wait themselves.  All spins are bounded;
-//     on timeout the kernel traps (a loud HIP error instead of a hang).
-// Hand-off inside the XCD: the producer's plain stores are complete in L2 when
-// `s_waitcnt vmcnt(0)` returns (the vector L1 is write-through); it then bumps the
-// slot's counter.  The consumer observes the counter, and reads the data with
-// agent-scope loads (`sc1`: L2-served, never the CU's possibly stale L1).  No
-// L2 write-back (`buffer_wbl2`) is needed -- or wanted: it is exactly the HBM
-// traffic this kernel exists to avoid -- because producer and consumer share the
-// L2.  If a line is evicted early it is simply read back from HBM: still correct.
-// The control words of an XCD are only touched by that XCD's workgroups; only the
-// polynomial counter is shared by the whole device.
-constexpr u32 kFusedMaxXcd = 16;       // HW_REG_XCC_ID is a 4-bit field
-constexpr u32 kFusedEnd = 0xFFFFFFu;   // polynomial field of a slot past the batch
-constexpr u32 kFusedSpinLimit = 1u << 24;
-#ifndef HEXL_AMD_FUSED_TT
-#define HEXL_AMD_FUSED_TT 2
+#ifdef HEXL_AMD_EXPERIMENTS
+// The plans that were built, verified bit-exact, measured and NOT adopted (mixed_pass,
+// fused_pass, the two-tile-pass "tiled" plan): compiled only with -DHEXL_AMD_EXPERIMENTS
+// (tools/build_variant.sh exp -DHEXL_AMD_EXPERIMENTS); the default build holds what make_plan
+// can select.
+#define HX_EXP_SECTION 1
+#include "ntt_experiments.inc"
+#undef HX_EXP_SECTION
 #endif
-constexpr u32 kFusedTT = HEXL_AMD_FUSED_TT;  // tiles per tile ticket
-
-// Developer diagnostic (tools/fused_stats.py, -DHEXL_AMD_FUSED_STATS builds only):
-// per-workgroup cycle totals of the scheduler and the two task bodies.
-#ifdef HEXL_AMD_FUSED_STATS
-__device__ unsigned long long* g_fused_stats = nullptr;  // [workgroup][8]
-extern "C" int hexl_amd_debug_set_fused_stats(void* buf) {
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fused_stats), &buf, sizeof(buf));
-}
-#define HX_FS_NOW() __builtin_readcyclecounter()
-#define HX_FS(...) __VA_ARGS__
-#else
-#define HX_FS_NOW() 0ull
-#define HX_FS(...)
-#endif
-
-// A slot is one word: (polynomial index + 1, or kFusedEnd) << 8 | phase-1 tasks
-// finished.  Zero = not assigned yet.  One load tells a phase-2 ticket both which
-// polynomial it works on and whether it may start.
-typedef u32 FusedSlot;
-struct FusedXcd {  // one 128-byte line
-  u32 ticket;
-  u32 pad[31];
-};
-struct FusedCtl {
-  u32 next_poly;  // device-wide
-  u32 pad[31];
-  FusedXcd xcd[kFusedMaxXcd];
-  // followed by FusedSlot[kFusedMaxXcd][cap]
-};
-
-// Control accesses.  Reads are agent-scope loads (`sc1`): never served by the vector
-// L1.  (A workgroup-scope fetch_add(p, 0) is folded into an `sc0` load by the
-// compiler, which the L1 may serve with a stale line: seen as a memory fault.)
-__device__ __forceinline__ u32 xcd_add(u32* p, u32 v) {
-  return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ u32 xcd_read(u32* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void fused_backoff(u32& spins) {
-  __builtin_amdgcn_s_sleep(8);
-  if (++spins > kFusedSpinLimit) __builtin_trap();
-}
-
-struct FusedTask {
-  u32 kind;  // 0 = no more work, 1 = phase 1, 2 = phase 2
-  u32 poly;
-  u32 idx;   // task index within the polynomial's phase
-  u32 slot;
-};
-
-// The slot's word, waiting for the assignment if it is still under way.
-__device__ __forceinline__ u32 fused_slot_word(FusedSlot* slots, u32 slot) {
-  u32 w, sp = 0;
-  while (((w = xcd_read(&slots[slot])) >> 8) == 0) fused_backoff(sp);
-  return w;
-}
-// Hands the next polynomial of the batch (or the end marker) to `slot`.
-__device__ __forceinline__ void fused_assign(FusedCtl* ctl, FusedSlot* slots, u32 slot, u32 batch) {
-  const u32 p = xcd_add(&ctl->next_poly, 1);
-  xcd_add(&slots[slot], (p < batch ? p + 1 : kFusedEnd) << 8);  // was 0
-}
-
-// One lane's scheduler step: ticket k -> the task it stands for (tickets that stand
-// for nothing -- pipeline fill, slots past the batch -- are replaced by fresh ones).
-__device__ __forceinline__ FusedTask fused_resolve(u32 k, FusedCtl* ctl, FusedXcd* X,
-                                                   FusedSlot* slots, u32 n1, u32 n2, u32 batch,
-                                                   u32 cap, u32 window,
-                                                   unsigned long long& dep_wait) {
-  for (;; k = xcd_add(&X->ticket, 1)) {
-    const u32 step = k / (n1 + n2), r = k - step * (n1 + n2);
-    if (r < n1) {  // phase 1 of slot `step`
-      if (step + 1 >= cap) return FusedTask{0, 0, 0, 0};  // cannot happen with the host's cap
-      if (r == 0) {
-        // This ticket also assigns polynomials, one slot ahead and in slot order
-        // (slot `step` was assigned by the previous step's ticket), so that the
-        // slots past the batch form a suffix.
-        if (step == 0) fused_assign(ctl, slots, 0, batch);
-        (void)fused_slot_word(slots, step);
-        fused_assign(ctl, slots, step + 1, batch);
-      }
-      const u32 poly1 = fused_slot_word(slots, step) >> 8;
-      if (poly1 == kFusedEnd) continue;  // phase-2 tickets of earlier slots still follow
-      return FusedTask{1, poly1 - 1, r, step};
-    }
-    if (step < window) continue;  // pipeline fill
-    const u32 slot = step - window;
-    u32 w = fused_slot_word(slots, slot);
-    // past the batch: so is every slot any later ticket refers to
-    if ((w >> 8) == kFusedEnd) return FusedTask{0, 0, 0, 0};
-    u32 sp = 0;
-    HX_FS(const unsigned long long w0 = HX_FS_NOW());
-    while ((w & 255) != n1) {
-      fused_backoff(sp);
-      w = xcd_read(&slots[slot]);
-    }
-    HX_FS(dep_wait += HX_FS_NOW() - w0);
-    return FusedTask{2, (w >> 8) - 1, r - n1, slot};
-  }
-}
-
-// Workgroups per CU the register budget is set for: the 5-stage strided subtree
-// (32 elements per thread) spills under the 96-VGPR cap of 5, so it gets 4.
-template <int R>
-constexpr int fused_waves() { return R >= 5 ? 4 : 5; }
-
-// R strided stages + S tile stages (N = 2^(R+S), tile = 2^S elements, S = 11).
-template <bool FWD, int R, int S, class A>
-__global__ void __launch_bounds__(256, (fused_waves<R>()))
-fused_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst m, u32 finish,
-           u32 batch, InvLast il, FusedCtl* ctl, u32 cap, u32 window) {
-  constexpr u32 log_n = R + S;
-  constexpr u32 kStridedTasks = 1u << (S - 8);  // 256 columns each
-  constexpr u32 kTT = kFusedTT <= (1u << R) ? kFusedTT : (1u << R);
-  constexpr u32 kTileTasks = (1u << R) / kTT;   // kTT tiles each
-  constexpr u32 n1 = FWD ? kStridedTasks : kTileTasks;
-  constexpr u32 n2 = FWD ? kTileTasks : kStridedTasks;
-  static_assert(n1 < 256, "the slot word counts phase-1 tasks in 8 bits");
-  __shared__ u64 lds[1 << S];
-  __shared__ u32 task_sh[2][4];
-  const u32 tid = threadIdx.x;
-  // HW_REG_XCC_ID (hwreg 20), bits [3:0]: the XCD this workgroup runs on
-  const u32 xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) & (kFusedMaxXcd - 1);
-  FusedXcd* X = &ctl->xcd[xcc];
-  FusedSlot* slots = reinterpret_cast<FusedSlot*>(ctl + 1) + (size_t)xcc * cap;
-  const u64 total = (u64)batch << log_n;
-  unsigned long long fs_dep = 0;
-  HX_FS(unsigned long long fs_claim = 0; unsigned long long fs_body[2] = {0, 0};
-        unsigned long long fs_n[2] = {0, 0}; const unsigned long long fs_t0 = HX_FS_NOW());
-
-  // (Drawing the ticket of the NEXT task before the current body runs -- to hide the
-  // atomic's latency behind it -- was measured slower, 5.2 vs 4.2 ms per step: the
-  // atomic's return sits in front of the body's own loads in the in-order vmcnt
-  // queue.)
-  for (u32 it = 0;; ++it) {
-    u32* ts = task_sh[it & 1];
-    HX_FS(const unsigned long long c0 = HX_FS_NOW());
-    if (tid == 0) {
-      const FusedTask t = fused_resolve(xcd_add(&X->ticket, 1), ctl, X, slots, n1, n2, batch, cap,
-                                        window, fs_dep);
-      ts[0] = t.kind;
-      ts[1] = t.poly;
-      ts[2] = t.idx;
-      ts[3] = t.slot;
-    }
-    // publishes the task; also separates the LDS use of consecutive tasks
-    __syncthreads();
-    const u32 kind = __builtin_amdgcn_readfirstlane(ts[0]);
-    const u32 poly = __builtin_amdgcn_readfirstlane(ts[1]);
-    const u32 idx = __builtin_amdgcn_readfirstlane(ts[2]);
-    HX_FS(const unsigned long long c1 = HX_FS_NOW(); fs_claim += c1 - c0);
-    if (kind == 0) break;
-    if ((kind == 1) == FWD) {
-      // strided stages.  Forward: the first R stages, HBM (streamed) -> L2 (plain
-      // stores stay there).  Inverse: the root R stages with N^-1 folded in,
-      // L2 -> HBM (streamed).
-      if (FWD)
-        strided_body<true, R, A, false, kStream, kPlain>(out, in, tw, m, log_n, 0, kFirstPass,
-                                                        poly * kStridedTasks + idx, il);
-      else
-        strided_body<false, R, A, true, kL2, kStream>(out, out, tw, m, log_n, 0, finish,
-                                                     poly * kStridedTasks + idx, il);
-    } else {
-      // tile stages.  Forward: the last S stages, L2 -> HBM (streamed).  Inverse: the
-      // deepest S stages, HBM -> L2.
-#pragma unroll 1
-      for (u32 tt = 0; tt < kTT; ++tt) {
-        const u32 tile = (poly << R) + idx * kTT + tt;
-        if (tt) __syncthreads();  // the previous tile's LDS reads are done
-        if (FWD)
-          tile_body<true, S, 0, S, false, A, false, kL2, kStream>(lds, out, out, tw, m, log_n,
-                                                                 finish, total, il, tile);
-        else
-          tile_body<false, S, 0, S, false, A, false, kPlain, kPlain>(lds, out, in, tw, m, log_n,
-                                                                    kFirstPass, total, il, tile);
-      }
-    }
-    if (kind == 1) {
-      // all of this task's stores are in L2 before the slot's counter moves
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) xcd_add(&slots[__builtin_amdgcn_readfirstlane(ts[3])], 1);
-    }
-    HX_FS(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); fs_body[kind - 1] += HX_FS_NOW() - c1;
-          fs_n[kind - 1] += 1);
-  }
-  HX_FS(if (tid == 0 && g_fused_stats) {
-    unsigned long long* o = g_fused_stats + (size_t)blockIdx.x * 8;
-    o[0] = fs_n[0]; o[1] = fs_n[1]; o[2] = fs_claim; o[3] = fs_dep; o[4] = fs_body[0];
-    o[5] = fs_body[1]; o[6] = HX_FS_NOW() - fs_t0; o[7] = xcc;
-  });
-  (void)fs_dep;
-}
 
 // ---------------------------------------------------------------------------
 // Host-side planning and launch
@@ -1572,40 +1278,6 @@ static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2
   return hipGetLastError();
 }
 
-// Top pass: the first S stages (heap levels 0..S-1) on tiles of 2^S rows x
-// 2^(TL-S) columns, N >= 2^TL.
-template <bool FWD, int TL, class A>
-static hipError_t launch_top(int S, u64* out, const u64* in, const ulonglong2* tw,
-                             const ModConst& m, u32 log_n, u32 finish, u64 batch,
-                             const InvLast& il, hipStream_t st) {
-  const u64 total = batch << log_n;
-  const unsigned grid = (unsigned)(total >> TL);
-  ScopedKernelTimer timer(FWD ? "ntt_fwd_tile_pass_top" : "ntt_inv_tile_pass_top", st);
-#define HX_LAUNCH_T(T)                                                                      \
-  case T:                                                                                   \
-    if constexpr (T <= TL - 4 && (TL == 10 || T >= 7))                                      \
-      hipLaunchKernelGGL((tile_pass<FWD, T, TL - T, TL, false, A, !FWD>), dim3(grid),       \
-                         dim3(1 << (TL - re_of(T))), 0, st, out, in, tw, m, log_n, finish, total, \
-                         il);                                                               \
-    else                                                                                    \
-      return hipErrorInvalidValue;                                                          \
-    break;
-  switch (S) {
-    HX_LAUNCH_T(1)
-    HX_LAUNCH_T(2)
-    HX_LAUNCH_T(3)
-    HX_LAUNCH_T(4)
-    HX_LAUNCH_T(5)
-    HX_LAUNCH_T(6)
-    HX_LAUNCH_T(7)
-    HX_LAUNCH_T(8)
-    default:
-      return hipErrorInvalidValue;
-  }
-#undef HX_LAUNCH_T
-  return hipGetLastError();
-}
-
 // Plan of one transform: an optional top tile_pass of `top_tile` stages (or
 // `n_strided` register-only passes), then a bottom tile_pass of `bottom` stages;
 // `tl` = log2 of the tile size both tile passes use.
@@ -1618,11 +1290,12 @@ struct Plan {
 };
 
 // Default for N >= 2^13: register-only strided pass(es) + an 11- or 12-stage
-// bottom tile_pass, two launches (kPlanSplit).  HEXL_AMD_PLAN=fused runs the two as
-// ONE persistent launch for N = 2^15, 2^16 (fused_pass; bit-exact, measured 10 %
-// slower than two launches, see its header and DESIGN.md); HEXL_AMD_PLAN=tiled
-// selects two LDS-tiled kernels (6 + 10 stages on 1024-element tiles for N = 2^16;
-// 4 % slower).
+// bottom tile_pass, two launches (kPlanSplit).  Builds with -DHEXL_AMD_EXPERIMENTS also hold
+// the plans that were measured and not adopted (ntt_experiments.inc): HEXL_AMD_PLAN=fused
+// runs the two passes as ONE persistent launch for N = 2^15, 2^16 (fused_pass; bit-exact,
+// 10 % slower than two launches), HEXL_AMD_PLAN=tiled selects two LDS-tiled
+// kernels (6 + 10 stages on 1024-element tiles for N = 2^16; 4 % slower), HEXL_AMD_PLAN=mixed
+// the chunk pipeline of mixed launches (as fast as two launches).
 enum PlanMode { kPlanFused = 0, kPlanSplit = 1, kPlanTiled = 2, kPlanMixed = 3 };
 static u32 env_u32(const char* name, u32 dflt) {
   const char* e = getenv(name);
@@ -1635,11 +1308,15 @@ static u32 env_u32(const char* name, u32 dflt) {
 struct Tuning {
   std::atomic<u32> plan, fused_window, fused_min_batch, fused_wg_per_cu, fp64, tile13, mixed_chunk, h60;
   Tuning() {
+#ifdef HEXL_AMD_EXPERIMENTS
     const char* e = getenv("HEXL_AMD_PLAN");
     plan = (e && strcmp(e, "tiled") == 0)   ? kPlanTiled
            : (e && strcmp(e, "fused") == 0) ? kPlanFused
            : (e && strcmp(e, "mixed") == 0) ? kPlanMixed
                                             : kPlanSplit;
+#else
+    plan = kPlanSplit;
+#endif
     mixed_chunk = env_u32("HEXL_AMD_MIXED_CHUNK", 512);
     // Slots (polynomials) an XCD may have in flight between the first phase-1 claim
     // and the last phase-2 claim; the smallest batch the fused launch is used for;
@@ -1663,11 +1340,17 @@ Tuning& tuning() {
 }
 int set_tuning(const char* key, u64 value) {
   Tuning& t = tuning();
+#ifdef HEXL_AMD_EXPERIMENTS
+  if (strcmp(key, "experiments") == 0 && value == 1) return 0;  // "is this an experiments build?"
   if (strcmp(key, "plan") == 0 && value <= kPlanMixed) t.plan = (u32)value;
   else if (strcmp(key, "mixed_chunk") == 0 && value >= 1 && value < (1u << 20)) t.mixed_chunk = (u32)value;
   else if (strcmp(key, "fused_window") == 0 && value < (1u << 16)) t.fused_window = (u32)value;
   else if (strcmp(key, "fused_min_batch") == 0 && value >= 1) t.fused_min_batch = (u32)value;
   else if (strcmp(key, "fused_wg_per_cu") == 0) t.fused_wg_per_cu = (u32)value;
+#else
+  // (the default build holds the split plan only; the other plan keys are refused)
+  if (strcmp(key, "plan") == 0 && value == kPlanSplit) t.plan = (u32)value;
+#endif
   else if (strcmp(key, "fp64") == 0 && value <= 2) t.fp64 = (u32)value;
   else if (strcmp(key, "tile13") == 0 && value <= 2) t.tile13 = (u32)value;
   else if (strcmp(key, "h60") == 0 && value <= 1) t.h60 = (u32)value;
@@ -1675,10 +1358,12 @@ int set_tuning(const char* key, u64 value) {
   return 0;
 }
 #endif  // HX_TU_DISPATCH
+#ifdef HEXL_AMD_EXPERIMENTS
 static PlanMode plan_mode() { return (PlanMode)tuning().plan.load(); }
 static bool plan_strided_requested() { return plan_mode() != kPlanTiled; }
 static u32 fused_window() { return tuning().fused_window.load(); }
 static u64 fused_min_batch() { return tuning().fused_min_batch.load(); }
+#endif
 
 static Plan make_plan(int L, bool allow_tile13 = true, u64 batch = ~0ull) {
   Plan p{};
@@ -1702,17 +1387,22 @@ static Plan make_plan(int L, bool allow_tile13 = true, u64 batch = ~0ull) {
     p.bottom = 13;
     return p;
   }
-  if (plan_strided_requested() && L >= 13) {
+#ifdef HEXL_AMD_EXPERIMENTS
+  if (plan_strided_requested())
+#endif
+  {
     // 11 bottom stages on 2048-element tiles up to N = 2^16 (strided pass of <= 5
     // stages: both kernels then carry a comparable share of the arithmetic), 12 on
-    // 4096-element tiles above.  HEXL_AMD_BOTTOM=11|12 overrides (A/B runs).
+    // 4096-element tiles above.  (Experiments builds: HEXL_AMD_BOTTOM=11|12 overrides.)
     p.bottom = L <= 16 ? 11 : 12;
+#ifdef HEXL_AMD_EXPERIMENTS
     static const int bottom_override = [] {
       const char* e = getenv("HEXL_AMD_BOTTOM");
       return e ? atoi(e) : 0;
     }();
     if ((bottom_override == 11 || bottom_override == 12) && L - bottom_override >= 1)
       p.bottom = bottom_override;
+#endif
     p.tl = p.bottom;
     int top = L - p.bottom;
     if (top <= 5) {
@@ -1724,6 +1414,7 @@ static Plan make_plan(int L, bool allow_tile13 = true, u64 batch = ~0ull) {
     }
     return p;
   }
+#ifdef HEXL_AMD_EXPERIMENTS  // the "tiled" plan: two LDS-tiled kernels
   if (L <= 16) {  // 1024-element tiles: top <= 6 stages, bottom <= 10
     p.tl = 10;
     const int half = (L + 1) / 2;
@@ -1736,14 +1427,7 @@ static Plan make_plan(int L, bool allow_tile13 = true, u64 batch = ~0ull) {
   p.top_tile = 8;
   p.bottom = L - 8;
   return p;
-}
-
-template <bool FWD, class A>
-static hipError_t launch_top_tl(int tl, int S, u64* out, const u64* in, const ulonglong2* tw,
-                                const ModConst& m, u32 log_n, u32 finish, u64 batch,
-                                const InvLast& il, hipStream_t st) {
-  if (tl == 10) return launch_top<FWD, 10, A>(S, out, in, tw, m, log_n, finish, batch, il, st);
-  return launch_top<FWD, 12, A>(S, out, in, tw, m, log_n, finish, batch, il, st);
+#endif
 }
 
 template <bool FWD, class A>
@@ -1762,72 +1446,11 @@ static hipError_t launch_bottom_tl(int tl, int S, u64* out, const u64* in, const
   return launch_bottom<FWD, 12, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc);
 }
 
-// Resident workgroups of a fused_pass instantiation on the current device
-// (blocks per CU by the occupancy query x CUs).  The scheduler needs no particular
-// grid size -- a workgroup that is not resident yet simply starts pulling tasks
-// later -- so the query's known off-by-one (MI355X_MICROARCH.md) is harmless.
-template <bool FWD, int R, class A>
-static hipError_t fused_grid(unsigned* grid) {
-  static std::mutex mu;
-  static int cached[64], cached_cus[64];  // per device; 0 = unknown
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return e;
-  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-  std::lock_guard<std::mutex> lock(mu);
-  if (!cached[dev]) {
-    int per_cu = 0, cus = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pass<FWD, R, 11, A>, 256, 0);
-    if (e != hipSuccess) return e;
-    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess) return e;
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > fused_waves<R>() + 1) per_cu = fused_waves<R>() + 1;
-    cached[dev] = per_cu;
-    cached_cus[dev] = cus > 0 ? cus : 1;
-  }
-  const u32 override_per_cu = tuning().fused_wg_per_cu.load();
-  *grid = (unsigned)((override_per_cu ? (int)override_per_cu : cached[dev]) * cached_cus[dev]);
-  return hipSuccess;
-}
-
-// The whole transform (R strided + 11 tile stages, N = 2^(R+11)) as one launch.
-template <bool FWD, int R, class A>
-static hipError_t launch_fused_r(const NttTables& t, u64* result, const u64* operand, u64 batch,
-                                 u32 fin, hipStream_t st) {
-  unsigned grid = 0;
-  hipError_t e = fused_grid<FWD, R, A>(&grid);
-  if (e != hipSuccess) return e;
-  // An XCD's ticket list reaches at most `batch` steps that hold a polynomial, the
-  // `window` steps that drain the pipeline, and one ticket per workgroup after that.
-  const u32 window = fused_window();
-  const u32 cap = (u32)batch + window + grid + 4;
-  const size_t bytes = sizeof(FusedCtl) + (size_t)kFusedMaxXcd * cap * sizeof(FusedSlot);
-  void* ws = nullptr;
-  StreamSequenceLock sequence(st);  // memset + launch of one call stay adjacent on the stream
-  e = stream_workspace(kWsFusedNtt, st, bytes, &ws);
-  if (e != hipSuccess) return e;
-  e = hipMemsetAsync(ws, 0, bytes, st);
-  if (e != hipSuccess) return e;
-  // no more workgroups than tasks of the larger phase
-  const u64 tasks = batch << 3;
-  if (tasks < grid) grid = (unsigned)tasks;
-  ScopedKernelTimer timer(FWD ? "ntt_fwd_fused_pass" : "ntt_inv_fused_pass", st);
-  hipLaunchKernelGGL((fused_pass<FWD, R, 11, A>), dim3(grid), dim3(256), 0, st, result, operand,
-                     FWD ? t.fwd : t.inv, t.mod, fin, (u32)batch, t.inv_last, (FusedCtl*)ws, cap,
-                     window);
-  return hipGetLastError();
-}
-
-template <bool FWD, class A>
-static hipError_t launch_fused(int R, const NttTables& t, u64* result, const u64* operand,
-                               u64 batch, u32 fin, hipStream_t st) {
-  switch (R) {
-    case 4: return launch_fused_r<FWD, 4, A>(t, result, operand, batch, fin, st);
-    case 5: return launch_fused_r<FWD, 5, A>(t, result, operand, batch, fin, st);
-    default: return hipErrorInvalidValue;
-  }
-}
+#ifdef HEXL_AMD_EXPERIMENTS
+#define HX_EXP_SECTION 2
+#include "ntt_experiments.inc"
+#undef HX_EXP_SECTION
+#endif
 
 // One transform of `batch` polynomials on stream `st`.
 template <class A>
@@ -1838,6 +1461,7 @@ static hipError_t forward_seq(const NttTables& t, const Plan& p, u64* result, co
   InvLast il{};
   hipError_t e;
   u32 first = kFirstPass;  // consumed by whichever pass runs first
+#ifdef HEXL_AMD_EXPERIMENTS
   if (p.top_tile) {
     if (mc) return hipErrorNotSupported;
     e = launch_top_tl<true, A>(p.tl, p.top_tile, result, src, t.fwd, t.mod,
@@ -1846,6 +1470,7 @@ static hipError_t forward_seq(const NttTables& t, const Plan& p, u64* result, co
     src = result;
     first = 0;
   }
+#endif
   u32 a0 = 0;
   for (int i = 0; i < p.n_strided; ++i) {
     e = launch_strided<true, A>(p.strided[i], result, src, t.fwd, t.mod, t.log_n, a0, first,
@@ -1878,52 +1503,11 @@ static hipError_t inverse_seq(const NttTables& t, const Plan& p, u64* result, co
                                  i == 0 ? fin : 0, batch, t.inv_last, st, mc);
     if (e != hipSuccess) return e;
   }
+#ifdef HEXL_AMD_EXPERIMENTS
   if (p.top_tile)
     return launch_top_tl<false, A>(p.tl, p.top_tile, result, result, t.inv,
                                    t.mod, t.log_n, fin, batch, t.inv_last, st);
-  return hipSuccess;
-}
-
-// N = 2^16 as a pipeline of mixed launches (see mixed_pass): chunk i's first pass shares
-// launch i with chunk i-1's second pass.
-template <bool FWD, class A>
-static hipError_t launch_mixed(const NttTables& t, u64* result, const u64* operand, u64 batch,
-                               u64 out_mf, hipStream_t st) {
-  const u64 chunk = tuning().mixed_chunk.load();
-  const u64 chunks = (batch + chunk - 1) / chunk;
-  const u32 fin = out_mf == 1 ? 2 : 1;
-  const u32 log_n = t.log_n;  // 16
-  const u64 n = 1ull << log_n;
-  ScopedKernelTimer timer(FWD ? "ntt_fwd_mixed_pass" : "ntt_inv_mixed_pass", st);
-  for (u64 i = 0; i <= chunks; ++i) {
-    // first-pass role: chunk i; second-pass role: chunk i - 1
-    const bool has1 = i < chunks, has2 = i >= 1;
-    const u64 off1 = i * chunk, off2 = (i - 1) * chunk;
-    const u64 polys1 = has1 ? (batch - off1 < chunk ? batch - off1 : chunk) : 0;
-    const u64 polys2 = has2 ? (batch - off2 < chunk ? batch - off2 : chunk) : 0;
-    // forward: pass 1 = strided (operand -> result), pass 2 = tile (in place on result);
-    // inverse: pass 1 = tile (operand -> result), pass 2 = strided (in place, root stage)
-    const u64 s_polys = FWD ? polys1 : polys2, t_polys = FWD ? polys2 : polys1;
-    const u64 s_off = (FWD ? off1 : off2) * n, t_off = (FWD ? off2 : off1) * n;
-    MixedSide sd{}, td{};
-    if (s_polys) {
-      sd.out = result + s_off;
-      sd.in = (FWD ? operand : result) + s_off;
-      sd.flags = FWD ? kFirstPass : fin;
-      sd.per_xcd = (u32)s_polys;  // N / 16 columns / 512 threads = 8 workgroups per polynomial
-    }
-    if (t_polys) {
-      td.out = result + t_off;
-      td.in = (FWD ? result : operand) + t_off;
-      td.flags = FWD ? fin : kFirstPass;
-      td.per_xcd = (u32)(t_polys * 2);  // 16 tiles per polynomial
-    }
-    const unsigned grid = (unsigned)((sd.per_xcd + td.per_xcd) * 8);
-    hipLaunchKernelGGL((mixed_pass<FWD, A>), dim3(grid), dim3(512), 0, st, sd, td,
-                       FWD ? t.fwd : t.inv, t.mod, log_n, t_polys << log_n, t.inv_last);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-  }
+#endif
   return hipSuccess;
 }
 
@@ -1936,6 +1520,7 @@ template <bool FWD, class A>
 static hipError_t transform_impl(const NttTables& t, u64* result, const u64* operand, u64 batch,
                                  u64 out_mf, hipStream_t st) {
   const Plan p = make_plan((int)t.log_n, true, batch);
+#ifdef HEXL_AMD_EXPERIMENTS
   if constexpr (!A::kH60) {  // (fused_pass is not instantiated for the Harvey60 policy)
     if (plan_mode() == kPlanFused && p.n_strided == 1 && p.bottom == 11 && !p.top_tile &&
         p.strided[0] >= 4 && batch >= fused_min_batch() && batch < (1ull << 23))
@@ -1946,6 +1531,7 @@ static hipError_t transform_impl(const NttTables& t, u64* result, const u64* ope
         batch < (1ull << 24))
       return launch_mixed<FWD, A>(t, result, operand, batch, out_mf, st);
   }
+#endif
   return FWD ? forward_seq<A>(t, p, result, operand, batch, out_mf, st)
              : inverse_seq<A>(t, p, result, operand, batch, out_mf, st);
 }
@@ -1955,7 +1541,9 @@ static hipError_t multi_impl(bool forward, const NttTables& t0, const MultiCtx& 
                              u64* result, const u64* operand, u64 out_mf, hipStream_t st) {
   // the multi-plan kernels: 11 / 12 bottom stages, or the whole of N = 8192 / 16384
   Plan p = make_plan((int)t0.log_n, /*allow_tile13=*/true, polys);
+#ifdef HEXL_AMD_EXPERIMENTS
   if (plan_mode() == kPlanTiled) return hipErrorNotSupported;
+#endif
   return forward ? forward_seq<A>(t0, p, result, operand, polys, out_mf, st, &mc)
                  : inverse_seq<A>(t0, p, result, operand, polys, out_mf, st, &mc);
 }
@@ -2026,9 +1614,35 @@ hipError_t ntt_inverse_launch(const NttTables& t, u64* result, const u64* operan
                               u64 out_mf, hipStream_t st) {
   return transform_dispatch(false, t, result, operand, batch, out_mf, st);
 }
+
+bool ntt_is_single_kernel(const NttTables& t, u64 batch) {
+  const Plan p = make_plan((int)t.log_n, true, batch);
+  return p.n_strided == 0 && p.top_tile == 0;
+}
 #endif  // HX_TU_DISPATCH
 
 #if HX_TU_DISPATCH
+// Whether the multi-plan kernels cover every pass of the plan make_plan picks for (log_n,
+// polys): checked BEFORE the first launch of a multi-plan sequence, so that "not supported"
+// always means "nothing enqueued" and the caller may fall back to plan-by-plan calls (a
+// sequence refused half way -- a later pass, or a later arithmetic policy of a mixed group --
+// would leave half-transformed data behind).  Mirrors the shape checks of launch_strided /
+// launch_bottom.
+static bool multi_plan_supported(u32 log_n, u64 polys) {
+#ifdef HEXL_AMD_EXPERIMENTS
+  if (plan_mode() == kPlanTiled) return false;
+#endif
+  const Plan p = make_plan((int)log_n, /*allow_tile13=*/true, polys);
+  if (p.top_tile) return false;
+  if (p.bottom < 11 || p.bottom > 14 || p.tl != p.bottom || log_n < (u32)p.tl) return false;
+  u32 a0 = 0;
+  for (int i = 0; i < p.n_strided; ++i) {
+    const int r = p.strided[i];
+    if (r < 1 || r > 5 || log_n < (u32)r + 8 || log_n < a0 + (u32)r + 6) return false;
+    a0 += (u32)r;
+  }
+  return a0 + (u32)p.bottom == log_n;
+}
 hipError_t ntt_multi_launch(bool forward, const NttTables* const* tabs, u32 num_plans,
                             const MultiMap& map, u64 polys, u64* result, const u64* operand,
                             u64 out_mf, hipStream_t st) {
@@ -2055,6 +1669,8 @@ hipError_t ntt_multi_launch(bool forward, const NttTables* const* tabs, u32 num_
   int policies = 0;
   for (int i = 0; i < kNumPolicies; ++i) policies += have[i] ? 1 : 0;
   mc.one_policy = policies == 1 ? 1u : 0u;
+  // nothing is enqueued unless every pass of every policy's sequence can be
+  if (!multi_plan_supported(t0.log_n, polys)) return hipErrorNotSupported;
   hipError_t e = hipSuccess;
   if (have[kPolicySmall] && e == hipSuccess)
     e = multi_entry_small(forward, t0, mc, polys, result, operand, out_mf, st);
@@ -2066,7 +1682,9 @@ hipError_t ntt_multi_launch(bool forward, const NttTables* const* tabs, u32 num_
     e = multi_entry_harvey60(forward, t0, mc, polys, result, operand, out_mf, st);
   if (have[kPolicyStrict] && e == hipSuccess)
     e = multi_entry_strict(forward, t0, mc, polys, result, operand, out_mf, st);
-  return e;
+  // past the check above a refusal can only come after launches were made: a hard error,
+  // never the "fall back" signal
+  return e == hipErrorNotSupported ? hipErrorLaunchFailure : e;
 }
 
 // The arithmetic policy a plan for modulus q is built for (its tables depend on it).

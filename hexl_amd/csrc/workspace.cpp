@@ -6,6 +6,7 @@
 #include <mutex>
 #include <tuple>
 #include <utility>
+#include <vector>
 
 namespace hexl_amd {
 namespace {
@@ -13,70 +14,116 @@ struct Entry {
   void* ptr = nullptr;
   size_t cap = 0;
 };
+// g_mu guards the two tables (lookup / insert / erase) and nothing else: no HIP call is made
+// under it, so one stream growing its scratch (hipFree waits for the device) does not stall
+// the enqueues of every other stream.
 std::mutex g_mu;
 std::map<std::tuple<int, hipStream_t, int>, Entry>& table() {
   static auto* t = new std::map<std::tuple<int, hipStream_t, int>, Entry>;  // never destroyed:
   return *t;  // HIP may already be torn down when static destructors run
 }
-std::map<std::pair<int, hipStream_t>, std::unique_ptr<std::mutex>>& sequence_table() {
-  static auto* t = new std::map<std::pair<int, hipStream_t>, std::unique_ptr<std::mutex>>;
+// The per-(device, stream) sequence locks.  Recursive: a composite that holds the lock of its
+// stream while it enqueues (KeySwitch) may call a transform that takes it again for its own
+// scratch (the one-launch fused transform).
+typedef std::recursive_mutex SeqMutex;
+std::map<std::pair<int, hipStream_t>, std::shared_ptr<SeqMutex>>& sequence_table() {
+  static auto* t = new std::map<std::pair<int, hipStream_t>, std::shared_ptr<SeqMutex>>;
   return *t;
+}
+std::shared_ptr<SeqMutex> sequence_mutex(int device, hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto& slot = sequence_table()[std::make_pair(device, stream)];
+  if (!slot) slot = std::make_shared<SeqMutex>();
+  return slot;
 }
 }  // namespace
 
-StreamSequenceLock::StreamSequenceLock(hipStream_t stream) : mu_(nullptr) {
+struct StreamSequenceLock::Held {
+  std::shared_ptr<SeqMutex> mu;  // keeps the mutex alive if its table entry is released meanwhile
+};
+
+StreamSequenceLock::StreamSequenceLock(hipStream_t stream) : held_(new Held) {
   int device = 0;
   (void)hipGetDevice(&device);
-  std::mutex* mu;
-  {
-    std::lock_guard<std::mutex> lock(g_mu);
-    auto& slot = sequence_table()[std::make_pair(device, stream)];
-    if (!slot) slot.reset(new std::mutex);
-    mu = slot.get();  // entries are never erased: the pointer stays valid
-  }
-  mu->lock();
-  mu_ = mu;
+  held_->mu = sequence_mutex(device, stream);
+  held_->mu->lock();
 }
 
-StreamSequenceLock::~StreamSequenceLock() { static_cast<std::mutex*>(mu_)->unlock(); }
+StreamSequenceLock::~StreamSequenceLock() {
+  held_->mu->unlock();
+  delete held_;
+}
 
 hipError_t stream_workspace(WorkspacePurpose purpose, hipStream_t stream, size_t bytes,
                             void** out) {
   int device = 0;
   hipError_t e = hipGetDevice(&device);
   if (e != hipSuccess) return e;
-  std::lock_guard<std::mutex> lock(g_mu);
-  Entry& en = table()[std::make_tuple(device, stream, (int)purpose)];
-  if (en.cap < bytes) {
-    if (en.ptr) {
+  // Same-stream callers are serialised by the stream's sequence lock (taken here as well, it
+  // is recursive), so the entry is ours while we grow it; g_mu only covers the map itself.
+  StreamSequenceLock sequence(stream);
+  Entry* en;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    en = &table()[std::make_tuple(device, stream, (int)purpose)];  // node addresses are stable
+  }
+  if (en->cap < bytes) {
+    // (hipFree / hipMalloc are illegal under stream capture: the first call of a size class
+    // must happen outside a capture, as tools/graph_replay.py does with its warm-up call)
+    if (en->ptr) {
       // hipFree waits for the device, so no kernel still reads the old buffer
-      e = hipFree(en.ptr);
-      en.ptr = nullptr;
-      en.cap = 0;
+      e = hipFree(en->ptr);
+      en->ptr = nullptr;
+      en->cap = 0;
       if (e != hipSuccess) return e;
     }
     size_t want = bytes < 4096 ? 4096 : bytes;
-    e = hipMalloc(&en.ptr, want);
+    e = hipMalloc(&en->ptr, want);
     if (e != hipSuccess) {
-      en.ptr = nullptr;
+      en->ptr = nullptr;
       return e;
     }
-    en.cap = want;
+    en->cap = want;
   }
-  *out = en.ptr;
+  *out = en->ptr;
   return hipSuccess;
 }
 
-void release_workspaces() {
+void release_stream_workspaces(hipStream_t stream) {
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return;
+  std::vector<void*> victims;
+  {
+    StreamSequenceLock sequence(stream);  // nobody is enqueueing against the buffers
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (auto it = table().begin(); it != table().end();) {
+      if (std::get<0>(it->first) == device && std::get<1>(it->first) == stream) {
+        if (it->second.ptr) victims.push_back(it->second.ptr);
+        it = table().erase(it);
+      } else {
+        ++it;
+      }
+    }
+  }
+  for (void* p : victims) (void)hipFree(p);  // waits for the device: queued kernels finish first
   std::lock_guard<std::mutex> lock(g_mu);
+  sequence_table().erase(std::make_pair(device, stream));  // (holders keep their shared_ptr)
+}
+
+void release_workspaces() {
+  std::vector<std::pair<int, void*>> victims;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (auto& kv : table())
+      if (kv.second.ptr) victims.emplace_back(std::get<0>(kv.first), kv.second.ptr);
+    table().clear();
+  }
   int prev = 0;
   (void)hipGetDevice(&prev);
-  for (auto& kv : table()) {
-    if (!kv.second.ptr) continue;
-    (void)hipSetDevice(std::get<0>(kv.first));
-    (void)hipFree(kv.second.ptr);
+  for (auto& v : victims) {
+    (void)hipSetDevice(v.first);
+    (void)hipFree(v.second);
   }
-  table().clear();
   (void)hipSetDevice(prev);
 }
 

@@ -3,8 +3,8 @@
 // Work enqueued on one HIP stream executes in order, so successive operations on a
 // stream may reuse one scratch buffer; operations on DIFFERENT streams may overlap
 // on the device and must not share scratch.  Buffers are therefore keyed by
-// (device, stream, purpose), grow on demand and live until the process ends (or
-// release_workspaces()).
+// (device, stream, purpose), grow on demand and live until released (release_workspaces,
+// release_stream_workspaces) or the process ends.
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <stddef.h>
@@ -27,6 +27,8 @@ hipError_t stream_workspace(WorkspacePurpose purpose, hipStream_t stream, size_t
 // then serialises the kernels, but of two half-finished sequences over one buffer -- or
 // free the buffer the other is still enqueuing against.  Keyed like the buffers by
 // (current device, stream); enqueueing is microseconds, the kernels run outside the lock.
+// Recursive: a composite that holds the lock while it enqueues (KeySwitch) may call a transform
+// that takes it again for its own scratch (the one-launch fused transform).
 class StreamSequenceLock {
  public:
   explicit StreamSequenceLock(hipStream_t stream);
@@ -35,11 +37,17 @@ class StreamSequenceLock {
   StreamSequenceLock& operator=(const StreamSequenceLock&) = delete;
 
  private:
-  void* mu_;
+  struct Held;
+  Held* held_;
 };
 
 // Frees every cached buffer of the current process (all devices).  The caller
-// guarantees no operation that uses them is in flight.
+// guarantees no operation that uses them is in flight.  C-ABI: hexl_amd_release_workspaces.
 void release_workspaces();
+
+// Frees the buffers (and the sequence lock) keyed by `stream` on the current device; for
+// owners about to destroy the stream (the per-thread staging streams of the host-pointer
+// entry points; callers that create and destroy streams: hexl_amd_release_stream_workspaces).
+void release_stream_workspaces(hipStream_t stream);
 
 }  // namespace hexl_amd

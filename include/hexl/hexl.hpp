@@ -19,5 +19,6 @@
 #include "hexl/util/check.hpp"
 #include "hexl/util/compiler.hpp"
 #include "hexl/util/defines.hpp"
+#include "hexl/util/device-mapped-allocator.hpp"
 #include "hexl/util/types.hpp"
 #include "hexl/util/util.hpp"

@@ -85,6 +85,33 @@ class NTT {
   void ComputeInverseBatch(uint64_t* result, const uint64_t* operand, uint64_t batch,
                            uint64_t input_mod_factor, uint64_t output_mod_factor);
 
+  /// Extension: polynomials of SEVERAL moduli in one call (the per-modulus loops of RNS
+  /// callers, hexl/experimental/seal/key-switch-internal.cpp:51-90, as one launch sequence on
+  /// the GPU).  `polys` polynomials back to back; polynomial i is transformed by
+  /// *ntts[plan_of_slot[(i / inner) % period]] (Map) or *ntts[prime_index[i]] (Indexed).
+  /// SEAL's [ciphertext][component][modulus][N] layout is inner = 1, period = k,
+  /// plan_of_slot = {0 .. k-1}; prime-major blocks are inner = polynomials per prime.  All
+  /// objects share one degree and one device.  Device or host pointers.
+  static void ComputeForwardMap(const NTT* const* ntts, size_t num_ntts,
+                                const uint8_t* plan_of_slot, uint64_t period, uint64_t inner,
+                                uint64_t* result, const uint64_t* operand, uint64_t polys,
+                                uint64_t input_mod_factor, uint64_t output_mod_factor);
+  static void ComputeInverseMap(const NTT* const* ntts, size_t num_ntts,
+                                const uint8_t* plan_of_slot, uint64_t period, uint64_t inner,
+                                uint64_t* result, const uint64_t* operand, uint64_t polys,
+                                uint64_t input_mod_factor, uint64_t output_mod_factor);
+  static void ComputeForwardIndexed(const NTT* const* ntts, size_t num_ntts,
+                                    const uint32_t* prime_index, uint64_t* result,
+                                    const uint64_t* operand, uint64_t polys,
+                                    uint64_t input_mod_factor, uint64_t output_mod_factor);
+  static void ComputeInverseIndexed(const NTT* const* ntts, size_t num_ntts,
+                                    const uint32_t* prime_index, uint64_t* result,
+                                    const uint64_t* operand, uint64_t polys,
+                                    uint64_t input_mod_factor, uint64_t output_mod_factor);
+  /// The C-ABI plan behind this object (a `const hexl_amd_ntt*`, include/hexl_amd.h), for
+  /// callers that mix the C++ API with the C one.
+  const void* PlanHandle() const;
+
   uint64_t GetMinimalRootOfUnity() const;
   uint64_t GetDegree() const;
   uint64_t GetModulus() const;

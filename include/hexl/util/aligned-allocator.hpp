@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <memory>
+#include <type_traits>
 #include <vector>
 
 #include "hexl/util/allocator.hpp"
@@ -42,8 +43,16 @@ class AlignedAllocator {
   struct rebind {
     using other = AlignedAllocator<U, Alignment>;
   };
-  bool operator==(const AlignedAllocator&) { return true; }
-  bool operator!=(const AlignedAllocator&) { return false; }
+  // Two allocators are interchangeable iff they draw from the same strategy.  (The reference
+  // answers "equal" unconditionally, aligned-allocator.hpp:60-61: a vector move-assigned
+  // across strategies then frees one strategy's block through the other.  With strategies
+  // that differ in kind -- malloc and pinned device-mapped memory -- that is a crash, so the
+  // comparison is real here and the allocator travels with its buffer.)
+  bool operator==(const AlignedAllocator& other) const { return m_strategy == other.m_strategy; }
+  bool operator!=(const AlignedAllocator& other) const { return !(*this == other); }
+  using propagate_on_container_move_assignment = std::true_type;
+  using propagate_on_container_copy_assignment = std::true_type;
+  using propagate_on_container_swap = std::true_type;
 
   T* allocate(size_t n) {
     static_assert((Alignment & (Alignment - 1)) == 0, "Alignment must be a power of two");

@@ -57,6 +57,34 @@ int hexl_amd_device_count(int* count);
  * straight to the kernels or through the *_host staging entry points. */
 int hexl_amd_pointer_is_device(const void* p);
 
+/* Host memory the kernels can address.  The *_host entry points (what the intel::hexl shim
+ * calls for host pointers) stage ordinary host memory through a device buffer: H2D copy,
+ * kernels, D2H copy.  Memory that is pinned AND mapped into the device's address space needs
+ * none of that: a one-kernel transform (degree <= 2^13, 2^14 from 192 polynomials) or an
+ * element-wise kernel runs straight on it over the link -- one launch, one synchronisation --
+ * and a multi-pass transform reads its operand there.
+ *   hexl_amd_host_alloc / _free        such memory from the runtime (hipHostMalloc, mapped)
+ *   hexl_amd_host_register / _unregister  an existing allocation made such (hipHostRegister,
+ *                                      mapped): one call over a caller's memory pool
+ *   hexl_amd_pointer_kind              0 ordinary host, 1 device / managed, 2 mapped host
+ * include/hexl/util/device-mapped-allocator.hpp wraps the first pair as an
+ * intel::hexl::AllocatorBase (allocator.hpp:12-51) for AlignedVector64 data buffers. */
+int hexl_amd_host_alloc(void** p, uint64_t bytes);
+int hexl_amd_host_free(void* p);
+int hexl_amd_host_register(void* p, uint64_t bytes);
+int hexl_amd_host_unregister(void* p);
+int hexl_amd_pointer_kind(const void* p);
+
+/* Debug contract: the reference's debug builds (HEXL_DEBUG) check every ELEMENT of an
+ * operand against its bound and throw (HEXL_CHECK_BOUNDS, hexl/include/hexl/util/check.hpp:32-35;
+ * hexl/ntt/ntt-internal.cpp:198, :261; hexl/eltwise/eltwise-mult-mod.cpp:31-33 and the other
+ * eltwise entry points; exercised by test/test-ntt.cpp:20-94).  *violations = number of words
+ * of data[0, n) that are >= bound; data may be host, mapped or device memory (device data:
+ * one reduction kernel, synchronous).  The debug flavour of the shim (libhexl_debug.so,
+ * compiled with -DHEXL_DEBUG) calls it before every operation and throws. */
+int hexl_amd_check_bounds(const uint64_t* data, uint64_t n, uint64_t bound,
+                          uint64_t* violations);
+
 /* ---------------------------------------------------------------------------
  * NTT plan == the state of one intel::hexl::NTT object
  * (hexl/include/hexl/ntt/ntt.hpp:22-293; ctors hexl/ntt/ntt-internal.cpp:24-52;
@@ -121,6 +149,50 @@ int hexl_amd_ntt_inverse_rns(const hexl_amd_ntt* const* plans,
                              const uint64_t* operand, uint64_t batch_per_plan,
                              uint64_t input_mod_factor,
                              uint64_t output_mod_factor, void* stream);
+
+/* Multi-prime form with a per-polynomial prime map ("plan*[] + per-poly prime
+ * index"): `polys` polynomials back to back, polynomial i transformed with
+ *     plans[ plan_of_slot[ (i / inner) % period ] ].
+ * One call covers the layouts RNS callers use:
+ *   - prime-major blocks (the _rns form): inner = polynomials per prime, period = primes,
+ *     plan_of_slot = 0, 1, 2, ...;
+ *   - SEAL's ciphertext layout [ciphertext][component][modulus][N], where modulus j of
+ *     every component sits at polynomial index = ... * k + j
+ *     (hexl/experimental/seal/key-switch-internal.cpp:60-90 indexes
+ *     t_target[j * coeff_count] per modulus j inside one component): inner = 1,
+ *     period = k, plan_of_slot = 0 .. k-1;
+ *   - any periodic pattern (a modulus chain with dropped levels, key-switching moduli
+ *     interleaved with the special prime, ...).
+ * All plans: same degree, same device.  plan_of_slot is host memory, `period` entries,
+ * each < num_plans.  For degrees 2^12 .. 2^17 (num_plans <= 40, period <= 1024) the whole
+ * batch is ONE launch sequence whatever the number of moduli -- the workgroup's polynomial
+ * selects its plan on the device; moduli of different arithmetic policies get one sequence
+ * per policy.  Other shapes fall back to one call per run of polynomials that share a plan
+ * (same results; the launch count then grows with the number of runs). */
+int hexl_amd_ntt_forward_map(const hexl_amd_ntt* const* plans, uint64_t num_plans,
+                             const uint8_t* plan_of_slot, uint64_t period, uint64_t inner,
+                             uint64_t* result, const uint64_t* operand, uint64_t polys,
+                             uint64_t input_mod_factor, uint64_t output_mod_factor,
+                             void* stream);
+int hexl_amd_ntt_inverse_map(const hexl_amd_ntt* const* plans, uint64_t num_plans,
+                             const uint8_t* plan_of_slot, uint64_t period, uint64_t inner,
+                             uint64_t* result, const uint64_t* operand, uint64_t polys,
+                             uint64_t input_mod_factor, uint64_t output_mod_factor,
+                             void* stream);
+
+/* The same with an explicit prime index per polynomial: prime_index is host memory, `polys`
+ * entries, each < num_plans.  The (inner, period) structure is recovered from the array
+ * (shortest period over runs of equal length); an array without one is served run by run. */
+int hexl_amd_ntt_forward_indexed(const hexl_amd_ntt* const* plans, uint64_t num_plans,
+                                 const uint32_t* prime_index, uint64_t* result,
+                                 const uint64_t* operand, uint64_t polys,
+                                 uint64_t input_mod_factor, uint64_t output_mod_factor,
+                                 void* stream);
+int hexl_amd_ntt_inverse_indexed(const hexl_amd_ntt* const* plans, uint64_t num_plans,
+                                 const uint32_t* prime_index, uint64_t* result,
+                                 const uint64_t* operand, uint64_t polys,
+                                 uint64_t input_mod_factor, uint64_t output_mod_factor,
+                                 void* stream);
 
 /* Host-pointer forms used by the intel::hexl::NTT shim: H2D, transform, D2H,
  * synchronous. */
@@ -350,6 +422,15 @@ int hexl_amd_profile_get(int i, const char** name, float* ms);
  *                      N = 8192 (64 KiB tile) and N = 16384 (128 KiB tile, batches >= 192),
  *                      1 = N = 8192 only, 0 = neither */
 int hexl_amd_set_tuning(const char* key, uint64_t value);
+
+/* Device scratch of the composite entry points (KeySwitch, the experimental one-launch
+ * transform) is cached per (device, stream) and grows on demand.  _release_stream_workspaces
+ * frees what is keyed by `stream` on the current device (call it before destroying a stream
+ * that ran such calls; waits for the device); _release_workspaces frees all of it (no call
+ * that uses scratch may be in flight).  The per-thread streams of the host-pointer entry
+ * points release theirs when the thread ends. */
+int hexl_amd_release_stream_workspaces(void* stream);
+int hexl_amd_release_workspaces(void);
 
 #ifdef __cplusplus
 }

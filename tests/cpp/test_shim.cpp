@@ -5,6 +5,7 @@
 // test/test-eltwise-*.cpp; test/test-number-theory.cpp), so each block reads like
 // the reference test it mirrors.  Needs a GPU: every compute call runs the HIP
 // kernels through the C-ABI (there is no CPU fallback).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
@@ -176,6 +177,81 @@ static void test_ntt_threads_and_sizes() {
   for (int v : ok) EXPECT(v == 1);
 }
 
+static void test_device_mapped_memory() {
+  // Extension: buffers in pinned, device-mapped host memory -- same calls, same results, the
+  // kernels run straight on them (include/hexl/util/device-mapped-allocator.hpp).
+  for (uint64_t N : {1024ull, 4096ull, 16384ull, 65536ull}) {
+    const uint64_t q = GeneratePrimes(1, 54, true, N)[0];
+    NTT ntt(N, q);
+    AlignedVector64<uint64_t> x = DeviceMappedVector(N), y = DeviceMappedVector(N);
+    V hx(N), hy(N);
+    uint64_t s = 99 + N;
+    for (uint64_t i = 0; i < N; ++i) {
+      s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+      x[i] = hx[i] = (s >> 8) % q;
+    }
+    ntt.ComputeForward(y.data(), x.data(), 1, 1);    // mapped -> mapped
+    ntt.ComputeForward(hy.data(), hx.data(), 1, 1);  // ordinary host memory (staged)
+    EXPECT(std::equal(hy.begin(), hy.end(), y.begin()));
+    ntt.ComputeForward(hy.data(), x.data(), 4, 4);   // mapped operand, ordinary result
+    for (uint64_t i = 0; i < N; ++i)
+      if (hy[i] >= 4 * q || hy[i] % q != y[i]) {
+        EXPECT(!"lazy forward from mapped memory");
+        break;
+      }
+    ntt.ComputeInverse(y.data(), y.data(), 1, 1);  // in place on mapped memory
+    EXPECT(std::equal(x.begin(), x.end(), y.begin()));
+    EltwiseMultMod(y.data(), x.data(), x.data(), N, q, 1);
+    EltwiseMultMod(hy.data(), hx.data(), hx.data(), N, q, 1);
+    EXPECT(std::equal(hy.begin(), hy.end(), y.begin()));
+    EltwiseFMAMod(y.data(), x.data(), 3, nullptr, N, q, 1);
+    EltwiseFMAMod(hy.data(), hx.data(), 3, nullptr, N, q, 1);
+    EXPECT(std::equal(hy.begin(), hy.end(), y.begin()));
+  }
+  {  // an existing allocation registered once (a caller's memory pool)
+    const uint64_t N = 8192, q = GeneratePrimes(1, 50, true, N)[0];
+    NTT ntt(N, q);
+    V pool(3 * N), ref(N);
+    for (uint64_t i = 0; i < N; ++i) pool[i] = ref[i] = (i * 2654435761ULL) % q;
+    RegisterHostMemory(pool.data(), pool.size() * sizeof(uint64_t));
+    ntt.ComputeForward(pool.data() + N, pool.data(), 1, 1);
+    ntt.ComputeInverse(pool.data() + 2 * N, pool.data() + N, 1, 1);
+    UnregisterHostMemory(pool.data());
+    EXPECT(std::equal(ref.begin(), ref.end(), pool.begin() + 2 * N));
+    V fwd(N);
+    ntt.ComputeForward(fwd.data(), ref.data(), 1, 1);
+    EXPECT(std::equal(fwd.begin(), fwd.end(), pool.begin() + N));
+  }
+}
+
+static void test_ntt_map_extension() {
+  // Extension: polynomials of several moduli in one call, SEAL's interleaved layout
+  // [component][modulus][N] (key-switch-internal.cpp:60-90), host buffers.
+  const uint64_t N = 4096, K = 3, comps = 4;
+  std::vector<uint64_t> primes = GeneratePrimes(K, 54, true, N);
+  std::vector<NTT> ntts;
+  for (uint64_t q : primes) ntts.emplace_back(N, q);
+  std::vector<const NTT*> ptrs;
+  for (auto& t : ntts) ptrs.push_back(&t);
+  V x(comps * K * N), want(comps * K * N), got(comps * K * N);
+  uint64_t s = 7;
+  for (uint64_t i = 0; i < comps * K; ++i)
+    for (uint64_t j = 0; j < N; ++j) {
+      s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+      x[i * N + j] = (s >> 8) % primes[i % K];
+    }
+  for (uint64_t i = 0; i < comps * K; ++i)
+    ntts[i % K].ComputeForward(want.data() + i * N, x.data() + i * N, 1, 1);
+  const uint8_t tab[3] = {0, 1, 2};
+  NTT::ComputeForwardMap(ptrs.data(), K, tab, K, 1, got.data(), x.data(), comps * K, 1, 1);
+  EXPECT(got == want);
+  std::vector<uint32_t> idx(comps * K);
+  for (uint64_t i = 0; i < comps * K; ++i) idx[i] = (uint32_t)(i % K);
+  NTT::ComputeInverseIndexed(ptrs.data(), K, idx.data(), got.data(), got.data(), comps * K, 1, 1);
+  EXPECT(got == x);
+  EXPECT_THROW(NTT::ComputeForwardMap(ptrs.data(), K, nullptr, K, 1, got.data(), x.data(), 1, 1, 1));
+}
+
 static void test_eltwise() {
   {  // TEST(EltwiseMultMod, 4 / 6 / 8big3), in place and out of place
     V a{2, 4, 3, 2}, b{2, 1, 2, 0}, r(4);
@@ -340,6 +416,8 @@ int main(int argc, char** argv) {
   test_ntt_powers_and_roots();
   test_ntt_allocator();
   test_ntt_threads_and_sizes();
+  test_device_mapped_memory();
+  test_ntt_map_extension();
   test_eltwise();
   if (g_fail) {
     std::printf("%d checks failed\n", g_fail);

@@ -49,3 +49,33 @@ def test_cpp_shim_kats_on_gpu(tmp_path):
     r = subprocess.run([EXE, kat], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all C++ shim checks passed" in r.stdout
+
+
+DBG_SRC = os.path.join(ROOT, "tests", "cpp", "test_shim_debug.cpp")
+DBG_EXE = os.path.join(ROOT, "tests", "cpp", "test_shim_debug")
+
+
+def build_debug_exe():
+    if os.path.exists(DBG_EXE) and os.path.getmtime(DBG_EXE) >= os.path.getmtime(DBG_SRC):
+        return
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-DHEXL_DEBUG",
+                           f"-I{os.path.join(ROOT, 'include')}", DBG_SRC, f"-L{LIB}",
+                           "-lhexl_debug", "-lhexl_amd", "-Wl,-rpath," + LIB, "-pthread", "-o",
+                           DBG_EXE])
+
+
+def test_cpp_debug_flavour_links():
+    """CPU: the HEXL_DEBUG flavour of the shim (libhexl_debug.so) exists and the test links."""
+    assert os.path.exists(os.path.join(LIB, "libhexl_debug.so"))
+    build_debug_exe()
+
+
+@pytest.mark.gpu
+def test_cpp_debug_contract_on_gpu():
+    """The reference's TEST(NTT, bad_input) (test/test-ntt.cpp:20-94) and the eltwise bad-input
+    blocks against libhexl_debug.so: out-of-range elements throw, legal inputs do not."""
+    build_debug_exe()
+    env = dict(os.environ, LD_LIBRARY_PATH=LIB + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([DBG_EXE], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all debug-contract checks passed" in r.stdout

@@ -304,6 +304,107 @@ def test_ntt_rns_shapes(hx, ho, n, bits_list, B):
     assert (host(hx, out) == x).all()
 
 
+def _mixed_primes(ho, n, bits_list):
+    primes = []
+    pools = {b: ho.generate_primes(bits_list.count(b), b, True, n) for b in set(bits_list)}
+    for b in bits_list:
+        primes.append(pools[b].pop(0))
+    return primes
+
+
+@pytest.mark.parametrize("n,bits_list,period_tab,inner,polys", [
+    # SEAL's [ciphertext][component][modulus][N]: modulus j at polynomial index ... * k + j
+    (4096, [54, 54], [0, 1], 1, 12),
+    (8192, [54, 45, 54], [0, 1, 2], 1, 9),                 # period 3, Lazy + Fp64 mixed
+    (65536, [54] * 8, list(range(8)), 1, 16),              # configs[3]'s 8 primes, interleaved
+    (16384, [28, 54, 45, 60, 61, 54, 45, 59], list(range(8)), 1, 24),  # all five policies
+    (4096, [54, 49, 60], [0, 1, 2, 1], 2, 19),             # inner 2, a plan used twice, ragged end
+    (32768, [54, 54, 54], [2, 0, 1], 3, 10),               # permuted table, last slot cut short
+    (2048, [54, 45], [0, 1], 1, 6),                        # below the multi-plan degrees: run by run
+    (1 << 18, [54, 60], [0, 1], 1, 4),                     # above them: run by run
+])
+def test_ntt_map_layouts(hx, ho, n, bits_list, period_tab, inner, polys):
+    """The per-polynomial prime map (hexl/experimental/seal/key-switch-internal.cpp:60-90
+    indexes t_target[j * coeff_count] per modulus j inside one ciphertext component): polynomial
+    i uses plans[tab[(i // inner) % period]], one call over interleaved layouts, against the
+    oracle -- forward canonical, forward lazy (range + congruence), inverse round trip."""
+    import torch
+    primes = _mixed_primes(ho, n, bits_list)
+    plans = [hx.NTT(n, p) for p in primes]
+    onts = [ho.NTT(n, p) for p in primes]
+    which = [period_tab[(i // inner) % len(period_tab)] for i in range(polys)]
+    x = np.stack([ho.fill_splitmix(n, 7000 + i, primes[k]) for i, k in enumerate(which)])
+    d = dev(hx, x)
+    out = torch.empty_like(d)
+    hx.ComputeForwardMap(plans, period_tab, inner, out, d, 1, 1)
+    got = host(hx, out)
+    want = np.stack([onts[k].forward(x[i], 1, 1) for i, k in enumerate(which)])
+    assert (got == want).all(), [i for i in range(polys) if not (got[i] == want[i]).all()]
+    lazy = torch.empty_like(d)
+    hx.ComputeForwardMap(plans, period_tab, inner, lazy, d, 1, 4)
+    lz = host(hx, lazy)
+    for i, k in enumerate(which):
+        q = np.uint64(primes[k])
+        assert (lz[i] < np.uint64(4) * q).all() and (lz[i] % q == want[i]).all(), i
+    hx.ComputeInverseMap(plans, period_tab, inner, out, out, 1, 1)  # in place
+    assert (host(hx, out) == x).all()
+    # the explicit per-polynomial index recovers the same structure
+    out2 = torch.empty_like(d)
+    hx.ComputeForwardIndexed(plans, which, out2, d, 1, 1)
+    assert (host(hx, out2) == want).all()
+    hx.ComputeInverseIndexed(plans, which, out2, out2, 1, 1)
+    assert (host(hx, out2) == x).all()
+
+
+def test_ntt_indexed_without_period(hx, ho):
+    """An index array with no periodic structure is served run by run."""
+    import torch
+    n = 4096
+    primes = _mixed_primes(ho, n, [54, 45, 60])
+    plans = [hx.NTT(n, p) for p in primes]
+    which = [0, 0, 1, 2, 2, 2, 0, 1, 1, 0, 2]
+    x = np.stack([ho.fill_splitmix(n, 90 + i, primes[k]) for i, k in enumerate(which)])
+    d = dev(hx, x)
+    out = torch.empty_like(d)
+    hx.ComputeForwardIndexed(plans, which, out, d, 1, 1)
+    got = host(hx, out)
+    for i, k in enumerate(which):
+        assert (got[i] == ho.NTT(n, primes[k]).forward(x[i], 1, 1)).all(), i
+    hx.ComputeInverseIndexed(plans, which, out, out, 1, 1)
+    assert (host(hx, out) == x).all()
+    with pytest.raises(hx.HexlAmdError):
+        hx.ComputeForwardIndexed(plans, [0, 1, 3] + [0] * 8, out, d, 1, 1)  # 3 is not a plan
+    with pytest.raises(hx.HexlAmdError):
+        hx.ComputeForwardMap(plans, [0, 5], 1, out, d, 1, 1)
+
+
+def test_ntt_config1_on_the_hip_path(hx, ho):
+    """BASELINE configs[0] at its exact parameters on the GPU: N = 1024, q = 0xffffee001
+    (36-bit), ONE polynomial, seed 1, Fwd(1,1) + Inv(1,1) against the oracle; the plan picks
+    the minimal root the survey recorded from the real reference (46310425)."""
+    n, q = 1024, 0xffffee001
+    ntt, ont = hx.NTT(n, q), ho.NTT(n, q)
+    assert ntt.GetMinimalRootOfUnity() == 46310425
+    x = ho.fill_splitmix(n, 1, q)
+    d = dev(hx, x)
+    ntt.ComputeForward(d, d, 1, 1)
+    f = host(hx, d)
+    assert (f == ont.forward(x, 1, 1)).all()
+    assert (f < np.uint64(q)).all()
+    ntt.ComputeInverse(d, d, 1, 1)
+    assert (host(hx, d) == x).all()
+    # out of place, lazy ranges
+    import torch
+    d = dev(hx, x)
+    out = torch.empty_like(d)
+    ntt.ComputeForward(out, d, 1, 4)
+    lz = host(hx, out)
+    assert (lz < np.uint64(4 * q)).all() and (lz % np.uint64(q) == f).all()
+    ntt.ComputeInverse(out, dev(hx, f), 1, 2)
+    lz = host(hx, out)
+    assert (lz < np.uint64(2 * q)).all() and (lz % np.uint64(q) == x).all()
+
+
 DEFN = json.load(open(os.path.join(os.path.dirname(__file__), "golden",
                                    "ntt_definition_fixtures.json")))
 
@@ -533,6 +634,8 @@ def test_ntt_fused_plan_matches_split_plan(hx, logn, bits):
     gives the same bits as the default two-launch plan -- canonical and lazy outputs,
     in place and out of place, batches that do and do not fill the chip."""
     import torch
+    if not hx.has_experiments():
+        pytest.skip("needs a -DHEXL_AMD_EXPERIMENTS build (HEXL_AMD_LIB=tools/libhexl_amd_exp.so)")
     n = 1 << logn
     q = hx.GeneratePrimes(1, bits, True, n)[0]
     ntt = hx.NTT(n, q)
@@ -565,6 +668,8 @@ def test_ntt_mixed_plan_matches_split_plan(hx, bits):
     second pass in one launch) gives the same bits as the default two-launch plan -- full,
     ragged and single-chunk pipelines, canonical and lazy outputs, in place and out of place."""
     import torch
+    if not hx.has_experiments():
+        pytest.skip("needs a -DHEXL_AMD_EXPERIMENTS build (HEXL_AMD_LIB=tools/libhexl_amd_exp.so)")
     n = 65536
     q = hx.GeneratePrimes(1, bits, True, n)[0]
     ntt = hx.NTT(n, q)
@@ -1019,6 +1124,78 @@ def test_key_switch_batch_vs_oracle(hx, ho, n, D, K, C, T, bits):
     hx.KeySwitchBatch(d_res, dev(hx, np.concatenate(targets)), T, n, D, K, R, C, moduli,
                       [dev(hx, k) for k in keys], msf)
     assert np.array_equal(host(hx, d_res), want)
+
+
+def test_key_switch_batch_under_the_fused_plan(hx, ho):
+    """Round-2 advisor finding: KeySwitch holds its stream's sequence lock while it enqueues and
+    its inverse transforms (T * C >= fused_min_batch polynomials of N = 32768) took the same
+    lock again inside the one-launch fused plan -- a self-deadlock on a non-recursive mutex.
+    The lock is recursive now; the call must return, bit-exact.  (Experiments builds only:
+    the default build has no fused plan to select.)"""
+    import threading
+    if not hx.has_experiments():
+        pytest.skip("needs a -DHEXL_AMD_EXPERIMENTS build (HEXL_AMD_LIB=tools/libhexl_amd_exp.so)")
+    n, D, K, C, T = 32768, 2, 3, 2, 33  # T * C = 66 >= 64
+    rng = np.random.default_rng(5)
+    moduli = [int(q) for q in ho.generate_primes(K, 54, True, n)]
+    keys = [np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                            for _ in range(C) for i in range(K)]) for _ in range(D)]
+    msf = [int(rng.integers(1, moduli[i], dtype=np.uint64)) for i in range(D)]
+    targets = [np.concatenate([rng.integers(0, moduli[j], n, dtype=np.uint64) for j in range(D)])
+               for _ in range(T)]
+    results = [np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                               for _ in range(C) for i in range(D)]) for _ in range(T)]
+    d_keys = [dev(hx, k) for k in keys]
+    d_t = dev(hx, np.concatenate(targets))
+    want = dev(hx, np.concatenate(results))
+    hx.KeySwitchBatch(want, d_t, T, n, D, K, D + 1, C, moduli, d_keys, msf)  # split plan
+    check = ho.key_switch(results[0], targets[0], n, D, K, D + 1, C, moduli, keys, msf)
+    assert np.array_equal(host(hx, want)[:check.size], check)
+    got = dev(hx, np.concatenate(results))
+    done = []
+
+    def run():
+        hx.KeySwitchBatch(got, d_t, T, n, D, K, D + 1, C, moduli, d_keys, msf)
+        done.append(True)
+
+    try:
+        hx.set_tuning("plan", hx.PLAN_FUSED)
+        th = threading.Thread(target=run, daemon=True)
+        th.start()
+        th.join(120)
+        assert done, "KeySwitchBatch under the fused plan did not return (sequence lock)"
+    finally:
+        hx.set_tuning("plan", hx.PLAN_SPLIT)
+    assert np.array_equal(host(hx, got), host(hx, want))
+
+
+def test_workspaces_can_be_released(hx, ho):
+    """Scratch of the composites is cached per (device, stream); the release entry points give
+    it back, and a later call simply allocates again."""
+    import torch
+    n, D, K, C = 4096, 2, 3, 2
+    rng = np.random.default_rng(9)
+    moduli = [int(q) for q in ho.generate_primes(K, 50, True, n)]
+    keys = [np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                            for _ in range(C) for i in range(K)]) for _ in range(D)]
+    msf = [int(rng.integers(1, moduli[i], dtype=np.uint64)) for i in range(D)]
+    target = np.concatenate([rng.integers(0, moduli[j], n, dtype=np.uint64) for j in range(D)])
+    result = np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                             for _ in range(C) for i in range(D)])
+    want = ho.key_switch(result, target, n, D, K, D + 1, C, moduli, keys, msf)
+    d_keys = [dev(hx, k) for k in keys]
+    st = torch.cuda.Stream()
+    for rep in range(3):
+        with torch.cuda.stream(st):
+            o = dev(hx, result)
+            hx.KeySwitch(o, dev(hx, target), n, D, K, D + 1, C, moduli, d_keys, msf)
+        st.synchronize()
+        assert np.array_equal(host(hx, o), want)
+        if rep == 0:
+            assert hx.lib.hexl_amd_release_stream_workspaces(st.cuda_stream) == 0
+        elif rep == 1:
+            torch.cuda.synchronize()
+            assert hx.lib.hexl_amd_release_workspaces() == 0
 
 
 def test_key_switch_two_streams_do_not_share_scratch(hx, ho):

@@ -5,10 +5,20 @@
 A "step" is one pass of the hot path over one batch of synthetic input: an
 in-place forward NTT (input_mod_factor = output_mod_factor = 1) followed by an
 in-place inverse NTT over 4096 polynomials of degree N = 65536 with a 55-bit
-prime (BASELINE.json configs[2]; at --gpus G > 1 rank g transforms the 4096
-polynomials of RNS prime g, configs[3]: embarrassingly parallel, no data-path
-collective, weak scaling).  Inputs are generated on the device (splitmix64) and
-are resident in HBM before the timed region starts.
+prime (BASELINE.json configs[2]).  Inputs are generated on the device
+(splitmix64) and are resident in HBM before the timed region starts.
+
+Multi-GPU (--gpus G > 1, one process per GPU, no data-path collective):
+  --scaling weak (default)  rank g transforms the 4096 polynomials of RNS prime g: per-GPU
+                            work fixed, the job grows with G (at G = 1 this is the headline
+                            configuration, which keeps the 1-GPU line comparable);
+  --scaling strong          the job is ALWAYS BASELINE configs[3] -- 8 RNS primes x 4096
+                            polynomials = 32,768 transforms per direction -- cut into G
+                            contiguous shards of the flat (prime, polynomial) index (SURVEY.md
+                            8e; hexl/experimental/seal/key-switch-internal.cpp:51-55 is the
+                            per-modulus loop being sharded): one prime per GPU at G = 8, four
+                            at G = 2, all eight (16 GiB) at G = 1, each rank running its
+                            primes through hexl_amd_ntt_forward_rns / _inverse_rns.
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement):
 value = Fwd+Inv NTTs per second over the whole job; `roofline` = algorithmic
@@ -35,11 +45,16 @@ BATCH = 4096
 PRIMES = [18014398510661633, 18014398512365569, 18014398514200577, 18014398514987009,
           18014398515511297, 18014398516559873, 18014398521016321, 18014398524424193]
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-TRAFFIC_PROFILE = "r2_hbm_traffic.json"
-# what keeps each kernel family below the HBM roofline (profiles/r2_pmc_summary.md)
+# Counter-derived figures of the bench kernels (HBM bytes per launch, VALU busy, instructions
+# per wave, shader clock): collected with rocprofv3 --pmc by tools/collect_profiles.sh, written
+# by tools/summarize_profiles.py together with a hash of the kernel sources they were measured
+# on.  They are NOT collected in this run; a profile of other sources is not reported.
+COUNTER_PROFILE = "r3_counters.json"
+KERNEL_SOURCES = ("ntt_kernels.hip", "modarith.h", "internal.h")
+# what keeps each kernel family below the HBM roofline (profiles/r3_pmc_summary.md)
 KERNEL_LIMITER = {"ntt_fwd_strided_pass": "hbm", "ntt_inv_strided_pass": "hbm",
-                  "ntt_fwd_tile_pass_bottom": "valu-issue", "ntt_inv_tile_pass_bottom": "valu-issue",
-                  "ntt_fwd_fused_pass": "valu-issue + scheduler", "ntt_inv_fused_pass": "valu-issue + scheduler"}
+                  "ntt_fwd_tile_pass_bottom": "valu-issue + latency",
+                  "ntt_inv_tile_pass_bottom": "valu-issue + latency"}
 PREWARM = 20            # untimed passes before the --warmup ones (see main)
 
 
@@ -117,6 +132,37 @@ def cpu_baseline(seconds_single=4.0, seconds_all=8.0):
         out["scalar_single_thread_value"] = run(scalar_fns, 1, 2.0)
     ho.lib.ho_ntt_destroy(plan)
     return out
+
+
+def kernel_source_hash():
+    """sha256 over the sources the NTT kernels are compiled from (ties a counter profile to a build)"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "hexl_amd", "csrc", name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def counter_profile():
+    """(per-kernel-family counters, note) from profiles/COUNTER_PROFILE if it was measured on
+    the kernel sources of this checkout, else ({}, why not)"""
+    path = os.path.join(ROOT, "profiles", COUNTER_PROFILE)
+    try:
+        prof = json.load(open(path))
+    except (OSError, ValueError):
+        return {}, "no counter profile committed (profiles/" + COUNTER_PROFILE + ")"
+    if prof.get("kernel_source_sha16") != kernel_source_hash():
+        return {}, ("profiles/" + COUNTER_PROFILE + " was collected on other kernel sources ("
+                    + str(prof.get("kernel_source_sha16")) + "): not reported")
+    return prof.get("by_bench_kernel_family", {}), (
+        "committed rocprofv3 --pmc profile of this command on these kernel sources (sha16 "
+        + prof["kernel_source_sha16"] + "), not collected in this run: profiles/" + COUNTER_PROFILE)
+
+
+def median(v):
+    v = sorted(v)
+    n = len(v)
+    return v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
 
 
 def event_timed(torch, fn, iters):
@@ -250,6 +296,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scaling", choices=("weak", "strong"),
+                    default=os.environ.get("BENCH_SCALING", "weak"),
+                    help="multi-GPU job: weak = one prime x 4096 polynomials per GPU (default); "
+                         "strong = always 8 primes x 4096 polynomials, sharded over the GPUs")
     ap.add_argument("--batch", type=int, default=BATCH, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-secondary", action="store_true", help=argparse.SUPPRESS)  # profile runs
@@ -292,23 +342,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    from hexl_amd.sharding import max_over_ranks, shard_range, units_by_prime
+    from hexl_amd.sharding import gather_over_ranks, job_partition, max_over_ranks
 
-    # weak scaling: `world` RNS primes x `batch` polynomials; the flat (prime, poly)
-    # unit range is cut into contiguous per-rank shards -> rank g owns prime g
+    # The job: weak = `world` primes x `batch` polynomials (rank g owns prime g); strong =
+    # the 8 primes x `batch` polynomials of configs[3] whatever `world` is.  Either way the flat
+    # (prime, polynomial) index is cut into contiguous per-rank shards, no collective on the
+    # data path.
     batch = args.batch
-    begin, end = shard_range(world * batch, world, rank)
-    (prime_idx, first_poly, count), = units_by_prime(begin, end, batch)
-    assert (first_poly, count) == (0, batch)
-    q = PRIMES[prime_idx % len(PRIMES)]
-    ntt = hx.NTT(N, q)
-    data = torch.empty((batch, N), dtype=torch.int64, device="cuda")
-    hx.fill_splitmix(data, N, batch, 1 + rank * batch, q)
+    strong = args.scaling == "strong"
+    num_primes = len(PRIMES) if strong else world
+    segments = job_partition(num_primes, batch, world, args.scaling)[rank]
+    my_polys = sum(c for _, _, c in segments)
+    plans = [hx.NTT(N, PRIMES[p % len(PRIMES)]) for p, _, _ in segments]
+    data = torch.empty((my_polys, N), dtype=torch.int64, device="cuda")
+    views, off = [], 0
+    for (p, first, count), plan in zip(segments, plans):
+        v = data[off:off + count]
+        hx.fill_splitmix(v, N, count, 1 + p * batch + first, PRIMES[p % len(PRIMES)])
+        views.append(v)
+        off += count
     check = data[:2].clone()
+    whole = len(segments) > 1 and all(c == segments[0][2] for _, _, c in segments)
 
     def step():
-        ntt.ComputeForward(data, data, 1, 1)
-        ntt.ComputeInverse(data, data, 1, 1)
+        if len(segments) == 1:
+            plans[0].ComputeForward(data, data, 1, 1)
+            plans[0].ComputeInverse(data, data, 1, 1)
+        elif whole:  # several whole primes: the RNS entry point (prime-major blocks)
+            hx.ComputeForwardRNS(plans, data, data, 1, 1)
+            hx.ComputeInverseRNS(plans, data, data, 1, 1)
+        else:  # a shard that cuts through primes: segment by segment
+            for plan, v in zip(plans, views):
+                plan.ComputeForward(v, v, 1, 1)
+            for plan, v in zip(plans, views):
+                plan.ComputeInverse(v, v, 1, 1)
 
     # The first ~10 passes over a freshly allocated 2 GiB buffer run 8 % slower (clock ramp,
     # first-touch page mapping), whatever W is; PREWARM untimed passes precede the W warm-up
@@ -316,40 +383,47 @@ def main():
     for _ in range(PREWARM + args.warmup):
         step()
     barrier()
-    hx.profile_start(8 * args.steps + 16)
+    hx.profile_start(8 * len(segments) * args.steps + 16)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()  # (on the launch stream; costs no synchronisation)
     barrier()
     elapsed = time.perf_counter() - t0
     records = hx.profile_stop()
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     # fwd followed by inv is the identity: the data must be back where it started
     assert torch.equal(check, data[:2]), "round trip mismatch inside the timed region"
 
-    elapsed = max_over_ranks(elapsed, dist, device="cuda" if backend == "nccl" else "cpu")
+    dev = "cuda" if backend == "nccl" else "cpu"
+    my_rate = 2 * my_polys * args.steps / elapsed
+    per_rank = gather_over_ranks(my_rate, dist, device=dev)
+    median_ms = max_over_ranks(median(step_ms), dist, device=dev)
+    elapsed = max_over_ranks(elapsed, dist, device=dev)
 
-    ntts = 2 * batch * args.steps * world
+    total_polys = num_primes * batch
+    ntts = 2 * total_polys * args.steps
     value = ntts / elapsed
     kern = {}
     for name, ms in records:
         kern.setdefault(name, []).append(ms)
     kern_avg = {k: sum(v) / len(v) for k, v in kern.items()}
+    kern_med = {k: median(v) for k, v in kern.items()}
     dominant = max(kern_avg, key=lambda k: kern_avg[k] * len(kern[k]))
-    alg_bytes = 16.0 * N * batch  # this kernel reads and writes every polynomial once
+    # a launch of rank 0 covers the polynomials of one of its segments; each kernel reads and
+    # writes every polynomial once
+    alg_bytes = 16.0 * N * segments[0][2]
     achieved = alg_bytes / (kern_avg[dominant] * 1e-3) / 1e9
 
-    # HBM bytes per launch of the dominant kernel from the committed PMC profile
-    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 read
-    # correction: profiles/r1_pmc_summary.md); null if the profile does not cover it
-    traffic, traffic_source = None, None
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)))
-        if batch == BATCH:
-            traffic = prof["by_bench_kernel_family"].get(dominant)
-            traffic_source = ("committed rocprofv3 --pmc profile of this command, not collected in "
-                              "this run: profiles/" + TRAFFIC_PROFILE)
-    except (OSError, KeyError, ValueError):
-        pass
+    # counter-derived figures per launch of each kernel (HBM bytes: FETCH_SIZE / WRITE_SIZE in
+    # separate passes with the gfx950 x2 read correction; VALU busy: SQ_ACTIVE_INST_VALU quad-
+    # cycles over SIMD-cycles) from the committed profile of THESE kernel sources, else null
+    counters, counters_note = ({}, "profile covers the default batch only")
+    if batch == BATCH and segments[0][2] == BATCH:
+        counters, counters_note = counter_profile()
+    traffic = (counters.get(dominant) or {}).get("hbm_bytes_per_launch")
 
     # Secondary figures (outside the timed region, rank 0 at N=1 only): EltwiseMultMod over the
     # headline batch and BASELINE.json configs[1] / configs[4], each as algorithmic GB/s and
@@ -357,8 +431,8 @@ def main():
     mult = None
     secondary = None
     if rank == 0 and batch == BATCH and not args.no_secondary:
-        mult = timed_eltwise(hx, torch, "EltwiseMultMod(input_mod_factor=1)", N, batch, q)
-    if rank == 0 and world == 1 and batch == BATCH and not args.no_secondary:
+        mult = timed_eltwise(hx, torch, "EltwiseMultMod(input_mod_factor=1)", N, batch, PRIMES[0])
+    if rank == 0 and world == 1 and batch == BATCH and not args.no_secondary and not strong:
         del data
         torch.cuda.empty_cache()
         secondary = secondary_configs(hx, torch)
@@ -368,29 +442,48 @@ def main():
             "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "prewarm_steps": PREWARM,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # the same step timed with HIP events on the launch stream: median over the K
+            # steps, max over ranks
+            "ms_per_step_event_median": median_ms,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
+            "per_rank_NTT_per_s": per_rank,
             "config": {
-                "workload": ("in-place ForwardNTT(1,1) + InverseNTT(1,1), N=65536, "
-                             f"55-bit prime per GPU, batch={batch} polys per GPU resident in HBM"),
-                "N": N, "batch_per_gpu": batch, "modulus_bits": 55,
-                "primes": PRIMES[:max(1, min(world, 8))],
-                "parallelism": f"batch-sharded x{world}, no collectives"},
+                "workload": (("BASELINE configs[3]: in-place ForwardNTT(1,1) + InverseNTT(1,1), N=65536, "
+                              f"8 RNS primes (55-bit) x {batch} polynomials = {total_polys} transforms per "
+                              f"direction, sharded over {world} GPU(s), resident in HBM") if strong else
+                             ("in-place ForwardNTT(1,1) + InverseNTT(1,1), N=65536, "
+                              f"55-bit prime per GPU, batch={batch} polys per GPU resident in HBM")),
+                "N": N, "batch_per_gpu": my_polys if strong else batch, "modulus_bits": 55,
+                "primes": PRIMES[:max(1, min(num_primes, 8))],
+                "polynomials_total": total_polys,
+                "rank0_segments": [{"prime": p, "first_poly": f, "count": c} for p, f, c in segments],
+                "parallelism": (f"{args.scaling} scaling: flat (prime, polynomial) index sharded x{world}, "
+                                "no collectives")},
             "hbm_algorithmic_GBps": value * 16.0 * N / 1e9,
             "roofline": {
                 "bound": "hbm", "kernel": dominant, "achieved": achieved,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic, "traffic_source": traffic_source,
+                "traffic": traffic, "traffic_source": counters_note,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "avg_kernel_ms": kern_avg,
-                "per_kernel": {k: {"ms": v, "GBps_algorithmic": alg_bytes / (v * 1e-3) / 1e9,
+                "avg_kernel_ms": kern_avg, "median_kernel_ms": kern_med,
+                # both rooflines per kernel: HBM (algorithmic bytes / event time, this run) and
+                # instruction issue (VALU busy from the committed counters of these sources)
+                "per_kernel": {k: {"ms": v, "ms_median": kern_med[k],
+                                   "GBps_algorithmic": alg_bytes / (v * 1e-3) / 1e9,
                                    "frac_of_hbm_peak": alg_bytes / (v * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                   "hbm_bytes_per_launch": (counters.get(k) or {}).get("hbm_bytes_per_launch"),
+                                   "valu_busy": (counters.get(k) or {}).get("valu_busy"),
+                                   "valu_insts_per_wave": (counters.get(k) or {}).get("valu_insts_per_wave"),
+                                   "shader_clock_GHz": (counters.get(k) or {}).get("shader_clock_GHz"),
                                    "limiter": KERNEL_LIMITER.get(k, "hbm")}
                                for k, v in kern_avg.items()},
+                "counters_source": counters_note,
                 "note": ("achieved = algorithmic bytes (16*N per transform, read + write once) of the "
                          "dominant kernel's launch / its HIP-event duration on the launch stream inside "
                          "the timed region; the bound of the path is HBM, `limiter` says what holds each "
-                         "kernel below it (the tile pass is VALU-issue limited: DESIGN.md 4-5)")},
+                         "kernel below it; valu_busy = SQ_ACTIVE_INST_VALU (quad-cycles) * 4 / (SIMDs * "
+                         "GRBM_GUI_ACTIVE per XCD) from rocprofv3 --pmc (DESIGN.md 5)")},
         }
         if mult is not None:
             out["eltwise_mult_mod"] = mult

@@ -819,6 +819,67 @@ __device__ __forceinline__ void handover() {
   }
 }
 
+// Developer experiment (-DHEXL_AMD_XLANE=1, tools/xlane_ab.py): the
+// hand-over between the two in-wave rounds whose gaps are 2^6 and 2^3 done in registers with
+// the cross-lane instructions instead of through LDS.  Element p = (h | a | b | l) (3-bit
+// fields a = p[6..8], b = p[3..5]) is register a of lane (b, l) in the gap-2^6 round and
+// register b of lane (a, l) in the gap-2^3 round: an 8 x 8 transpose between the register
+// index and lane bits 3..5, three exchange steps -- register bit k <-> lane bit 3 + k -- each
+// swapping x[r | 2^k] of the lanes with the bit clear against x[r] of their partners:
+//   lane bit 5: v_permlane32_swap (lanes 32-63 of vdst <-> lanes 0-31 of src), 8 per step;
+//   lane bit 4: v_permlane16_swap (odd rows of vdst <-> even rows of src), 8 per step;
+//   lane bit 3: no swap instruction: two v_mov_b32 row_ror:8 with bank masks and a copy, 24.
+// 40 VALU instructions (+ hazard nops) against 8 ds_write_b64 + 8 ds_read_b64 + 7 v_xor.
+#ifndef HEXL_AMD_XLANE
+#define HEXL_AMD_XLANE 0
+#endif
+__device__ __forceinline__ void xlane_swap_bit(u32& lo_r, u32& hi_r /* x[r | 2^k] */, u32& lo_0,
+                                               u32& hi_0 /* x[r] */, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (k == 2) {
+    auto a = __builtin_amdgcn_permlane32_swap(lo_0, lo_r, false, false);
+    lo_0 = a[0]; lo_r = a[1];
+    auto b = __builtin_amdgcn_permlane32_swap(hi_0, hi_r, false, false);
+    hi_0 = b[0]; hi_r = b[1];
+  } else if (k == 1) {
+    auto a = __builtin_amdgcn_permlane16_swap(lo_0, lo_r, false, false);
+    lo_0 = a[0]; lo_r = a[1];
+    auto b = __builtin_amdgcn_permlane16_swap(hi_0, hi_r, false, false);
+    hi_0 = b[0]; hi_r = b[1];
+  } else {  // lanes 8-15 of each row take x[r | 1] of lanes 0-7, which take their x[r]
+    const u32 t_lo = lo_0, t_hi = hi_0;
+    lo_0 = __builtin_amdgcn_update_dpp(lo_0, lo_r, 0x128 /* row_ror:8 */, 0xF, 0xC, false);
+    hi_0 = __builtin_amdgcn_update_dpp(hi_0, hi_r, 0x128, 0xF, 0xC, false);
+    lo_r = __builtin_amdgcn_update_dpp(lo_r, t_lo, 0x128, 0xF, 0x3, false);
+    hi_r = __builtin_amdgcn_update_dpp(hi_r, t_hi, 0x128, 0xF, 0x3, false);
+  }
+#endif
+}
+__device__ __forceinline__ void xlane_transpose8(u64* x) {
+  u32 lo[8], hi[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    lo[e] = (u32)x[e];
+    hi[e] = (u32)(x[e] >> 32);
+  }
+#pragma unroll
+  for (int k = 2; k >= 0; --k)
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      if (!((r >> k) & 1)) xlane_swap_bit(lo[r | (1 << k)], hi[r | (1 << k)], lo[r], hi[r], k);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = ((u64)hi[e] << 32) | lo[e];
+}
+// whether the hand-over between rounds J and J + 1 (forward order) is done across lanes
+template <int S, int CB, int J>
+constexpr bool xlane_boundary() {
+  using RD = Rounds<S, CB>;
+  // (J >= 1: round 0 of the forward pass / the last round of the inverse are handled in
+  // tile_body, straight from / to global memory)
+  return HEXL_AMD_XLANE && re_of(S) == 3 && J >= 1 && J + 1 < RD::NR && RD::r(J) == 3 &&
+         RD::r(J + 1) == 3 && RD::w(J) == 6 && RD::w(J + 1) == 3;
+}
+
 // forward rounds J .. NR-1: LDS -> registers -> subtree -> same LDS slots.
 // `pre` holds the twiddles of round J when Rounds::pre_fwd(J).
 template <int S, int CB, int TL, int J, class A, bool CTW = false>
@@ -834,11 +895,16 @@ __device__ __forceinline__ void fwd_mid_rounds(u64* x, u64* lds, const TwT<A>* t
       round_twiddles<S, CB, TL, J, CTW>(wv, tw, tid, g);
       w = wv;
     }
-    lds_load_round<S, CB, TL, J>(x, lds, tid);
+    // (cross-lane experiment: the values arrived in registers / leave in registers)
+    if constexpr (!xlane_boundary<S, CB, J - 1>()) lds_load_round<S, CB, TL, J>(x, lds, tid);
     if constexpr (RD::pre_fwd(J + 1)) round_twiddles<S, CB, TL, J + 1, CTW>(wn, tw, tid, g);
     round_compute<S, CB, J, A, true, false>(x, w, m, il);
-    lds_store_round<S, CB, TL, J>(x, lds, tid);
-    handover<RD::w(J), RD::r(J) == kRE>();
+    if constexpr (xlane_boundary<S, CB, J>()) {
+      xlane_transpose8(x);
+    } else {
+      lds_store_round<S, CB, TL, J>(x, lds, tid);
+      handover<RD::w(J), RD::r(J) == kRE>();
+    }
     HX_STAMP(3 + J);
     fwd_mid_rounds<S, CB, TL, J + 1, A, CTW>(x, lds, tw, tid, g, m, il, wn);
   }
@@ -861,12 +927,16 @@ __device__ __forceinline__ void inv_mid_rounds(u64* x, u64* lds, const TwT<A>* t
       round_twiddles<S, CB, TL, J, CTW>(wv, tw, tid, g);
       w = wv;
     }
-    lds_load_round<S, CB, TL, J>(x, lds, tid);
+    if constexpr (!xlane_boundary<S, CB, J>()) lds_load_round<S, CB, TL, J>(x, lds, tid);
     if constexpr (RD::pre_inv(J - 1)) round_twiddles<S, CB, TL, J - 1, CTW>(J == 1 ? pre0 : wn, tw, tid, g);
     round_compute<S, CB, J, A, false, false>(x, w, m, il);
-    lds_store_round<S, CB, TL, J>(x, lds, tid);
-    // the next (shallower) round J-1 regroups across waves iff its gap exceeds a wave
-    handover<RD::w(J - 1), RD::r(J - 1) == kRE>();
+    if constexpr (xlane_boundary<S, CB, J - 1>()) {
+      xlane_transpose8(x);  // (the exchange is its own inverse)
+    } else {
+      lds_store_round<S, CB, TL, J>(x, lds, tid);
+      // the next (shallower) round J-1 regroups across waves iff its gap exceeds a wave
+      handover<RD::w(J - 1), RD::r(J - 1) == kRE>();
+    }
     inv_mid_rounds<S, CB, TL, J - 1, A, CTW>(x, lds, tw, tid, g, m, il, wn, pre0);
   }
 }

@@ -30,6 +30,36 @@ def test_shard_range_covers_exactly_once():
     assert units_by_prime(3, 9, 4) == [(0, 3, 1), (1, 0, 4), (2, 0, 1)]
 
 
+def test_strong_scaling_partition_of_config4():
+    """bench.py --scaling strong: the job is always BASELINE configs[3] (8 primes x 4096
+    polynomials); every (prime, polynomial) unit belongs to exactly one rank for any number of
+    GPUs, whole primes for G in {1, 2, 4, 8}."""
+    from hexl_amd.sharding import job_partition
+    P, B = 8, 4096
+    for world in (1, 2, 3, 4, 5, 8, 16):
+        parts = job_partition(P, B, world, "strong")
+        assert len(parts) == world
+        seen = set()
+        for segs in parts:
+            for prime, first, count in segs:
+                assert 0 <= prime < P and 0 <= first and first + count <= B and count > 0
+                for u in range(prime * B + first, prime * B + first + count, 512):
+                    assert u not in seen
+                    seen.add(u)
+                seen.add(prime * B + first + count - 1)
+        assert sum(c for segs in parts for _, _, c in segs) == P * B
+        sizes = [sum(c for _, _, c in segs) for segs in parts]
+        assert max(sizes) - min(sizes) <= 1
+        if world in (1, 2, 4, 8):  # several WHOLE primes per GPU
+            for g, segs in enumerate(parts):
+                per = P // world
+                assert segs == [(g * per + k, 0, B) for k in range(per)]
+    # weak: every rank its own prime, the job grows
+    assert job_partition(8, B, 4, "weak") == [[(g, 0, B)] for g in range(4)]
+    with pytest.raises(ValueError):
+        job_partition(8, B, 2, "sideways")
+
+
 def _worker(rank, world, port, out_dir):
     import torch
     import torch.distributed as dist

@@ -23,8 +23,12 @@ run_pmc() {  # name, counters..., then -- command
 }
 run_pmc fetch FETCH_SIZE -- $BENCH
 run_pmc write WRITE_SIZE -- $BENCH
-run_pmc sq SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY -- $BENCH
+# (GRBM_GUI_ACTIVE rides along in both SQ passes -- GRBM is its own block -- so that VALU busy
+# = SQ_ACTIVE_INST_VALU * 4 / (SIMDs * GRBM_GUI_ACTIVE per XCD) is formed within one pass)
+run_pmc sq SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE -- $BENCH
+run_pmc sq2 SQ_BUSY_CU_CYCLES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE -- $BENCH
 run_pmc lds SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -- $BENCH
 run_pmc cal_fetch FETCH_SIZE -- $REPO/tools/ubench
 run_pmc cal_write WRITE_SIZE -- $REPO/tools/ubench
+rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z_0-9]*VALU[A-Z_0-9]*\|SQ_BUSY[A-Z_]*\|GRBM_[A-Z_]*" | sort -u > $OUT/available_counters.txt
 ls -R $OUT | head -50

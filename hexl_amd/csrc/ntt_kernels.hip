@@ -1180,7 +1180,10 @@ __global__ void __launch_bounds__(1 << (TL - re_of(S)), (min_waves<S, CB>()))
 tile_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst m, u32 log_n,
           u32 flags, u64 total, InvLast il) {
   __shared__ u64 lds[1 << TL];
-  // (The XCD-aware block order of strided_pass was measured here too: 2-7 % slower.)
+  // (The XCD-aware block order of strided_pass was measured here too: 2-7 % slower.  So was
+  // a workgroup that walks 2 or 4 consecutive tiles instead of one -- a k-th of the
+  // dispatches, no wait for the previous tile's store acknowledgements: forward +2 / +8 %,
+  // inverse +65 / +53 % slower, round 3.)
   // forward: streamed loads and stores; inverse: plain (see ld_global)
   tile_body<FWD, S, CB, TL, GUARD, A, LAST, FWD ? kStream : kPlain, FWD ? kStream : kPlain>(
       lds, out, in, tw, m, log_n, flags, total, il, blockIdx.x);
@@ -1305,8 +1308,9 @@ static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2
     }
   }
 #define HX_LAUNCH_B2(T, G, LST)                                                           \
-  hipLaunchKernelGGL((tile_pass<FWD, T, 0, TL, G, A, LST>), dim3(grid), dim3(1 << (TL - re_of(T))), \
-                     0, st, out, in, tw, m, log_n, finish, total, il)
+  hipLaunchKernelGGL((tile_pass<FWD, T, 0, TL, G, A, LST>),                               \
+                     dim3(grid),                                                          \
+                     dim3(1 << (TL - re_of(T))), 0, st, out, in, tw, m, log_n, finish, total, il)
 #define HX_LAUNCH_B(T)                                                                    \
   case T:                                                                                 \
     if constexpr (T <= TL && (TL <= 10 || T >= 9) && (TL != 11 || T == 11) &&               \

@@ -3,7 +3,9 @@
 
     <prefix>/include/hexl/**                    the intel::hexl headers
     <prefix>/include/hexl_amd.h                 the C-ABI
-    <prefix>/lib/libhexl.so, libhexl_amd.so
+    <prefix>/lib/libhexl.so, libhexl_amd.so, libhexl_debug.so (the HEXL_DEBUG flavour: the
+                                                reference's debug builds name theirs hexl_debug,
+                                                hexl/CMakeLists.txt:68-72; target HEXL::hexl_debug)
     <prefix>/lib/cmake/hexl-1.2.5/HEXLConfig.cmake, HEXLConfigVersion.cmake, HEXLTargets.cmake
     <prefix>/lib/pkgconfig/hexl.pc
 
@@ -58,6 +60,17 @@ if(NOT TARGET HEXL::hexl)
         INTERFACE_COMPILE_FEATURES cxx_std_17
         INTERFACE_LINK_LIBRARIES HEXL::hexl_amd)
 endif()
+if(NOT TARGET HEXL::hexl_debug AND EXISTS "${_hexl_prefix}/lib/libhexl_debug.so")
+    # the debug flavour: element-wise bound checks that throw (HEXL_CHECK_BOUNDS)
+    add_library(HEXL::hexl_debug SHARED IMPORTED)
+    set_target_properties(HEXL::hexl_debug PROPERTIES
+        IMPORTED_LOCATION "${_hexl_prefix}/lib/libhexl_debug.so"
+        IMPORTED_NO_SONAME TRUE
+        INTERFACE_INCLUDE_DIRECTORIES "${_hexl_prefix}/include"
+        INTERFACE_COMPILE_FEATURES cxx_std_17
+        INTERFACE_COMPILE_DEFINITIONS HEXL_DEBUG
+        INTERFACE_LINK_LIBRARIES HEXL::hexl_amd)
+endif()
 unset(_hexl_prefix)
 """
 
@@ -104,6 +117,9 @@ def install(prefix):
         if not os.path.exists(src):
             raise RuntimeError(f"{src} is missing: run python hexl_amd/build.py first")
         shutil.copy(src, lib)
+    dbg = os.path.join(HERE, "lib", "libhexl_debug.so")
+    if os.path.exists(dbg):
+        shutil.copy(dbg, lib)
     open(os.path.join(cmk, "HEXLConfig.cmake"), "w").write(CONFIG % subst)
     open(os.path.join(cmk, "HEXLTargets.cmake"), "w").write(TARGETS)
     open(os.path.join(cmk, "HEXLConfigVersion.cmake"), "w").write(VERSION_FILE % subst)

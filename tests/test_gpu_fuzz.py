@@ -123,6 +123,53 @@ def test_fuzz_ntt_rns(hx, ho, idx):
     assert np.array_equal(hx.to_numpy(buf).reshape(x.shape), exp), tag
 
 
+@pytest.mark.parametrize("idx", range(CASES))
+def test_fuzz_ntt_map(hx, ho, idx):
+    """The per-polynomial prime map (hexl_amd_ntt_*_map / _indexed): random tables (repeats,
+    permutations), `inner`, periods, ragged ends, mixed arithmetic policies, lazy outputs."""
+    import torch
+    rng = random.Random(SEED * 15485863 + idx)
+    logn = rng.choice([3, 10, 12, 12, 13, 14, 15, 16, 18])
+    n = 1 << logn
+    primes = []
+    while len(primes) < rng.choice([1, 2, 3, 5, 8]):
+        p = draw_prime(ho, rng, logn)
+        if p not in primes:
+            primes.append(p)
+    period = rng.choice([1, 2, 3, 4, 7, 8])
+    tab = [rng.randrange(len(primes)) for _ in range(period)]
+    inner = rng.choice([1, 1, 1, 2, 3, 5])
+    polys = min(rng.choice([1, 2, 5, 8, 13, 24, 31]), max(1, MAX_ELEMS // n))
+    which = [tab[(i // inner) % period] for i in range(polys)]
+    forward = rng.random() < 0.5
+    in_mf, out_mf = rng.choice([(1, 1), (2, 1), (4, 4), (1, 4)] if forward
+                               else [(1, 1), (2, 1), (2, 2)])
+    indexed = rng.random() < 0.4
+    tag = dict(idx=idx, n=n, primes=primes, tab=tab, inner=inner, polys=polys, fwd=forward,
+               in_mf=in_mf, out_mf=out_mf, indexed=indexed)
+    x = np.stack([rand_u64(rng, (n,), in_mf * primes[k]) for k in which])
+    onts = [ho.NTT(n, q) for q in primes]
+    exp = np.stack([(onts[k].forward if forward else onts[k].inverse)(x[i], in_mf, out_mf)
+                    for i, k in enumerate(which)])
+    plans = [hx.NTT(n, q) for q in primes]
+    src = hx.from_numpy(x)
+    dst = src if rng.random() < 0.5 else torch.full_like(src, 0x3C3C3C3C)
+    if indexed:
+        (hx.ComputeForwardIndexed if forward else hx.ComputeInverseIndexed)(
+            plans, which, dst, src, in_mf, out_mf)
+    else:
+        (hx.ComputeForwardMap if forward else hx.ComputeInverseMap)(
+            plans, tab, inner, dst, src, in_mf, out_mf)
+    got = hx.to_numpy(dst).reshape(polys, n)
+    for i, k in enumerate(which):
+        q = np.uint64(primes[k])
+        if out_mf == 1:
+            assert np.array_equal(got[i], exp[i]), (tag, i)
+        else:
+            assert (got[i] < np.uint64(out_mf) * q).all(), (tag, i)
+            assert np.array_equal(got[i] % q, exp[i] % q), (tag, i)
+
+
 ELT_OPS = ["add", "add_scalar", "sub", "sub_scalar", "mult", "fma", "fma_null", "reduce",
            "cmp_add", "cmp_sub_mod"]
 

@@ -1183,7 +1183,9 @@ tile_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst m
   // (The XCD-aware block order of strided_pass was measured here too: 2-7 % slower.  So was
   // a workgroup that walks 2 or 4 consecutive tiles instead of one -- a k-th of the
   // dispatches, no wait for the previous tile's store acknowledgements: forward +2 / +8 %,
-  // inverse +65 / +53 % slower, round 3.)
+  // inverse +65 / +53 % slower, round 3.  And a tile-index-major order -- consecutive workgroups
+  // take the same tile of consecutive polynomials, everything in flight sharing one set of
+  // per-lane twiddles (31.5 KiB: L1-resident): forward +1 %, inverse +8 % slower, round 3.)
   // forward: streamed loads and stores; inverse: plain (see ld_global)
   tile_body<FWD, S, CB, TL, GUARD, A, LAST, FWD ? kStream : kPlain, FWD ? kStream : kPlain>(
       lds, out, in, tw, m, log_n, flags, total, il, blockIdx.x);

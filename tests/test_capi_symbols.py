@@ -34,6 +34,26 @@ def test_library_exports_every_declared_symbol(hx):
     assert sorted(hx.C_ABI_SYMBOLS) == syms
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/hexl_amd.h is the FFI boundary: it must compile as C (a cgo / JNI / ctypes stub
+    binds it), with nothing but <stdint.h> / <stddef.h> types in the signatures."""
+    import subprocess
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "hexl_amd.h"\n'
+                   "int probe(void) {\n"
+                   "  hexl_amd_ntt* plan = 0; const hexl_amd_ntt* plans[1]; uint8_t slot[1] = {0};\n"
+                   "  uint64_t bad = 0; void* p = 0;\n"
+                   "  plans[0] = plan;\n"
+                   "  return hexl_amd_ntt_forward_map(plans, 1, slot, 1, 1, 0, 0, 0, 1, 1, 0) +\n"
+                   "         hexl_amd_check_bounds(0, 0, 1, &bad) + hexl_amd_host_alloc(&p, 0) +\n"
+                   "         hexl_amd_pointer_kind(p) + hexl_amd_release_workspaces();\n"
+                   "}\n")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only",
+                           "-I" + os.path.join(ROOT, "include"), str(src)])
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "hexl_amd.h")).read(), flags=re.S)
+    assert "torch" not in text and "hip" not in text.replace("hexl_amd", "")  # outside comments
+
+
 def test_shim_library_exports_reference_api():
     """libhexl.so carries the intel::hexl symbols a HEXL caller links against."""
     path = os.path.join(ROOT, "hexl_amd", "lib", "libhexl.so")

@@ -743,6 +743,9 @@ __device__ __forceinline__ void round_twiddles(T* wv, const T* __restrict__ tw, 
 #ifndef HX_EXP_NO_SCALAR_TW  // developer experiment: per-lane loads for every twiddle
     if (w >= 6) node = __builtin_amdgcn_readfirstlane(node);  // uniform across the wave
 #endif
+#ifdef HX_EXP_UNIFORM_TW  // developer experiment (WRONG results): no per-lane twiddle traffic
+    node = __builtin_amdgcn_readfirstlane(node);
+#endif
     load_twiddles<r, CTW>(wv + (s << r), tw, node);
   }
 }

@@ -378,6 +378,61 @@ def test_ntt_indexed_without_period(hx, ho):
         hx.ComputeForwardMap(plans, [0, 5], 1, out, d, 1, 1)
 
 
+def test_pointer_kinds_and_zero_copy_host_path(hx, ho):
+    """hexl_amd_pointer_kind: 0 ordinary host memory, 1 device memory, 2 pinned device-mapped host
+    memory (from hexl_amd_host_alloc, or an existing buffer after hexl_amd_host_register); the
+    *_host entry points give the oracle's bits on all of them (mapped memory: the kernels run
+    straight on the caller's buffer, one-kernel and two-pass transforms, element-wise ops)."""
+    import ctypes as C
+    lib = hx.lib
+    plain = np.zeros(8, dtype=np.uint64)
+    assert lib.hexl_amd_pointer_kind(plain.ctypes.data_as(C.c_void_p)) == 0
+    assert lib.hexl_amd_pointer_kind(C.c_void_p(dev(hx, plain).data_ptr())) == 1
+    for n, bits in ((4096, 49), (8192, 54), (65536, 54)):
+        q = ho.generate_primes(1, bits, True, n)[0]
+        ntt, ont = hx.NTT(n, q), ho.NTT(n, q)
+        x = ho.fill_splitmix(n, 5 + n, q)
+        want = ont.forward(x, 1, 1)
+        pm = C.c_void_p()
+        assert lib.hexl_amd_host_alloc(C.byref(pm), 2 * n * 8) == 0
+        assert lib.hexl_amd_pointer_kind(pm) == 2
+        m = np.ctypeslib.as_array(C.cast(pm, C.POINTER(C.c_uint64)), shape=(2 * n,))
+        m[:n] = x
+        out = C.c_void_p(pm.value + n * 8)
+        assert lib.hexl_amd_pointer_kind(out) == 2  # interior pointers too
+        assert lib.hexl_amd_ntt_forward_host(ntt._h, out, pm, 1, 1, 1) == 0
+        assert np.array_equal(m[n:], want)
+        assert lib.hexl_amd_ntt_inverse_host(ntt._h, out, out, 1, 1, 1) == 0  # in place
+        assert np.array_equal(m[n:], x)
+        # element-wise on mapped memory: MultMod (op 4)
+        assert lib.hexl_amd_eltwise_host(4, out, pm, pm, 0, n, q, 1, 1) == 0
+        assert np.array_equal(m[n:], ho.eltwise_mult_mod(x, x, q, 1))
+        assert lib.hexl_amd_host_free(pm) == 0
+        # an existing allocation, registered
+        buf = np.zeros(2 * n, dtype=np.uint64)
+        buf[:n] = x
+        pb = buf.ctypes.data_as(C.c_void_p)
+        assert lib.hexl_amd_host_register(pb, buf.nbytes) == 0
+        try:
+            assert lib.hexl_amd_pointer_kind(pb) == 2
+            po = C.c_void_p(pb.value + n * 8)
+            assert lib.hexl_amd_ntt_forward_host(ntt._h, po, pb, 1, 1, 1) == 0
+            assert np.array_equal(buf[n:], want)
+        finally:
+            assert lib.hexl_amd_host_unregister(pb) == 0
+        assert lib.hexl_amd_pointer_kind(pb) == 0
+    # bounds check entry point on the three kinds
+    bad = C.c_uint64(0)
+    v = np.array([1, 2, 3, 769, 5, 770], dtype=np.uint64)
+    assert lib.hexl_amd_check_bounds(v.ctypes.data_as(C.c_void_p), v.size, 769, C.byref(bad)) == 0
+    assert bad.value == 2
+    d = dev(hx, v)
+    assert lib.hexl_amd_check_bounds(C.c_void_p(d.data_ptr()), v.size, 769, C.byref(bad)) == 0
+    assert bad.value == 2
+    assert lib.hexl_amd_check_bounds(C.c_void_p(d.data_ptr()), v.size, 771, C.byref(bad)) == 0
+    assert bad.value == 0
+
+
 def test_ntt_config1_on_the_hip_path(hx, ho):
     """BASELINE configs[0] at its exact parameters on the GPU: N = 1024, q = 0xffffee001
     (36-bit), ONE polynomial, seed 1, Fwd(1,1) + Inv(1,1) against the oracle; the plan picks

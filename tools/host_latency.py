@@ -16,7 +16,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hexl_amd as hx  # noqa: E402
 
 REPS = 300
-for N, bits in ((4096, 49), (4096, 54), (8192, 54), (16384, 54), (32768, 54), (65536, 54)):
+SIZES = ((4096, 49), (4096, 54), (8192, 54), (16384, 54), (32768, 54), (65536, 54), (131072, 54))
+for N, bits in SIZES:
     q = hx.GeneratePrimes(1, bits, True, N)[0]
     ntt = hx.NTT(N, q)
     src = np.random.default_rng(1).integers(0, q, N, dtype=np.uint64)

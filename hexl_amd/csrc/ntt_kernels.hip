@@ -1474,6 +1474,14 @@ static Plan make_plan(int L, bool allow_tile13 = true, u64 batch = ~0ull) {
     // stages: both kernels then carry a comparable share of the arithmetic), 12 on
     // 4096-element tiles above.  (Experiments builds: HEXL_AMD_BOTTOM=11|12 overrides.)
     p.bottom = L <= 16 ? 11 : 12;
+    // N = 2^18, 2^19: five strided stages + the 13- / 14-stage tile pass on the 64 / 128 KiB
+    // tiles of the one-kernel plans -- two HBM round trips instead of three (3 + 3 + 12,
+    // 4 + 3 + 12 stages); round 3.  HEXL_AMD_BIGTILE=0: the three-pass plans (A/B runs).
+    static const bool big_tile = [] {
+      const char* e = getenv("HEXL_AMD_BIGTILE");
+      return !(e && e[0] == '0');
+    }();
+    if (big_tile && (L == 18 || L == 19)) p.bottom = L - 5;
 #ifdef HEXL_AMD_EXPERIMENTS
     static const int bottom_override = [] {
       const char* e = getenv("HEXL_AMD_BOTTOM");

@@ -27,6 +27,8 @@ rec = hx.profile_stop()
 agg = {}
 for k, v in rec:
     agg.setdefault(k, []).append(v)
+REPS = 10  # (a name may be launched several times per transform: degrees above 2^17)
 print(os.path.basename(os.environ.get("HEXL_AMD_LIB", "default")),
       {k.replace("ntt_", ""): round(sum(v) / len(v), 3) for k, v in agg.items()},
-      "sum %.3f ms" % sum(sum(v) / len(v) for v in agg.values()))
+      "launches per step %d," % (sum(len(v) for v in agg.values()) // REPS),
+      "sum %.3f ms per step" % (sum(sum(v) for v in agg.values()) / REPS))

@@ -609,6 +609,41 @@ def test_ntt_fp64_policy_matches_integer_policy(hx, n, batch):
         assert int(x.min()) >= 0 and int(x.max()) < 2 * q and torch.equal(x % q, a)
 
 
+@pytest.mark.parametrize("n,bits,small_end", [(4096, 30, True), (65536, 31, False), (16384, 31, True),
+                                              (8192, 32, True), (65536, 32, True)])
+def test_ntt_integer_policies_around_2_pow_32(hx, ho, n, bits, small_end):
+    """With the Fp64 policy switched off the moduli between 2^30 and 2^32 take the Harvey60
+    policy and the Lazy policy starts at 2^32 (its quotient estimates shift the high word of a
+    value: round 3); both against the oracle and against the Fp64 plan, all mod factors."""
+    import torch
+    q = ho.generate_primes(1, bits, small_end, n)[0]
+    try:
+        hx.set_tuning("fp64", 0)
+        integer = hx.NTT(n, q)
+    finally:
+        hx.set_tuning("fp64", 1)
+    fp = hx.NTT(n, q)
+    ont = ho.NTT(n, q)
+    batch = 3
+    for in_mf, out_mf in ((1, 1), (4, 1), (2, 4)):
+        x = np.stack([ho.fill_splitmix(n, 300 + b, in_mf * q) for b in range(batch)])
+        want = ont.forward(x, in_mf, 1)
+        a, b = dev(hx, x), dev(hx, x)
+        integer.ComputeForward(a, a, in_mf, out_mf)
+        fp.ComputeForward(b, b, in_mf, out_mf)
+        for got in (host(hx, a), host(hx, b)):
+            assert (got < np.uint64(out_mf * q)).all() and (got % np.uint64(q) == want).all()
+            if out_mf == 1:
+                assert (got == want).all()
+    for in_mf, out_mf in ((1, 1), (2, 1), (2, 2)):
+        x = np.stack([ho.fill_splitmix(n, 400 + b, in_mf * q) for b in range(batch)])
+        want = ont.inverse(x, in_mf, 1)
+        a = dev(hx, x)
+        integer.ComputeInverse(a, a, in_mf, out_mf)
+        got = host(hx, a)
+        assert (got < np.uint64(out_mf * q)).all() and (got % np.uint64(q) == want).all()
+
+
 @pytest.mark.parametrize("n,batch,bits,small_end", [(4096, 64, 59, False), (65536, 64, 59, False),
                                                     (1 << 17, 3, 56, True), (1 << 13, 5, 58, True),
                                                     (1 << 14, 200, 59, False), (64, 7, 57, True),

@@ -124,6 +124,10 @@ def _load():
     sig("hexl_amd_host_unregister", ci, vp)
     sig("hexl_amd_pointer_kind", ci, vp)
     sig("hexl_amd_check_bounds", ci, p64, u64, u64, C.POINTER(u64))
+    sig("hexl_amd_device_alloc", ci, C.POINTER(vp), u64, ci)
+    sig("hexl_amd_device_free", ci, vp)
+    sig("hexl_amd_copy", ci, vp, vp, u64, vp, ci)
+    sig("hexl_amd_synchronize", ci, vp)
     sig("hexl_amd_release_stream_workspaces", ci, vp)
     sig("hexl_amd_release_workspaces", ci)
     return lib
@@ -155,7 +159,8 @@ C_ABI_SYMBOLS = [
     "hexl_amd_ntt_inverse_indexed", "hexl_amd_release_stream_workspaces",
     "hexl_amd_release_workspaces", "hexl_amd_host_alloc", "hexl_amd_host_free",
     "hexl_amd_host_register", "hexl_amd_host_unregister", "hexl_amd_pointer_kind",
-    "hexl_amd_check_bounds",
+    "hexl_amd_check_bounds", "hexl_amd_device_alloc", "hexl_amd_device_free", "hexl_amd_copy",
+    "hexl_amd_synchronize",
 ]
 
 

@@ -228,6 +228,36 @@ int hexl_amd_host_unregister(void* p) {
   return HEXL_AMD_OK;
 }
 
+int hexl_amd_device_alloc(void** p, uint64_t bytes, int device) {
+  if (!p) return fail(HEXL_AMD_ERR_INVALID_ARG, "p == nullptr");
+  *p = nullptr;
+  if (bytes == 0) return HEXL_AMD_OK;
+  if (device < 0) HX_HIP(hipGetDevice(&device));
+  DeviceScope scope(device);
+  if (scope.err != hipSuccess) return hip_fail(scope.err, "hipSetDevice");
+  HX_HIP(hipMalloc(p, (size_t)bytes));
+  return HEXL_AMD_OK;
+}
+int hexl_amd_device_free(void* p) {
+  if (!p) return HEXL_AMD_OK;
+  HX_HIP(hipFree(p));
+  return HEXL_AMD_OK;
+}
+int hexl_amd_copy(void* dst, const void* src, uint64_t bytes, void* stream, int blocking) {
+  if (bytes == 0) return HEXL_AMD_OK;
+  if (!dst || !src) return fail(HEXL_AMD_ERR_INVALID_ARG, "dst == nullptr or src == nullptr");
+  HX_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDefault, (hipStream_t)stream));
+  if (blocking) HX_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return HEXL_AMD_OK;
+}
+int hexl_amd_synchronize(void* stream) {
+  if (stream)
+    HX_HIP(hipStreamSynchronize((hipStream_t)stream));
+  else
+    HX_HIP(hipDeviceSynchronize());
+  return HEXL_AMD_OK;
+}
+
 int hexl_amd_check_bounds(const uint64_t* data, uint64_t n, uint64_t bound,
                           uint64_t* violations) {
   if (!violations) return fail(HEXL_AMD_ERR_INVALID_ARG, "violations == nullptr");

@@ -64,6 +64,14 @@ void* DeviceMappedAllocate(size_t bytes) {
 void DeviceMappedFree(void* p) noexcept { (void)hexl_amd_host_free(p); }
 void RegisterHostMemory(void* p, size_t bytes) { check(hexl_amd_host_register(p, bytes)); }
 void UnregisterHostMemory(void* p) noexcept { (void)hexl_amd_host_unregister(p); }
+void* DeviceMalloc(size_t bytes) {
+  void* p = nullptr;
+  check(hexl_amd_device_alloc(&p, bytes, -1));
+  return p;
+}
+void DeviceFree(void* p) noexcept { (void)hexl_amd_device_free(p); }
+void Copy(void* dst, const void* src, size_t bytes) { check(hexl_amd_copy(dst, src, bytes, nullptr, 1)); }
+void DeviceSynchronize() { check(hexl_amd_synchronize(nullptr)); }
 AllocatorStrategyPtr DeviceMappedStrategy() {
   static AllocatorStrategyPtr s = std::make_shared<DeviceMappedAllocator>();
   return s;

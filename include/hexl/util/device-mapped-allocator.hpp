@@ -29,6 +29,14 @@ void DeviceMappedFree(void* p) noexcept;
 void RegisterHostMemory(void* p, size_t bytes);
 void UnregisterHostMemory(void* p) noexcept;
 
+/// Device memory for callers without a HIP toolchain: buffers for the device-pointer forms of
+/// NTT / Eltwise* (the throughput path).  The memory is NOT host-accessible: move data with
+/// Copy (either side may be host, mapped or device memory; synchronous).
+void* DeviceMalloc(size_t bytes);
+void DeviceFree(void* p) noexcept;
+void Copy(void* dst, const void* src, size_t bytes);
+void DeviceSynchronize();
+
 struct DeviceMappedAllocator : AllocatorBase {
   void* allocate(size_t bytes_count) final { return DeviceMappedAllocate(bytes_count); }
   void deallocate(void* p, size_t) final { DeviceMappedFree(p); }

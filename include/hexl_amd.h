@@ -75,6 +75,21 @@ int hexl_amd_host_register(void* p, uint64_t bytes);
 int hexl_amd_host_unregister(void* p);
 int hexl_amd_pointer_kind(const void* p);
 
+/* Device buffers for callers without a HIP toolchain of their own (a HEXL maintainer's GPU
+ * branch, a cgo / JNI / ctypes host): the device-pointer entry points above are the throughput
+ * path, and these four calls are all it takes to use them.
+ *   hexl_amd_device_alloc   `bytes` of device memory on `device` (-1: the calling thread's current
+ *                           device)
+ *   hexl_amd_device_free
+ *   hexl_amd_copy           dst <- src, `bytes`; each side may be host, mapped or device memory
+ *                           (the direction is detected); enqueued on `stream` (NULL: the default
+ *                           stream) and complete on return when `blocking` is non-zero
+ *   hexl_amd_synchronize    waits for everything enqueued on `stream` (NULL: the whole device) */
+int hexl_amd_device_alloc(void** p, uint64_t bytes, int device);
+int hexl_amd_device_free(void* p);
+int hexl_amd_copy(void* dst, const void* src, uint64_t bytes, void* stream, int blocking);
+int hexl_amd_synchronize(void* stream);
+
 /* Debug contract: the reference's debug builds (HEXL_DEBUG) check every ELEMENT of an
  * operand against its bound and throw (HEXL_CHECK_BOUNDS, hexl/include/hexl/util/check.hpp:32-35;
  * hexl/ntt/ntt-internal.cpp:198, :261; hexl/eltwise/eltwise-mult-mod.cpp:31-33 and the other

@@ -250,6 +250,26 @@ static void test_ntt_map_extension() {
   NTT::ComputeInverseIndexed(ptrs.data(), K, idx.data(), got.data(), got.data(), comps * K, 1, 1);
   EXPECT(got == x);
   EXPECT_THROW(NTT::ComputeForwardMap(ptrs.data(), K, nullptr, K, 1, got.data(), x.data(), 1, 1, 1));
+  // the same on device buffers (DeviceMalloc / Copy: no HIP toolchain needed): one launch
+  // sequence over the interleaved layout, then a batch call and an element-wise op in place
+  const size_t bytes = x.size() * sizeof(uint64_t);
+  uint64_t* d = static_cast<uint64_t*>(DeviceMalloc(bytes));
+  Copy(d, x.data(), bytes);
+  NTT::ComputeForwardMap(ptrs.data(), K, tab, K, 1, d, d, comps * K, 1, 1);
+  V back(x.size());
+  Copy(back.data(), d, bytes);
+  EXPECT(back == want);
+  NTT::ComputeInverseIndexed(ptrs.data(), K, idx.data(), d, d, comps * K, 1, 1);
+  Copy(back.data(), d, bytes);
+  EXPECT(back == x);
+  EltwiseAddMod(d, d, d, N, primes[0]);  // first polynomial doubled mod its prime, on the device
+  Copy(back.data(), d, N * sizeof(uint64_t));
+  for (uint64_t j = 0; j < N; ++j)
+    if (back[j] != (2 * x[j]) % primes[0]) {
+      EXPECT(!"EltwiseAddMod on device memory");
+      break;
+    }
+  DeviceFree(d);
 }
 
 static void test_eltwise() {

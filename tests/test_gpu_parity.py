@@ -433,6 +433,32 @@ def test_pointer_kinds_and_zero_copy_host_path(hx, ho):
     assert bad.value == 0
 
 
+@pytest.mark.parametrize("n,batch,bits", [(4096, 1, 49), (4096, 8, 54), (16384, 2, 54), (16384, 3, 54),
+                                          (32768, 1, 54), (65536, 1, 54), (1024, 1, 35), (64, 3, 40)])
+def test_host_pointer_paths_on_ordinary_memory(hx, ho, n, batch, bits):
+    """The *_host entry points on ordinary (pageable) host memory, both sides of the 256 KiB
+    bounce-buffer threshold -- one-kernel and two-pass plans in place on the pinned mapped bounce
+    buffer below it, staged H2D / D2H above -- in place and out of place, against the oracle."""
+    import ctypes as C
+    q = ho.generate_primes(1, bits, True, n)[0]
+    ntt, ont = hx.NTT(n, q), ho.NTT(n, q)
+    x = np.stack([ho.fill_splitmix(n, 900 + b, q) for b in range(batch)])
+    want = ont.forward(x, 1, 1)
+    src, dst = x.copy(), np.zeros_like(x)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    assert hx.lib.hexl_amd_ntt_forward_host(ntt._h, p(dst), p(src), batch, 1, 1) == 0
+    assert np.array_equal(dst, want) and np.array_equal(src, x)
+    assert hx.lib.hexl_amd_ntt_inverse_host(ntt._h, p(dst), p(dst), batch, 1, 1) == 0  # in place
+    assert np.array_equal(dst, x)
+    # element-wise: MultMod (op 4) and FMAMod with a null addend (op 5), out of place / in place
+    a, b = x.reshape(-1).copy(), want.reshape(-1).copy()
+    r = np.zeros_like(a)
+    assert hx.lib.hexl_amd_eltwise_host(4, p(r), p(a), p(b), 0, a.size, q, 1, 1) == 0
+    assert np.array_equal(r, ho.eltwise_mult_mod(a, b, q, 1))
+    assert hx.lib.hexl_amd_eltwise_host(5, p(a), p(a), None, 7, a.size, q, 1, 1) == 0
+    assert np.array_equal(a, ho.eltwise_fma_mod(x.reshape(-1), 7, None, q, 1))
+
+
 def test_ntt_config1_on_the_hip_path(hx, ho):
     """BASELINE configs[0] at its exact parameters on the GPU: N = 1024, q = 0xffffee001
     (36-bit), ONE polynomial, seed 1, Fwd(1,1) + Inv(1,1) against the oracle; the plan picks

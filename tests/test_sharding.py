@@ -133,3 +133,38 @@ def test_bench_self_launcher_builds_the_rank_environment(tmp_path):
     subprocess.check_call(cmd, timeout=300)
     assert (tmp_path / "rank0").read_text() == "0 0 2 127.0.0.1"
     assert (tmp_path / "rank1").read_text() == "1 1 2 127.0.0.1"
+
+
+def test_bench_counter_profile_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
+    """bench.py reports the counter-derived figures (HBM bytes per launch, VALU busy, shader clock)
+    only when the committed profile was measured on the kernel sources of this checkout (round-2
+    advisor: a roofline fraction read from a stale profile does not follow code changes)."""
+    import json
+
+    import bench
+    assert bench.median([3.0, 1.0, 2.0]) == 2.0 and bench.median([4.0, 1.0, 2.0, 3.0]) == 2.5
+    h = bench.kernel_source_hash()
+    assert len(h) == 16 and h == bench.kernel_source_hash()
+    counters, note = bench.counter_profile()
+    committed = json.load(open(os.path.join(bench.ROOT, "profiles", bench.COUNTER_PROFILE)))
+    if committed["kernel_source_sha16"] == h:
+        assert counters["ntt_fwd_tile_pass_bottom"]["valu_busy"] > 0.5 and "these kernel sources" in note
+        for fam in ("ntt_fwd_strided_pass", "ntt_fwd_tile_pass_bottom", "ntt_inv_tile_pass_bottom",
+                    "ntt_inv_strided_pass"):
+            # one launch reads and writes 4096 polynomials of 512 KiB once: traffic ~ algorithmic bytes
+            assert abs(counters[fam]["hbm_bytes_per_launch"] / (16.0 * 65536 * 4096) - 1.0) < 0.01
+    else:
+        assert counters == {} and "other kernel sources" in note
+    # a profile of other sources is not reported
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    os.makedirs(tmp_path / "hexl_amd" / "csrc")
+    for name in bench.KERNEL_SOURCES:
+        (tmp_path / "hexl_amd" / "csrc" / name).write_text("// " + name)
+    (tmp_path / "profiles" / bench.COUNTER_PROFILE).write_text(json.dumps(
+        {"kernel_source_sha16": "0" * 16, "by_bench_kernel_family": {"k": {"valu_busy": 1.0}}}))
+    assert bench.counter_profile()[0] == {}
+    (tmp_path / "profiles" / bench.COUNTER_PROFILE).write_text(json.dumps(
+        {"kernel_source_sha16": bench.kernel_source_hash(),
+         "by_bench_kernel_family": {"k": {"valu_busy": 1.0}}}))
+    assert bench.counter_profile()[0] == {"k": {"valu_busy": 1.0}}

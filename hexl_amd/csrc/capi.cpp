@@ -1384,9 +1384,23 @@ int hexl_amd_key_switch_host(uint64_t* result, const uint64_t* t_target_iter_ptr
     return rc;
   int device = 0;
   HX_HIP(hipGetDevice(&device));
-  // staging: result (C D n) | target (D n) | D key blocks of C K n words
+  // staging: result (C D n) | target (D n) | D key blocks of C K n words.  The keys are the bulk
+  // of a call's bytes (n = 16384, 7 moduli: 14.7 MB against 0.9 MB of result) and long-lived on
+  // the caller's side: a key block that already IS device memory (uploaded once with
+  // hexl_amd_device_alloc + hexl_amd_copy, intel::hexl::DeviceMalloc + Copy) is used where it
+  // lies -- host result / target with device-resident keys is the cheap way to call this from
+  // an unmodified per-ciphertext loop.
   const size_t res_words = (size_t)C * D * n, key_words = (size_t)C * K * n;
-  if (int rc = g_staging.ensure(device, (res_words + D * n + D * key_words) * sizeof(u64)))
+  std::vector<const u64*> kp(D);
+  size_t host_keys = 0;
+  for (u64 j = 0; j < D; ++j) {
+    void* alias = nullptr;
+    if (pointer_kind(k_switch_keys[j], &alias) == 1)
+      kp[j] = (const u64*)alias;
+    else
+      ++host_keys;
+  }
+  if (int rc = g_staging.ensure(device, (res_words + D * n + host_keys * key_words) * sizeof(u64)))
     return rc;
   u64* d_res = (u64*)g_staging.buf;
   u64* d_tgt = d_res + res_words;
@@ -1394,11 +1408,12 @@ int hexl_amd_key_switch_host(uint64_t* result, const uint64_t* t_target_iter_ptr
   hipStream_t st = g_staging.stream;
   HX_HIP(hipMemcpyAsync(d_res, result, res_words * sizeof(u64), hipMemcpyHostToDevice, st));
   HX_HIP(hipMemcpyAsync(d_tgt, t_target_iter_ptr, D * n * sizeof(u64), hipMemcpyHostToDevice, st));
-  std::vector<const u64*> kp(D);
-  for (u64 j = 0; j < D; ++j) {
-    HX_HIP(hipMemcpyAsync(d_keys + j * key_words, k_switch_keys[j], key_words * sizeof(u64),
+  for (u64 j = 0, slot = 0; j < D; ++j) {
+    if (kp[j]) continue;
+    HX_HIP(hipMemcpyAsync(d_keys + slot * key_words, k_switch_keys[j], key_words * sizeof(u64),
                           hipMemcpyHostToDevice, st));
-    kp[j] = d_keys + j * key_words;
+    kp[j] = d_keys + slot * key_words;
+    ++slot;
   }
   if (int rc = key_switch_device(d_res, d_tgt, 1, n, D, K, R, C, moduli, kp.data(),
                                  modswitch_factors, st))

@@ -423,6 +423,8 @@ void KeySwitch(uint64_t* result, const uint64_t* t_target_iter_ptr, uint64_t n,
                const uint64_t* root_of_unity_powers_ptr) {
   if (root_of_unity_powers_ptr != nullptr)  // key-switch-internal.cpp:31-34
     throw std::invalid_argument("Parameter root_of_unity_powers_ptr is not supported yet.");
+  // (host result / target with device-resident keys goes through the host entry point, which
+  // uses such key blocks where they lie)
   const bool dev = on_device(result, t_target_iter_ptr,
                              k_switch_keys ? k_switch_keys[0] : nullptr);
   if (dev)

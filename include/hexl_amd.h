@@ -358,7 +358,10 @@ int hexl_amd_key_switch_batch(uint64_t* result, const uint64_t* t_target_iter_pt
                               uint64_t rns_modulus_size, uint64_t key_component_count,
                               const uint64_t* moduli, const uint64_t* const* k_switch_keys,
                               const uint64_t* modswitch_factors, void* stream);
-/* Same as hexl_amd_key_switch with host buffers everywhere (synchronous). */
+/* Same as hexl_amd_key_switch with host result / target buffers (synchronous).  Each key block
+ * k_switch_keys[j] may be host memory (copied to the device for the call) or device memory
+ * (used where it lies): the keys are the bulk of a call's bytes and long-lived, so a caller that
+ * uploads them once (hexl_amd_device_alloc + hexl_amd_copy) pays only for result and target. */
 int hexl_amd_key_switch_host(uint64_t* result, const uint64_t* t_target_iter_ptr,
                              uint64_t n, uint64_t decomp_modulus_size,
                              uint64_t key_modulus_size, uint64_t rns_modulus_size,

@@ -1314,6 +1314,42 @@ def test_workspaces_can_be_released(hx, ho):
             assert hx.lib.hexl_amd_release_workspaces() == 0
 
 
+def test_key_switch_host_with_device_resident_keys(hx, ho):
+    """hexl_amd_key_switch_host: host result / target; key blocks on the host (copied per call), on
+    the device (uploaded once, used where they lie) or mixed -- the same bits as the oracle."""
+    import ctypes as C
+    import time
+    n, D, K, C_ = 8192, 4, 5, 2
+    rng = np.random.default_rng(31)
+    moduli = [int(q) for q in ho.generate_primes(K, 54, True, n)]
+    keys = [np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                            for _ in range(C_) for i in range(K)]) for _ in range(D)]
+    msf = [int(rng.integers(1, moduli[i], dtype=np.uint64)) for i in range(D)]
+    target = np.concatenate([rng.integers(0, moduli[j], n, dtype=np.uint64) for j in range(D)])
+    result = np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                             for _ in range(C_) for i in range(D)])
+    want = ho.key_switch(result, target, n, D, K, D + 1, C_, moduli, keys, msf)
+    mod = (C.c_uint64 * K)(*moduli)
+    fac = (C.c_uint64 * D)(*msf)
+    d_keys = [dev(hx, k) for k in keys]
+    p = lambda a: a.ctypes.data_as(C.c_void_p).value  # noqa: E731
+    times = {}
+    for label, ptrs in (("host keys", [p(k) for k in keys]),
+                        ("device keys", [k.data_ptr() for k in d_keys]),
+                        ("mixed", [p(keys[0]), d_keys[1].data_ptr(), p(keys[2]), d_keys[3].data_ptr()])):
+        kp = (C.c_void_p * D)(*ptrs)
+        for rep in range(3):
+            r = result.copy()
+            t0 = time.perf_counter()
+            rc = hx.lib.hexl_amd_key_switch_host(r.ctypes.data_as(C.c_void_p),
+                                                 target.ctypes.data_as(C.c_void_p), n, D, K, D + 1,
+                                                 C_, mod, C.cast(kp, C.POINTER(C.c_void_p)), fac)
+            times[label] = time.perf_counter() - t0
+            assert rc == 0, hx.lib.hexl_amd_last_error()
+            assert np.array_equal(r, want), label
+    print("KeySwitch from host buffers, n=8192 D=4:", {k: f"{v * 1e6:.0f} us" for k, v in times.items()})
+
+
 def test_key_switch_two_streams_do_not_share_scratch(hx, ho):
     """KeySwitch calls issued from one thread on two streams overlap on the device; their
     scratch (coefficient-form targets, operand transforms, products) is keyed by stream, so

@@ -643,7 +643,12 @@ constexpr int kMaxTileLog = 14;
 // round of every (S, CB) geometry is bank-conflict free (simulated for all
 // patterns; SQ_LDS_BANK_CONFLICT confirms).  No padding: the tile is exactly
 // 32 KiB, four workgroups = 32 waves per CU.
-__device__ __forceinline__ u32 lds_slot(u32 p) {
+// RE = log2 elements per thread.  The 16-element geometry (rounds of 4 stages: lane strides of
+// 16 slots, runs of 16 lanes 256 slots apart, contiguous runs) has its own swizzle; with the
+// 8-element one its two deepest rounds ran with two-way conflicts on every access.
+template <int RE>
+__device__ __forceinline__ constexpr u32 lds_slot(u32 p) {
+  if (RE == 4) return p ^ ((p >> 4) & 63);
   return p ^ ((p >> 3) & 7) ^ (((p >> 6) & 7) << 3);
 }
 
@@ -785,9 +790,9 @@ __device__ __forceinline__ void lds_load_round(u64* x, u64* lds, u32 tid) {
   constexpr int kThreads = 1 << (TL - kRE);
 #pragma unroll
   for (int s = 0; s < SS; ++s) {
-    const u32 a0 = lds_slot(tile_index<r, w>(s * kThreads + tid, 0)) << 3;
+    const u32 a0 = lds_slot<kRE>(tile_index<r, w>(s * kThreads + tid, 0)) << 3;
 #pragma unroll
-    for (int e = 0; e < (1 << r); ++e) x[(s << r) + e] = lds_at(lds, a0 ^ (lds_slot((u32)e << w) << 3));
+    for (int e = 0; e < (1 << r); ++e) x[(s << r) + e] = lds_at(lds, a0 ^ (lds_slot<kRE>((u32)e << w) << 3));
   }
 }
 
@@ -799,9 +804,9 @@ __device__ __forceinline__ void lds_store_round(const u64* x, u64* lds, u32 tid)
   constexpr int kThreads = 1 << (TL - kRE);
 #pragma unroll
   for (int s = 0; s < SS; ++s) {
-    const u32 a0 = lds_slot(tile_index<r, w>(s * kThreads + tid, 0)) << 3;
+    const u32 a0 = lds_slot<kRE>(tile_index<r, w>(s * kThreads + tid, 0)) << 3;
 #pragma unroll
-    for (int e = 0; e < (1 << r); ++e) lds_at(lds, a0 ^ (lds_slot((u32)e << w) << 3)) = x[(s << r) + e];
+    for (int e = 0; e < (1 << r); ++e) lds_at(lds, a0 ^ (lds_slot<kRE>((u32)e << w) << 3)) = x[(s << r) + e];
   }
 }
 
@@ -940,6 +945,7 @@ __device__ __forceinline__ void inv_mid_rounds(u64* x, u64* lds, const TwT<A>* t
       // the next (shallower) round J-1 regroups across waves iff its gap exceeds a wave
       handover<RD::w(J - 1), RD::r(J - 1) == kRE>();
     }
+    HX_STAMP(3 + (RD::NR - 1 - J));
     inv_mid_rounds<S, CB, TL, J - 1, A, CTW>(x, lds, tw, tid, g, m, il, wn, pre0);
   }
 }
@@ -1049,10 +1055,10 @@ __device__ __forceinline__ void fwd_copy_out(u64* lds, u64* out, u32 tid, const 
                                              u64 total, const ModConst& m) {
   constexpr int kE = el_of(S);
   u64 v[kE];
-  u32 a0 = lds_slot(xfer_p0<false, S, CB, TL>(tid, 0)) << 3;
+  u32 a0 = lds_slot<re_of(S)>(xfer_p0<false, S, CB, TL>(tid, 0)) << 3;
   HX_OPAQUE(a0);  // one v_xor per access (else: the swizzle redone and shifted per element)
 #pragma unroll
-  for (int i = 0; i < kE; ++i) v[i] = lds_at(lds, a0 ^ (lds_slot(xfer_dp<false, S, CB>(i)) << 3));
+  for (int i = 0; i < kE; ++i) v[i] = lds_at(lds, a0 ^ (lds_slot<re_of(S)>(xfer_dp<false, S, CB>(i)) << 3));
 #pragma unroll
   for (int i = 0; i < kE; ++i) {
     if (FIN)
@@ -1154,17 +1160,21 @@ __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
       fetch_tile<false, S, CB, TL, GUARD, A, LDK>(x, in, tid, g, total, flags, m);
     }
     __builtin_amdgcn_s_setprio(0);
+    HX_PROFILE_WAIT_VMEM();
+    HX_STAMP(1);
     {
-      const u32 a0 = lds_slot(xfer_p0<false, S, CB, TL>(tid, 0)) << 3;
+      const u32 a0 = lds_slot<re_of(S)>(xfer_p0<false, S, CB, TL>(tid, 0)) << 3;
 #pragma unroll
-      for (int i = 0; i < kE; ++i) lds_at(lds, a0 ^ (lds_slot(xfer_dp<false, S, CB>(i)) << 3)) = x[i];
+      for (int i = 0; i < kE; ++i) lds_at(lds, a0 ^ (lds_slot<re_of(S)>(xfer_dp<false, S, CB>(i)) << 3)) = x[i];
     }
     handover<RD::w(NR - 1), RD::r(NR - 1) == kRE>();
+    HX_STAMP(2);
     inv_mid_rounds<S, CB, TL, NR - 1, A, CTW>(x, lds, tw, tid, g, m, il, wtop, w0);
     {
       if constexpr (!RD::pre_inv(0)) round_twiddles<S, CB, TL, 0, CTW>(w0, tw, tid, g);
       lds_load_round<S, CB, TL, 0>(x, lds, tid);
       round_compute<S, CB, 0, A, false, LAST>(x, w0, m, il);
+      HX_STAMP(7);
       if (finish == 2) {
 #pragma unroll
         for (int i = 0; i < kE; ++i) x[i] = inv_finish<A>(x[i], m, true);
@@ -1174,6 +1184,9 @@ __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
       }
 #pragma unroll
       for (int i = 0; i < kE; ++i) store_elem<true, S, CB, TL, GUARD, STK>(out, tid, i, x[i], g, total);
+      HX_STAMP(8);
+      HX_PROFILE_WAIT_VMEM();
+      HX_STAMP(9);
     }
   }
 }
@@ -1189,9 +1202,13 @@ tile_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst m
   // inverse +65 / +53 % slower, round 3.  And a tile-index-major order -- consecutive workgroups
   // take the same tile of consecutive polynomials, everything in flight sharing one set of
   // per-lane twiddles (31.5 KiB: L1-resident): forward +1 %, inverse +8 % slower, round 3.)
-  // forward: streamed loads and stores; inverse: plain (see ld_global)
-  tile_body<FWD, S, CB, TL, GUARD, A, LAST, FWD ? kStream : kPlain, FWD ? kStream : kPlain>(
-      lds, out, in, tw, m, log_n, flags, total, il, blockIdx.x);
+  // forward: streamed loads and stores; inverse followed by a strided pass: plain (see ld_global)
+  // (an inverse pass that ends the transform -- the one-kernel plans, N <= 2^14 -- streams too:
+  // 2-7 % at 1 GiB batches, round 3; its stores through an LDS copy-out, tile-contiguous per
+  // wave like the forward's: slower; its data loads ahead of its twiddle loads: no effect)
+  constexpr int kKind = (FWD || (LAST && CB == 0)) ? kStream : kPlain;
+  tile_body<FWD, S, CB, TL, GUARD, A, LAST, kKind, kKind>(lds, out, in, tw, m, log_n, flags, total, il,
+                                                          blockIdx.x);
 }
 
 // Bottom pass over polynomials of several moduli (see strided_pass_multi); N >= 2^TL, so

@@ -6,6 +6,7 @@
 #      prescribes): FETCH_SIZE, WRITE_SIZE, SQ issue counters, LDS counters
 #   3. the same FETCH/WRITE passes over tools/ubench's copy kernels (known traffic)
 #      to calibrate the counters
+# Every pass runs under its own `timeout` (a counter pass that hangs must not eat the GPU budget).
 # Summarise afterwards with tools/summarize_profiles.py (runs anywhere).
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
@@ -13,13 +14,13 @@ OUT=$REPO/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- \
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- \
   python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_under_trace.json 2> $OUT/trace.log
 run_pmc() {  # name, counters..., then -- command
   local name=$1; shift
   local ctr=()
   while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
-  rocprofv3 --pmc "${ctr[@]}" --output-format csv -d $OUT/$name -o p -- "$@" > /dev/null 2> $OUT/$name.log
+  timeout 300 rocprofv3 --pmc "${ctr[@]}" --output-format csv -d $OUT/$name -o p -- "$@" > /dev/null 2> $OUT/$name.log
 }
 run_pmc fetch FETCH_SIZE -- $BENCH
 run_pmc write WRITE_SIZE -- $BENCH

@@ -50,7 +50,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 # by tools/summarize_profiles.py together with a hash of the kernel sources they were measured
 # on.  They are NOT collected in this run; a profile of other sources is not reported.
 COUNTER_PROFILE = "r3_counters.json"
-KERNEL_SOURCES = ("ntt_kernels.hip", "modarith.h", "internal.h")
+KERNEL_SOURCES = ("ntt_kernels.hip", "modarith.h", "tile_geometry.h", "internal.h")
 # what keeps each kernel family below the HBM roofline (profiles/r3_pmc_summary.md)
 KERNEL_LIMITER = {"ntt_fwd_strided_pass": "hbm", "ntt_inv_strided_pass": "hbm",
                   "ntt_fwd_tile_pass_bottom": "valu-issue + latency",

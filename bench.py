@@ -430,6 +430,22 @@ def main():
     # fraction of the 8 TB/s HBM peak (algorithmic bytes: SURVEY.md 8d / BASELINE.md 4).
     mult = None
     secondary = None
+    copy_gbps = None
+    if rank == 0 and not args.no_secondary:
+        # what a plain device-to-device copy of the same batch sustains on this box (read + write
+        # bytes / median event time of 10): the practical ceiling SURVEY.md 8d asks the HBM
+        # fractions to be quoted against as well
+        dst = torch.empty_like(data)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(12)]
+        for a, b in evs:
+            a.record()
+            dst.copy_(data)
+            b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in evs[2:])
+        copy_gbps = 2.0 * data.numel() * 8 / (ms[len(ms) // 2] * 1e-3) / 1e9
+        del dst
+        torch.cuda.empty_cache()
     if rank == 0 and batch == BATCH and not args.no_secondary:
         mult = timed_eltwise(hx, torch, "EltwiseMultMod(input_mod_factor=1)", N, batch, PRIMES[0])
     if rank == 0 and world == 1 and batch == BATCH and not args.no_secondary and not strong:
@@ -465,6 +481,8 @@ def main():
                 "bound": "hbm", "kernel": dominant, "achieved": achieved,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic, "traffic_source": counters_note,
+                "copy_GBps_measured": copy_gbps,
+                "frac_of_measured_copy": (achieved / copy_gbps) if copy_gbps else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_kernel_ms": kern_avg, "median_kernel_ms": kern_med,
                 # both rooflines per kernel: HBM (algorithmic bytes / event time, this run) and

@@ -79,3 +79,30 @@ def test_cpp_debug_contract_on_gpu():
     r = subprocess.run([DBG_EXE], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all debug-contract checks passed" in r.stdout
+
+
+REF_EXAMPLE_SRC = "/root/reference/example/example.cpp"
+REF_EXAMPLE_EXE = os.path.join(ROOT, "oracle", "_ref", "hexl_example")
+
+
+def test_reference_example_compiles_unmodified():
+    """CPU, in the build container only: the reference's own example program
+    (example/example.cpp: every Eltwise* entry point and an NTT round trip through
+    "hexl/hexl.hpp") compiles and links, unmodified and where it lies, against this repo's
+    headers and libhexl.so (oracle/Makefile `ref-example`; nothing of it enters the repo)."""
+    if not os.path.exists(REF_EXAMPLE_SRC):
+        pytest.skip("reference tree not present")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "ref-example"])
+    assert os.path.exists(REF_EXAMPLE_EXE)
+
+
+@pytest.mark.gpu
+def test_reference_example_runs_on_gpu():
+    """The binary built above runs on the GPU: its eight examples complete and none of its own
+    comparisons against the reference's expected vectors reports a mismatch."""
+    if not os.path.exists(REF_EXAMPLE_EXE):
+        pytest.skip("oracle/_ref/hexl_example was not built (needs the reference tree at build time)")
+    r = subprocess.run([REF_EXAMPLE_EXE], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Not equal" not in r.stdout, r.stdout
+    assert r.stdout.count("Done running") == 8, r.stdout

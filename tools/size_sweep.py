@@ -3,7 +3,8 @@ arithmetic policy, batches of a fixed number of bytes resident in HBM (default 1
 forward / inverse pass over the batch, launches per transform, algorithmic GB/s (16 N bytes per
 transform: one read and one write of the polynomial) and its fraction of the 8 TB/s peak.  Prints a
 markdown table ("prime bits" b = the first prime GeneratePrimes(1, b, true, N) returns, in (2^b, 2^(b+1)):
-Small, Fp64, Lazy, Harvey60 and Strict arithmetic); times are HIP-event medians taken by the library's own launch profiler."""
+Small, Fp64, Lazy, Harvey60 and Strict arithmetic); times are HIP-event medians taken by the library's own launch profiler after a
+150 ms warm-up of the same call."""
 import os
 import statistics
 import sys
@@ -16,13 +17,20 @@ import hexl_amd as hx  # noqa: E402
 BYTES = int(os.environ.get("SWEEP_MIB", "1024")) << 20
 BITS = [int(b) for b in os.environ.get("SWEEP_BITS", "28,49,55,60,61").split(",")]
 LOGN = range(int(os.environ.get("SWEEP_LOGN_MIN", "10")), int(os.environ.get("SWEEP_LOGN_MAX", "20")) + 1)
-REPS = 7
+REPS = 15
+WARM_MS = float(os.environ.get("SWEEP_WARM_MS", "150"))
 
 
 def timed(fn):
-    """Median over REPS of the summed kernel time of one call (ms) and the launches per call."""
-    fn()
-    torch.cuda.synchronize()
+    """Median over REPS of the summed kernel time of one call (ms) and the launches per call.  The
+    call is first repeated for WARM_MS of wall time: a burst that starts from an idle GPU runs its
+    first tens of milliseconds below the sustained rate (clock ramp), up to 15 % at these sizes."""
+    import time
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < WARM_MS:
+        for _ in range(4):
+            fn()
+        torch.cuda.synchronize()
     hx.profile_start(4096)
     for _ in range(REPS):
         fn()

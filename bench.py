@@ -322,27 +322,20 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # Dry-run hooks for a 1-GPU box (tests of the multi-rank code path): BENCH_ONE_DEVICE=1
-    # puts every rank on cuda:0, BENCH_BACKEND=gloo replaces RCCL for the barrier / max.
-    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    # puts every rank on cuda:0, BENCH_BACKEND=gloo skips the RCCL probe.
+    from hexl_amd.sharding import job_partition, rendezvous
     if os.environ.get("BENCH_ONE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    # The ranks meet for a barrier and two scalar reductions only (no data-path collective):
+    # gloo is always there, RCCL is used when -- and only when -- every rank brought it up
+    # (hexl_amd/sharding.py: rendezvous); the line says which in "rendezvous".
+    rv = rendezvous(rank, world, local_rank, prefer=os.environ.get("BENCH_BACKEND", "nccl"))
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        rv.barrier()
         torch.cuda.synchronize()
 
-    from hexl_amd.sharding import gather_over_ranks, job_partition, max_over_ranks
 
     # The job: weak = `world` primes x `batch` polynomials (rank g owns prime g); strong =
     # the 8 primes x `batch` polynomials of configs[3] whatever `world` is.  Either way the flat
@@ -397,11 +390,10 @@ def main():
     # fwd followed by inv is the identity: the data must be back where it started
     assert torch.equal(check, data[:2]), "round trip mismatch inside the timed region"
 
-    dev = "cuda" if backend == "nccl" else "cpu"
     my_rate = 2 * my_polys * args.steps / elapsed
-    per_rank = gather_over_ranks(my_rate, dist, device=dev)
-    median_ms = max_over_ranks(median(step_ms), dist, device=dev)
-    elapsed = max_over_ranks(elapsed, dist, device=dev)
+    per_rank = rv.gather(my_rate)
+    median_ms = rv.max(median(step_ms))
+    elapsed = rv.max(elapsed)
 
     total_polys = num_primes * batch
     ntts = 2 * total_polys * args.steps
@@ -464,6 +456,10 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "per_rank_NTT_per_s": per_rank,
+            # what the ranks met on for the barrier and the scalar reductions (no data-path
+            # collective): "nccl" (= RCCL), "gloo" (RCCL unavailable / failed its probe: why is in
+            # rendezvous_note), "none" (one process)
+            "launcher": "processes", "rendezvous": rv.backend or "none", "rendezvous_note": rv.note,
             "config": {
                 "workload": (("BASELINE configs[3]: in-place ForwardNTT(1,1) + InverseNTT(1,1), N=65536, "
                               f"8 RNS primes (55-bit) x {batch} polynomials = {total_polys} transforms per "
@@ -512,8 +508,7 @@ def main():
         elif world > 1:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    rv.close()
 
 
 if __name__ == "__main__":

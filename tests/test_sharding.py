@@ -106,6 +106,48 @@ def test_two_rank_gloo_partition_matches_single_process(tmp_path, world):
     assert (got == np.stack(ref)).all()
 
 
+def _rendezvous_worker(rank, world, port, out_dir, prefer):
+    from hexl_amd.sharding import rendezvous
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    rv = rendezvous(rank, world, local_rank=rank, prefer=prefer, probe_seconds=5.0)
+    rv.barrier()
+    slowest = rv.max(10.0 + rank)
+    rates = rv.gather(100.0 * (rank + 1))
+    with open(os.path.join(out_dir, f"rv{rank}"), "w") as f:
+        f.write(repr((rv.backend, rv.note, slowest, rates)))
+    rv.barrier()
+    rv.close()
+
+
+@pytest.mark.parametrize("prefer", ["nccl", "gloo"])
+def test_rendezvous_falls_back_to_gloo_when_rccl_cannot_come_up(tmp_path, prefer):
+    """bench.py's ranks meet through hexl_amd.sharding.rendezvous: RCCL when every rank brings
+    it up, otherwise gloo BY ITSELF (round-3 review: an RCCL init failure must not lose the
+    scaling run of a collective-free job).  Here there is no GPU, so asking for "nccl" has to
+    end on gloo with the reason recorded, on every rank alike, and the barrier and the two
+    reductions bench.py uses must work."""
+    import ast
+
+    import torch.multiprocessing as mp
+    port = 31000 + (os.getpid() % 2000) + (7 if prefer == "gloo" else 0)
+    mp.spawn(_rendezvous_worker, args=(2, port, str(tmp_path), prefer), nprocs=2, join=True)
+    for rank in range(2):
+        backend, note, slowest, rates = ast.literal_eval((tmp_path / f"rv{rank}").read_text())
+        assert backend == "gloo"
+        assert slowest == 11.0 and rates == [100.0, 200.0]
+        if prefer == "nccl":
+            assert note and ("GPU" in note or "NCCL" in note or "RCCL" in note), note
+        else:
+            assert note == "gloo requested"
+    # one process: nothing to meet on
+    from hexl_amd.sharding import rendezvous
+    rv = rendezvous(0, 1)
+    assert rv.backend is None and rv.max(3.0) == 3.0 and rv.gather(2.0) == [2.0]
+    rv.barrier()
+    rv.close()
+
+
 def test_bench_self_launcher_builds_the_rank_environment(tmp_path):
     """`python bench.py --gpus N` outside torchrun re-runs itself under
     torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1; the ranks see

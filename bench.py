@@ -291,6 +291,61 @@ def launcher_command(gpus, argv, port=None):
             "--master-port", str(port or free_port()), os.path.abspath(__file__)] + list(argv)
 
 
+MULTI_DEVICE_BIN = os.path.join(ROOT, "tests", "cpp", "multi_device")
+
+
+def run_multi_device(devices, scaling, steps, warmup, batch=BATCH, n=N, timeout=900):
+    """tests/cpp/multi_device: ONE process, one std::thread + stream + plans per GPU over the
+    C-ABI alone (what a C++ caller of the reference does).  Returns its JSON."""
+    import subprocess
+    if not os.path.exists(MULTI_DEVICE_BIN):
+        raise SystemExit(f"{MULTI_DEVICE_BIN} is missing: python -c 'import __graft_entry__ as g; g.build()'")
+    cmd = [MULTI_DEVICE_BIN, "--devices", ",".join(str(d) for d in devices), "--scaling", scaling,
+           "--n", str(n), "--batch", str(batch), "--primes", str(len(PRIMES)), "--bits", "54",
+           "--steps", str(steps), "--warmup", str(warmup)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+    try:
+        out = json.loads(line)
+    except ValueError:
+        raise SystemExit(f"multi_device failed (rc {r.returncode}): {r.stdout[-500:]} {r.stderr[-500:]}")
+    if not out.get("ok"):
+        raise SystemExit(f"multi_device: {out.get('error')}")
+    return out
+
+
+def threads_main(args):
+    """--launcher threads: the same job as the one-process-per-GPU launcher, driven from ONE
+    process through the C-ABI (tests/cpp/multi_device.cpp), same JSON shape."""
+    devices = [0] * args.gpus if os.environ.get("BENCH_ONE_DEVICE") == "1" else list(range(args.gpus))
+    md = run_multi_device(devices, args.scaling, args.steps, args.warmup + PREWARM // 2, batch=args.batch)
+    strong = args.scaling == "strong"
+    total = md["polynomials_total"]
+    print(json.dumps({
+        "metric": "Fwd+Inv NTTs/sec, N=65536 q~55b batch=4096",
+        "value": md["value"], "unit": "NTT/s", "n_gpus": args.gpus, "steps": args.steps,
+        "warmup": args.warmup, "prewarm_steps": PREWARM // 2, "ms_per_step": md["ms_per_step"],
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u64",
+        "data": "synthetic", "per_rank_NTT_per_s": md["per_rank_NTT_per_s"],
+        "launcher": "threads", "rendezvous": "none", "rendezvous_note": "one process: std::thread per GPU",
+        "devices": md["devices"], "visible_devices": md["visible_devices"],
+        "verified": {"probe_polynomials_compared": md["probe_polynomials_compared"],
+                     "probe_mismatches": md["probe_mismatches"], "ref_device": md["ref_device"]},
+        "config": {
+            "workload": (("BASELINE configs[3]: in-place ForwardNTT(1,1) + InverseNTT(1,1), N=65536, "
+                          f"8 RNS primes (55-bit) x {args.batch} polynomials = {total} transforms per "
+                          f"direction, sharded over {args.gpus} GPU(s), resident in HBM") if strong else
+                         ("in-place ForwardNTT(1,1) + InverseNTT(1,1), N=65536, "
+                          f"55-bit prime per GPU, batch={args.batch} polys per GPU resident in HBM")),
+            "N": N, "batch_per_gpu": md["per_rank_polynomials"][0], "modulus_bits": 55,
+            "polynomials_total": total,
+            "parallelism": (f"{args.scaling} scaling: flat (prime, polynomial) index sharded x{args.gpus}, "
+                            "one host thread + stream + plans per GPU in one process (C-ABI), no collectives")},
+        "hbm_algorithmic_GBps": md["value"] * 16.0 * N / 1e9,
+        "roofline": None, "cpu_baseline": None,
+    }))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -300,11 +355,20 @@ def main():
                     default=os.environ.get("BENCH_SCALING", "weak"),
                     help="multi-GPU job: weak = one prime x 4096 polynomials per GPU (default); "
                          "strong = always 8 primes x 4096 polynomials, sharded over the GPUs")
+    ap.add_argument("--launcher", choices=("processes", "threads"),
+                    default=os.environ.get("BENCH_LAUNCHER", "processes"),
+                    help="processes (default): one process per GPU under torch.distributed.run; "
+                         "threads: one process, one std::thread + stream + plans per GPU over the "
+                         "C-ABI (tests/cpp/multi_device.cpp)")
     ap.add_argument("--batch", type=int, default=BATCH, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-secondary", action="store_true", help=argparse.SUPPRESS)  # profile runs
     args = ap.parse_args()
 
+    if args.launcher == "threads":
+        if int(os.environ.get("RANK", "0")) == 0:  # (under torchrun: rank 0 drives all devices)
+            threads_main(args)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not under a launcher: spawn the ranks ourselves; rank 0's JSON line passes through
         import subprocess

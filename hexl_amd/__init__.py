@@ -128,6 +128,10 @@ def _load():
     sig("hexl_amd_device_free", ci, vp)
     sig("hexl_amd_copy", ci, vp, vp, u64, vp, ci)
     sig("hexl_amd_synchronize", ci, vp)
+    sig("hexl_amd_set_device", ci, ci)
+    sig("hexl_amd_get_device", ci, C.POINTER(ci))
+    sig("hexl_amd_stream_create", ci, C.POINTER(vp), ci)
+    sig("hexl_amd_stream_destroy", ci, vp)
     sig("hexl_amd_release_stream_workspaces", ci, vp)
     sig("hexl_amd_release_workspaces", ci)
     return lib
@@ -160,7 +164,8 @@ C_ABI_SYMBOLS = [
     "hexl_amd_release_workspaces", "hexl_amd_host_alloc", "hexl_amd_host_free",
     "hexl_amd_host_register", "hexl_amd_host_unregister", "hexl_amd_pointer_kind",
     "hexl_amd_check_bounds", "hexl_amd_device_alloc", "hexl_amd_device_free", "hexl_amd_copy",
-    "hexl_amd_synchronize",
+    "hexl_amd_synchronize", "hexl_amd_set_device", "hexl_amd_get_device",
+    "hexl_amd_stream_create", "hexl_amd_stream_destroy",
 ]
 
 

@@ -53,7 +53,11 @@ struct DeviceScope {
   int prev = -1;
   bool switched = false;
   hipError_t err = hipSuccess;
-  explicit DeviceScope(int device) {
+  DeviceScope() = default;
+  explicit DeviceScope(int device) { enter(device); }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+  void enter(int device) {
     err = hipGetDevice(&prev);
     if (err == hipSuccess && prev != device) {
       err = hipSetDevice(device);
@@ -64,6 +68,25 @@ struct DeviceScope {
     if (switched) (void)hipSetDevice(prev);
   }
 };
+
+// The device a launch on `st` runs on: the stream's own, or the calling thread's current
+// device for the default stream(s).
+hipError_t stream_device(hipStream_t st, int* device) {
+  if (st == nullptr || st == hipStreamPerThread || st == hipStreamLegacy) return hipGetDevice(device);
+  return hipStreamGetDevice(st, device);
+}
+// Makes the device that owns `st` current for the scope (every stream-taking entry point
+// without a plan: a worker thread of a multi-GPU caller need not set a current device).
+struct StreamDeviceScope : DeviceScope {
+  int device = 0;
+  explicit StreamDeviceScope(hipStream_t st) {
+    err = stream_device(st, &device);
+    if (err == hipSuccess) enter(device);
+  }
+};
+#define HX_ON_STREAM_DEVICE(st)                          \
+  StreamDeviceScope stream_scope_((hipStream_t)(st));    \
+  if (stream_scope_.err != hipSuccess) return hip_fail(stream_scope_.err, "selecting the stream's device")
 
 // Per-thread staging buffers for the host-pointer entry points.
 struct Staging {
@@ -179,8 +202,9 @@ int hexl_amd_device_count(int* count) {
 // 0 = ordinary host memory (or unknown), 1 = device / managed memory, 2 = pinned host memory
 // mapped into the device's address space (hipHostMalloc / hipHostRegister: kernels can read
 // and write it over the link).  *dev_alias: the address kernels use (kinds 1 and 2).
-static int pointer_kind(const void* p, void** dev_alias) {
+static int pointer_kind(const void* p, void** dev_alias, int* owner = nullptr) {
   if (dev_alias) *dev_alias = nullptr;
+  if (owner) *owner = -1;
   if (!p) return 0;
   hipPointerAttribute_t attr;
   hipError_t e = hipPointerGetAttributes(&attr, p);
@@ -190,6 +214,7 @@ static int pointer_kind(const void* p, void** dev_alias) {
   }
   if (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged) {
     if (dev_alias) *dev_alias = const_cast<void*>(p);
+    if (owner) *owner = attr.device;  // the device the allocation lives on
     return 1;
   }
   if (attr.type == hipMemoryTypeHost && attr.devicePointer) {
@@ -200,6 +225,23 @@ static int pointer_kind(const void* p, void** dev_alias) {
     return 2;
   }
   return 0;
+}
+
+// Kind of the whole range [p, p + bytes): 2 only if its LAST byte is mapped too and maps to
+// the alias of the first plus the same offset (a buffer that starts inside a registered pool
+// and runs past its end, or straddles two registrations, is ordinary host memory to the
+// zero-copy paths: they stage it instead of faulting on the device); 1 likewise for device
+// memory; otherwise 0.
+static int range_kind(const void* p, size_t bytes, void** dev_alias) {
+  const int k = pointer_kind(p, dev_alias);
+  if (k == 0 || bytes <= 1) return k;
+  void* last_alias = nullptr;
+  const int kl = pointer_kind((const char*)p + bytes - 1, &last_alias);
+  if (kl != k || (char*)last_alias - (char*)*dev_alias != (ptrdiff_t)(bytes - 1)) {
+    if (dev_alias) *dev_alias = nullptr;
+    return 0;
+  }
+  return k;
 }
 
 int hexl_amd_pointer_is_device(const void* p) { return pointer_kind(p, nullptr) == 1 ? 1 : 0; }
@@ -246,8 +288,37 @@ int hexl_amd_device_free(void* p) {
 int hexl_amd_copy(void* dst, const void* src, uint64_t bytes, void* stream, int blocking) {
   if (bytes == 0) return HEXL_AMD_OK;
   if (!dst || !src) return fail(HEXL_AMD_ERR_INVALID_ARG, "dst == nullptr or src == nullptr");
+  HX_ON_STREAM_DEVICE(stream);
   HX_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDefault, (hipStream_t)stream));
   if (blocking) HX_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return HEXL_AMD_OK;
+}
+int hexl_amd_set_device(int device) {
+  HX_HIP(hipSetDevice(device));
+  return HEXL_AMD_OK;
+}
+int hexl_amd_get_device(int* device) {
+  if (!device) return fail(HEXL_AMD_ERR_INVALID_ARG, "device == nullptr");
+  HX_HIP(hipGetDevice(device));
+  return HEXL_AMD_OK;
+}
+int hexl_amd_stream_create(void** stream, int device) {
+  if (!stream) return fail(HEXL_AMD_ERR_INVALID_ARG, "stream == nullptr");
+  *stream = nullptr;
+  if (device < 0) HX_HIP(hipGetDevice(&device));
+  DeviceScope scope(device);
+  if (scope.err != hipSuccess) return hip_fail(scope.err, "hipSetDevice");
+  hipStream_t st = nullptr;
+  HX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  *stream = (void*)st;
+  return HEXL_AMD_OK;
+}
+int hexl_amd_stream_destroy(void* stream) {
+  if (!stream) return HEXL_AMD_OK;
+  HX_ON_STREAM_DEVICE(stream);
+  HX_HIP(hipStreamSynchronize((hipStream_t)stream));
+  release_stream_workspaces((hipStream_t)stream);
+  HX_HIP(hipStreamDestroy((hipStream_t)stream));
   return HEXL_AMD_OK;
 }
 int hexl_amd_synchronize(void* stream) {
@@ -265,15 +336,21 @@ int hexl_amd_check_bounds(const uint64_t* data, uint64_t n, uint64_t bound,
   if (n == 0) return HEXL_AMD_OK;
   if (!data) return fail(HEXL_AMD_ERR_INVALID_ARG, "data == nullptr");
   void* alias = nullptr;
-  const int kind = pointer_kind(data, &alias);
+  int owner = -1;
+  const int kind = pointer_kind(data, &alias, &owner);
   if (kind == 0) {  // the caller's own host buffer: validating it is not computing on it
     uint64_t bad = 0;
     for (uint64_t i = 0; i < n; ++i) bad += data[i] >= bound;
     *violations = bad;
     return HEXL_AMD_OK;
   }
+  // the reduction kernel runs on the device that owns the data (mapped host memory: the
+  // calling thread's current device)
   int device = 0;
   HX_HIP(hipGetDevice(&device));
+  if (kind == 1 && owner >= 0) device = owner;
+  DeviceScope scope(device);
+  if (scope.err != hipSuccess) return hip_fail(scope.err, "hipSetDevice");
   if (int rc = g_staging.ensure(device, sizeof(unsigned long long))) return rc;
   unsigned long long* counter = (unsigned long long*)g_staging.buf;
   hipStream_t st = g_staging.stream;
@@ -779,7 +856,8 @@ static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t*
   // launch, one synchronisation; a multi-pass transform reads the operand in its first pass
   // (no H2D copy) and copies the result back.
   void *op_dev = nullptr, *res_dev = nullptr;
-  const int op_kind = pointer_kind(operand, &op_dev), res_kind = pointer_kind(result, &res_dev);
+  const int op_kind = range_kind(operand, bytes, &op_dev),
+            res_kind = range_kind(result, bytes, &res_dev);
   if (op_kind == 2 && (bytes < host_pipeline_min_bytes() || batch < 4)) {
     if (int rc = g_staging.ensure(p->device, 8)) return rc;  // (the stream)
     hipStream_t st = g_staging.stream;
@@ -801,7 +879,8 @@ static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t*
     HX_HIP(hipStreamSynchronize(st));
     return HEXL_AMD_OK;
   }
-  if (op_kind == 0 && res_kind == 0 && bytes <= host_bounce_max_bytes()) {
+  if (op_kind == 0 && res_kind == 0 && bytes <= host_bounce_max_bytes() &&
+      pointer_kind(operand, nullptr) != 1 && pointer_kind(result, nullptr) != 1) {
     // ordinary host memory, small call: the kernels (one or two passes) run in place on the
     // mapped bounce buffer
     if (int rc = g_staging.ensure(p->device, 8)) return rc;  // (the stream)
@@ -818,10 +897,11 @@ static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t*
     if (int rc = g_staging.ensure(p->device, bytes)) return rc;
     u64* d = (u64*)g_staging.buf;
     hipStream_t st = g_staging.stream;
-    HX_HIP(hipMemcpyAsync(d, operand, bytes, hipMemcpyHostToDevice, st));
+    // (hipMemcpyDefault: a mixed argument set -- device operand, host result -- lands here too)
+    HX_HIP(hipMemcpyAsync(d, operand, bytes, hipMemcpyDefault, st));
     hipError_t e = run(d, batch, st);
     if (e != hipSuccess) return hip_fail(e, "NTT launch");
-    HX_HIP(hipMemcpyAsync(result, d, bytes, hipMemcpyDeviceToHost, st));
+    HX_HIP(hipMemcpyAsync(result, d, bytes, hipMemcpyDefault, st));
     HX_HIP(hipStreamSynchronize(st));
     return HEXL_AMD_OK;
   }
@@ -924,6 +1004,7 @@ static int check_elt(EltOp op, const EltArgs& g) {
 
 static int elt_run(EltOp op, const EltArgs& g, void* stream) {
   if (int rc = check_elt(op, g)) return rc;
+  HX_ON_STREAM_DEVICE(stream);
   hipError_t e = eltwise_launch(op, g, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "eltwise launch");
   return HEXL_AMD_OK;
@@ -1010,21 +1091,26 @@ static int eltwise_host_run(EltOp op, EltArgs g, uint64_t* result, const uint64_
   HX_HIP(hipGetDevice(&device));
   const size_t bytes = (size_t)n * sizeof(u64);
   const bool has_b = operand2 != nullptr;
-  {  // mapped caller memory: the streaming kernel runs straight on it (see ntt_run_host)
-    void *r = nullptr, *a = nullptr, *b = nullptr;
-    if (pointer_kind(result, &r) == 2 && pointer_kind(operand1, &a) == 2 &&
-        (!has_b || pointer_kind(operand2, &b) == 2)) {
-      if (int rc = g_staging.ensure(device, 8)) return rc;
-      g.result = (u64*)r;
-      g.a = (const u64*)a;
-      g.b = (const u64*)b;
-      hipError_t e = eltwise_launch(op, g, g_staging.stream);
-      if (e != hipSuccess) return hip_fail(e, "eltwise launch");
-      HX_HIP(hipStreamSynchronize(g_staging.stream));
-      return HEXL_AMD_OK;
-    }
+  void *r = nullptr, *a = nullptr, *b = nullptr;
+  const int kr = range_kind(result, bytes, &r), ka = range_kind(operand1, bytes, &a),
+            kb = has_b ? range_kind(operand2, bytes, &b) : 0;
+  // mapped caller memory: the streaming kernel runs straight on it (see ntt_run_host)
+  if (kr == 2 && ka == 2 && (!has_b || kb == 2)) {
+    if (int rc = g_staging.ensure(device, 8)) return rc;
+    g.result = (u64*)r;
+    g.a = (const u64*)a;
+    g.b = (const u64*)b;
+    hipError_t e = eltwise_launch(op, g, g_staging.stream);
+    if (e != hipSuccess) return hip_fail(e, "eltwise launch");
+    HX_HIP(hipStreamSynchronize(g_staging.stream));
+    return HEXL_AMD_OK;
   }
-  if (bytes <= host_bounce_max_bytes()) {  // small call: the mapped bounce buffer (ntt_run_host)
+  // small call, every buffer ordinary host memory: the mapped bounce buffer (ntt_run_host).
+  // (The shim sends mixed argument sets here too -- a device operand with a host result: those
+  // are not host-dereferenceable and take the staged copies below, whose direction is detected.)
+  if (bytes <= host_bounce_max_bytes() && kr == 0 && ka == 0 && kb == 0 &&
+      pointer_kind(result, nullptr) == 0 && pointer_kind(operand1, nullptr) == 0 &&
+      (!has_b || pointer_kind(operand2, nullptr) == 0)) {
     if (int rc = g_staging.ensure(device, 8)) return rc;
     if (int rc = g_staging.ensure_bounce(bytes * (has_b ? 2 : 1))) return rc;
     u64* ha = (u64*)g_staging.bounce;
@@ -1044,14 +1130,14 @@ static int eltwise_host_run(EltOp op, EltArgs g, uint64_t* result, const uint64_
   u64* da = (u64*)g_staging.buf;
   u64* db = has_b ? da + n : nullptr;
   hipStream_t st = g_staging.stream;
-  HX_HIP(hipMemcpyAsync(da, operand1, bytes, hipMemcpyHostToDevice, st));
-  if (has_b) HX_HIP(hipMemcpyAsync(db, operand2, bytes, hipMemcpyHostToDevice, st));
+  HX_HIP(hipMemcpyAsync(da, operand1, bytes, hipMemcpyDefault, st));
+  if (has_b) HX_HIP(hipMemcpyAsync(db, operand2, bytes, hipMemcpyDefault, st));
   g.result = da;
   g.a = da;
   g.b = db;
   hipError_t e = eltwise_launch(op, g, st);
   if (e != hipSuccess) return hip_fail(e, "eltwise launch");
-  HX_HIP(hipMemcpyAsync(result, da, bytes, hipMemcpyDeviceToHost, st));
+  HX_HIP(hipMemcpyAsync(result, da, bytes, hipMemcpyDefault, st));
   HX_HIP(hipStreamSynchronize(st));
   return HEXL_AMD_OK;
 }
@@ -1077,6 +1163,7 @@ int hexl_amd_dyadic_multiply(uint64_t* result, const uint64_t* operand1, const u
                              void* stream) {
   if (int rc = check_dyadic(result, operand1, operand2, n, moduli, num_moduli)) return rc;
   if (num_moduli == 0) return HEXL_AMD_OK;
+  HX_ON_STREAM_DEVICE(stream);
   hipError_t e = dyadic_multiply_launch(result, operand1, operand2, n, moduli, num_moduli, 1,
                                         (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "dyadic multiply launch");
@@ -1089,6 +1176,7 @@ int hexl_amd_dyadic_multiply_batch(uint64_t* result, const uint64_t* operand1,
   if (int rc = check_dyadic(result, operand1, operand2, n, moduli, num_moduli)) return rc;
   if (num_moduli == 0 || num_pairs == 0) return HEXL_AMD_OK;
   if (num_pairs > 65535) return fail(HEXL_AMD_ERR_INVALID_ARG, "num_pairs must be <= 65535");
+  HX_ON_STREAM_DEVICE(stream);
   hipError_t e = dyadic_multiply_launch(result, operand1, operand2, n, moduli, num_moduli,
                                         num_pairs, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "dyadic multiply launch");
@@ -1352,6 +1440,7 @@ int hexl_amd_key_switch(uint64_t* result, const uint64_t* t_target_iter_ptr, uin
                                 key_modulus_size, rns_modulus_size, key_component_count, moduli,
                                 k_switch_keys, modswitch_factors))
     return rc;
+  HX_ON_STREAM_DEVICE(stream);
   return key_switch_device(result, t_target_iter_ptr, 1, n, decomp_modulus_size, key_modulus_size,
                            rns_modulus_size, key_component_count, moduli, k_switch_keys,
                            modswitch_factors, (hipStream_t)stream);
@@ -1370,6 +1459,7 @@ int hexl_amd_key_switch_batch(uint64_t* result, const uint64_t* t_target_iter_pt
   if (num_targets == 0) return HEXL_AMD_OK;
   if (num_targets * key_component_count > 65535)
     return fail(HEXL_AMD_ERR_INVALID_ARG, "num_targets * key_component_count must be <= 65535");
+  HX_ON_STREAM_DEVICE(stream);
   return key_switch_device(result, t_target_iter_ptr, num_targets, n, decomp_modulus_size,
                            key_modulus_size, rns_modulus_size, key_component_count, moduli,
                            k_switch_keys, modswitch_factors, (hipStream_t)stream);
@@ -1506,7 +1596,11 @@ int hexl_amd_release_stream_workspaces(void* stream) {
   return HEXL_AMD_OK;
 }
 int hexl_amd_release_workspaces(void) {
-  release_workspaces();
+  const int busy = release_workspaces();
+  if (busy)
+    return fail(HEXL_AMD_ERR_INVALID_ARG,
+                "%d scratch buffer(s) not released: a composite call was enqueueing on their "
+                "stream", busy);
   return HEXL_AMD_OK;
 }
 
@@ -1520,6 +1614,7 @@ int hexl_amd_set_tuning(const char* key, uint64_t value) {
 int hexl_amd_fill_splitmix(uint64_t* data, uint64_t n, uint64_t batch, uint64_t seed0,
                            uint64_t bound, void* stream) {
   if (!data) return fail(HEXL_AMD_ERR_INVALID_ARG, "data == nullptr");
+  HX_ON_STREAM_DEVICE(stream);
   hipError_t e = fill_splitmix_launch(data, n, batch, seed0, bound, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "fill launch");
   return HEXL_AMD_OK;

@@ -247,6 +247,10 @@ void compute_map(bool forward, const NTT* const* ntts, size_t num_ntts,
     plans[k] = static_cast<const hexl_amd_ntt*>(ntts[k]->PlanHandle());
   }
   const uint64_t n = ntts[0]->GetDegree();
+  // polynomial i sits at operand + i * n whatever its modulus: one degree for all
+  for (size_t k = 1; k < num_ntts; ++k)
+    if (ntts[k]->GetDegree() != n)
+      throw std::invalid_argument("hexl: the NTT objects of a prime map must share one degree");
   auto which = [&](uint64_t i) -> uint64_t {
     return prime_index ? prime_index[i] : plan_of_slot[(i / inner) % period];
   };

@@ -106,25 +106,49 @@ void release_stream_workspaces(hipStream_t stream) {
     }
   }
   for (void* p : victims) (void)hipFree(p);  // waits for the device: queued kernels finish first
+  // The stream's sequence mutex goes only when nobody else holds a reference to it (references
+  // are taken under g_mu, so the count cannot rise while we look): a thread that holds or
+  // waits for it keeps sequencing on the SAME mutex as everybody who comes after.
   std::lock_guard<std::mutex> lock(g_mu);
-  sequence_table().erase(std::make_pair(device, stream));  // (holders keep their shared_ptr)
+  auto it = sequence_table().find(std::make_pair(device, stream));
+  if (it != sequence_table().end() && it->second.use_count() == 1) sequence_table().erase(it);
 }
 
-void release_workspaces() {
-  std::vector<std::pair<int, void*>> victims;
+int release_workspaces() {
+  // Key by key under the stream's sequence lock (the order every user takes: sequence lock,
+  // then g_mu): a composite call that is enqueueing against a buffer finishes its sequence
+  // first; buffers whose stream is busy on ANOTHER thread right now are left alone and counted.
+  std::vector<std::tuple<int, hipStream_t, int>> keys;
   {
     std::lock_guard<std::mutex> lock(g_mu);
-    for (auto& kv : table())
-      if (kv.second.ptr) victims.emplace_back(std::get<0>(kv.first), kv.second.ptr);
-    table().clear();
+    for (auto& kv : table()) keys.push_back(kv.first);
+  }
+  std::vector<std::pair<int, void*>> victims;
+  int busy = 0;
+  for (auto& key : keys) {
+    std::shared_ptr<SeqMutex> mu = sequence_mutex(std::get<0>(key), std::get<1>(key));
+    if (!mu->try_lock()) {
+      ++busy;
+      continue;
+    }
+    {
+      std::lock_guard<std::mutex> lock(g_mu);
+      auto it = table().find(key);
+      if (it != table().end()) {
+        if (it->second.ptr) victims.emplace_back(std::get<0>(key), it->second.ptr);
+        table().erase(it);
+      }
+    }
+    mu->unlock();
   }
   int prev = 0;
   (void)hipGetDevice(&prev);
   for (auto& v : victims) {
     (void)hipSetDevice(v.first);
-    (void)hipFree(v.second);
+    (void)hipFree(v.second);  // waits for the device: kernels already queued finish first
   }
   (void)hipSetDevice(prev);
+  return busy;
 }
 
 }  // namespace hexl_amd

@@ -41,9 +41,11 @@ class StreamSequenceLock {
   Held* held_;
 };
 
-// Frees every cached buffer of the current process (all devices).  The caller
-// guarantees no operation that uses them is in flight.  C-ABI: hexl_amd_release_workspaces.
-void release_workspaces();
+// Frees every cached buffer of the current process (all devices), each under its stream's
+// sequence lock.  Returns the number of buffers left alone because another thread was
+// enqueueing against them at that moment (0: everything freed).  C-ABI:
+// hexl_amd_release_workspaces.
+int release_workspaces();
 
 // Frees the buffers (and the sequence lock) keyed by `stream` on the current device; for
 // owners about to destroy the stream (the per-thread staging streams of the host-pointer

@@ -90,6 +90,28 @@ int hexl_amd_device_free(void* p);
 int hexl_amd_copy(void* dst, const void* src, uint64_t bytes, void* stream, int blocking);
 int hexl_amd_synchronize(void* stream);
 
+/* Devices and streams for callers that drive several GPUs from one process ("one
+ * host thread + one stream per GPU"; the per-modulus loop of
+ * hexl/experimental/seal/key-switch-internal.cpp:51-90 cut across devices).  Nothing here
+ * requires the caller to track a "current device":
+ *   - a plan runs on the device it was created for (hexl_amd_ntt_create(..., device)), whatever
+ *     the calling thread's current device is; its `stream` argument must be NULL or a stream
+ *     of that device;
+ *   - every other stream-taking entry point (element-wise ops, DyadicMultiply, KeySwitch,
+ *     hexl_amd_fill_splitmix, hexl_amd_copy) runs on the device that OWNS `stream`; with
+ *     stream == NULL on the calling thread's current device;
+ *   - hexl_amd_device_alloc takes the device explicitly.
+ * hexl_amd_stream_create: a non-blocking stream on `device` (-1: the current device).
+ * hexl_amd_stream_destroy: waits for the stream, frees the scratch the composite entry points
+ * keyed by it, destroys it.  hexl_amd_set_device / _get_device: the calling thread's current
+ * device, for callers that prefer the HIP model (one hipSetDevice per worker thread).
+ * tests/cpp/multi_device.cpp is the reference caller: one std::thread + stream + plans per
+ * device, BASELINE configs[3] sharded by the flat (prime, polynomial) index. */
+int hexl_amd_set_device(int device);
+int hexl_amd_get_device(int* device);
+int hexl_amd_stream_create(void** stream, int device);
+int hexl_amd_stream_destroy(void* stream);
+
 /* Debug contract: the reference's debug builds (HEXL_DEBUG) check every ELEMENT of an
  * operand against its bound and throw (HEXL_CHECK_BOUNDS, hexl/include/hexl/util/check.hpp:32-35;
  * hexl/ntt/ntt-internal.cpp:198, :261; hexl/eltwise/eltwise-mult-mod.cpp:31-33 and the other
@@ -444,8 +466,9 @@ int hexl_amd_set_tuning(const char* key, uint64_t value);
 /* Device scratch of the composite entry points (KeySwitch, the experimental one-launch
  * transform) is cached per (device, stream) and grows on demand.  _release_stream_workspaces
  * frees what is keyed by `stream` on the current device (call it before destroying a stream
- * that ran such calls; waits for the device); _release_workspaces frees all of it (no call
- * that uses scratch may be in flight).  The per-thread streams of the host-pointer entry
+ * that ran such calls; waits for the device); _release_workspaces frees all of it, buffer by
+ * buffer under its stream's sequence lock -- a buffer another thread is enqueueing against at
+ * that moment is left alone and the call returns HEXL_AMD_ERR_INVALID_ARG (call again later).  The per-thread streams of the host-pointer entry
  * points release theirs when the thread ends. */
 int hexl_amd_release_stream_workspaces(void* stream);
 int hexl_amd_release_workspaces(void);

@@ -45,6 +45,7 @@ BATCH = 4096
 PRIMES = [18014398510661633, 18014398512365569, 18014398514200577, 18014398514987009,
           18014398515511297, 18014398516559873, 18014398521016321, 18014398524424193]
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+HBM_ACHIEVABLE_GBPS = 6290.0  # same guide: 6.29 TB/s measured with a float4 copy ("~6.3 achievable")
 # Counter-derived figures of the bench kernels (HBM bytes per launch, VALU busy, instructions
 # per wave, shader clock): collected with rocprofv3 --pmc by tools/collect_profiles.sh, written
 # by tools/summarize_profiles.py together with a hash of the kernel sources they were measured
@@ -134,6 +135,37 @@ def cpu_baseline(seconds_single=4.0, seconds_all=8.0):
     return out
 
 
+HOST_PATH_SHAPES = ((4096, 49), (16384, 54), (65536, 54))  # (N, GeneratePrimes bit size)
+
+
+def cpu_per_call_baseline(hx):
+    """cpu_baseline leg of `host_path`: the oracle's restatement of the reference's algorithm
+    (its AVX-512 variant where the host has AVX-512) on ONE thread, one forward transform of one
+    polynomial per call, same N and q as host_path -- the figure an unmodified single-call
+    caller of the reference sees on this box's CPU."""
+    import ctypes as C
+
+    from oracle import hexl_oracle as ho
+    simd = bool(ho.lib.ho_has_avx512())
+    fwd = ho.lib.ho_ntt_forward_batch_avx512 if simd else ho.lib.ho_ntt_forward_batch
+    out = {}
+    for n, bits in HOST_PATH_SHAPES:
+        q = hx.GeneratePrimes(1, bits, True, n)[0]
+        plan = ho.lib.ho_ntt_create(n, q, 0)
+        buf = ho.fill_splitmix(n, 11, q)
+        p = buf.ctypes.data_as(C.POINTER(C.c_uint64))
+        reps = 2000 if n <= 16384 else 400
+        for _ in range(20):
+            fwd(plan, p, p, 1, 1, 1)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fwd(plan, p, p, 1, 1, 1)
+        out[f"N={n}"] = {"us_per_call": (time.perf_counter() - t0) / reps * 1e6, "threads": 1,
+                         "isa": "avx512 (8 lanes)" if simd else "scalar", "kind": "port"}
+        ho.lib.ho_ntt_destroy(plan)
+    return out
+
+
 def kernel_source_hash():
     """sha256 over the sources the NTT kernels are compiled from (ties a counter profile to a build)"""
     import hashlib
@@ -179,6 +211,29 @@ def event_timed(torch, fn, iters):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
+def graph_timed(torch, fn, calls, replays=40):
+    """average seconds per call of fn replayed from a captured HIP graph of `calls` calls"""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(calls):
+                fn()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(replays):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (replays * calls) * 1e-3
+
+
 def rate(bytes_algorithmic, seconds, **extra):
     g = bytes_algorithmic / seconds / 1e9
     return dict({"us": seconds * 1e6, "GBps_algorithmic": g, "frac_of_hbm_peak": g / HBM_PEAK_GBPS},
@@ -207,11 +262,25 @@ def secondary_configs(hx, torch):
     ntt = hx.NTT(n, q)
     out["config2"] = {
         "shape": f"N={n}, q={q} (50-bit), batch={b}",
+        "timing": "eager: calls issued back to back on one stream (launch gaps included)",
         "fwd": rate(16.0 * n * b, event_timed(torch, lambda: ntt.ComputeForward(y, x, 1, 1), 200)),
         "inv": rate(16.0 * n * b, event_timed(torch, lambda: ntt.ComputeInverse(y, x, 1, 1), 200)),
         "multmod": rate(24.0 * n * b,
                         event_timed(torch, lambda: hx.EltwiseMultMod(y, x, x, n * b, q, 1), 200)),
     }
+    # the same calls replayed from a captured HIP graph of 32 back-to-back launches: what a
+    # caller that batches its launches sees (the C-ABI launches are stream-ordered and
+    # allocation-free, hence capturable); benchmark/bench-ntt.cpp:212-239 is the reference's
+    # own N = 4096 loop
+    try:
+        out["config2"]["graph_of_32"] = {
+            "fwd": rate(16.0 * n * b, graph_timed(torch, lambda: ntt.ComputeForward(y, x, 1, 1), 32)),
+            "inv": rate(16.0 * n * b, graph_timed(torch, lambda: ntt.ComputeInverse(y, x, 1, 1), 32)),
+            "multmod": rate(24.0 * n * b,
+                            graph_timed(torch, lambda: hx.EltwiseMultMod(y, x, x, n * b, q, 1), 32)),
+        }
+    except Exception as e:  # noqa: BLE001 -- graph capture is a measurement aid, not the product
+        out["config2"]["graph_of_32"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     n, b, q = 131072, 1024, 1152921504616808449  # configs[4]: N=131072, 61-bit prime, batch 1024
     a = torch.empty(b * n, dtype=torch.int64, device="cuda")
     c = torch.empty_like(a)
@@ -251,7 +320,16 @@ def secondary_configs(hx, torch):
         for _ in range(12):  # the first passes over a fresh buffer run slower
             step()
         sec = event_timed(torch, step, 10)
-        other[label] = {"q": q, "ms_per_step": sec * 1e3, "NTT_per_s": 2 * b / sec}
+        hx.profile_start(64)
+        for _ in range(4):
+            step()
+        kern = {}
+        for name, ms in hx.profile_stop():
+            kern.setdefault(name, []).append(ms)
+        other[label] = {"q": q, "ms_per_step": sec * 1e3, "NTT_per_s": 2 * b / sec,
+                        "avg_kernel_ms": {k: sum(v) / len(v) for k, v in kern.items()},
+                        # algorithmic bytes of the step's two transforms / its time / 8 TB/s
+                        "transform_frac": 2 * 16.0 * n * b / sec / 1e9 / HBM_PEAK_GBPS}
     out["headline_shape_other_moduli"] = other
     del x
     # configs[3] on ONE GPU: the 8 RNS primes x 4096 polynomials (16 GiB) through the
@@ -273,6 +351,145 @@ def secondary_configs(hx, torch):
     out["config4_on_one_gpu"] = {
         "shape": f"N={n}, 8 primes (55-bit) x {b} polynomials, hexl_amd_ntt_forward_rns/_inverse_rns",
         "ms_per_step": sec * 1e3, "NTT_per_s": 2 * len(primes) * b / sec}
+    return out
+
+
+def sustained_run(torch, step, polys, seconds=3.0):
+    """The same step loop for >= `seconds`: the power-capped steady state (a burst from idle
+    runs up to 15 % off it) and long enough for an outside sampler to see the
+    GPU busy.  Every step is bracketed by HIP events on the launch stream; queued 64 at a time."""
+    torch.cuda.synchronize()
+    ms, t0 = [], time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(65)]
+        marks[0].record()
+        for i in range(64):
+            step()
+            marks[i + 1].record()
+        torch.cuda.synchronize()
+        ms += [marks[i].elapsed_time(marks[i + 1]) for i in range(64)]
+    wall = time.perf_counter() - t0
+    srt = sorted(ms)
+    med = median(ms)
+    return {"seconds": wall, "steps": len(ms), "ms_per_step_median": med,
+            "ms_per_step_mean_wall": wall / len(ms) * 1e3,
+            "ms_per_step_p10": srt[len(srt) // 10], "ms_per_step_p90": srt[(len(srt) * 9) // 10],
+            "NTT_per_s": 2 * polys / (med * 1e-3),
+            "NTT_per_s_wall": 2 * polys * len(ms) / wall}
+
+
+def host_path(hx):
+    """What an UNMODIFIED caller of the reference gets: intel::hexl::NTT::ComputeForward on ONE
+    polynomial in host memory per call (hexl/include/hexl/ntt/ntt.hpp:99-110), synchronous --
+    through hexl_amd_ntt_forward_host, the entry point the C++ shim binds.  Per call, by kind of
+    buffer: ordinary (pageable) host memory; pinned device-mapped host memory
+    (hexl_amd_host_alloc = intel::hexl::DeviceMappedAllocator); device memory + a
+    synchronisation; device memory, calls queued.  Beside it the CPU: the oracle's AVX-512
+    variant of the reference's algorithm on ONE host thread, same N and q (the reference itself
+    is single-threaded per call)."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    out = {"unit": "us per call, one forward transform of one polynomial",
+           "entry_point": "hexl_amd_ntt_forward_host (what intel::hexl::NTT::ComputeForward binds)"}
+    for n, bits in HOST_PATH_SHAPES:
+        q = hx.GeneratePrimes(1, bits, True, n)[0]
+        ntt = hx.NTT(n, q)
+        src = np.random.default_rng(11).integers(0, q, n, dtype=np.uint64)
+        reps = 300 if n <= 16384 else 150
+        row = {"q": q}
+
+        def timed(call, sync_each=False):
+            for _ in range(20):
+                call()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                call()
+                if sync_each:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e6
+        a, b = src.copy(), np.zeros(n, dtype=np.uint64)
+        pa, pb = a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)
+        row["ordinary_host_memory"] = timed(lambda: hx.lib.hexl_amd_ntt_forward_host(ntt._h, pb, pa, 1, 1, 1))
+        want = b.copy()
+        pm = C.c_void_p()
+        if hx.lib.hexl_amd_host_alloc(C.byref(pm), 2 * n * 8) == 0:
+            m = np.ctypeslib.as_array(C.cast(pm, C.POINTER(C.c_uint64)), shape=(2 * n,))
+            m[:n] = src
+            po = C.c_void_p(pm.value + n * 8)
+            row["device_mapped_host_memory"] = timed(
+                lambda: hx.lib.hexl_amd_ntt_forward_host(ntt._h, po, pm, 1, 1, 1))
+            row["results_identical"] = bool(np.array_equal(m[n:], want))
+            del m
+            hx.lib.hexl_amd_host_free(pm)
+        d = hx.from_numpy(src)
+        o = torch.empty_like(d)
+        row["device_memory_plus_sync"] = timed(lambda: ntt.ComputeForward(o, d, 1, 1), sync_each=True)
+        row["device_memory_queued"] = timed(lambda: ntt.ComputeForward(o, d, 1, 1))
+        out[f"N={n}"] = row
+    return out
+
+
+def composites(hx):
+    """The in-tree composite callers on device buffers: KeySwitch at a
+    CKKS-like shape, per target, one target per call and 256 per call; DyadicMultiply as GB/s at
+    56 bytes per coefficient (2 x 2 polynomials in, 3 out)."""
+    import numpy as np
+    import torch
+    rng = np.random.default_rng(1)
+
+    def gpu_time(fn, reps):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+    out = {}
+    n, k = 32768, 16
+    moduli = hx.GeneratePrimes(k, 54, True, n)
+    x = hx.from_numpy(np.concatenate([rng.integers(0, q, n, dtype=np.uint64) for q in moduli] * 2))
+    y = hx.from_numpy(np.concatenate([rng.integers(0, q, n, dtype=np.uint64) for q in moduli] * 2))
+    r = torch.empty(3 * n * k, dtype=torch.int64, device="cuda")
+    t = gpu_time(lambda: hx.DyadicMultiply(r, x, y, n, moduli), 50)
+    out["dyadic_multiply"] = dict(rate(56.0 * n * k, t), shape=f"n={n} x {k} moduli (55-bit), one pair per call",
+                                  bytes_per_coefficient=56)
+    pairs = 64
+    xb, yb = x.repeat(pairs), y.repeat(pairs)
+    rb = torch.empty(3 * n * k * pairs, dtype=torch.int64, device="cuda")
+    t = gpu_time(lambda: hx.DyadicMultiplyBatch(rb, xb, yb, pairs, n, moduli), 10)
+    out["dyadic_multiply_batch"] = dict(rate(56.0 * n * k * pairs, t),
+                                        shape=f"n={n} x {k} moduli, {pairs} pairs per call")
+    del x, y, r, xb, yb, rb
+    n, D, C = 16384, 7, 2
+    K = D + 1
+    moduli = hx.GeneratePrimes(K, 54, True, n)
+    keys = [hx.from_numpy(np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                                          for _ in range(C) for i in range(K)])) for _ in range(D)]
+    msf = [int(rng.integers(1, moduli[i], dtype=np.uint64)) for i in range(D)]
+    target = np.concatenate([rng.integers(0, moduli[j], n, dtype=np.uint64) for j in range(D)])
+    result = np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                             for _ in range(C) for i in range(D)])
+    ks = {"shape": f"n={n}, {D} decomposition moduli (55-bit) + special prime, {C} key components"}
+    d_t, d_r = hx.from_numpy(target), hx.from_numpy(result)
+    t = gpu_time(lambda: hx.KeySwitch(d_r, d_t, n, D, K, D + 1, C, moduli, keys, msf), 30)
+    ks["one_target_per_call_us"] = t * 1e6
+    for T in (256,):
+        d_tt, d_rr = hx.from_numpy(np.tile(target, T)), hx.from_numpy(np.tile(result, T))
+        t = gpu_time(lambda: hx.KeySwitchBatch(d_rr, d_tt, T, n, D, K, D + 1, C, moduli, keys, msf), 5)
+        ks[f"{T}_targets_per_call_us_per_target"] = t * 1e6 / T
+        ks[f"{T}_targets_per_call_ms"] = t * 1e3
+        del d_tt, d_rr
+    out["key_switch"] = ks
+    torch.cuda.empty_cache()
     return out
 
 
@@ -376,6 +593,13 @@ def main():
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         raise SystemExit(subprocess.call(launcher_command(args.gpus, sys.argv[1:]), env=env))
 
+    # Exactly ONE line on stdout, the JSON: libraries under us write banners to file descriptor 1
+    # (gloo's "Rank 0 is connected to ...", RCCL's version block), so everything but the line goes
+    # to stderr from here on and the line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
 
     import hexl_amd as hx
@@ -454,6 +678,8 @@ def main():
     # fwd followed by inv is the identity: the data must be back where it started
     assert torch.equal(check, data[:2]), "round trip mismatch inside the timed region"
 
+    # the steady state: the same loop for >= 3 s (outside the K timed steps)
+    sustained = sustained_run(torch, step, my_polys, float(os.environ.get("BENCH_SUSTAINED_S", "3")))
     my_rate = 2 * my_polys * args.steps / elapsed
     per_rank = rv.gather(my_rate)
     median_ms = rv.max(median(step_ms))
@@ -472,6 +698,19 @@ def main():
     # writes every polynomial once
     alg_bytes = 16.0 * N * segments[0][2]
     achieved = alg_bytes / (kern_avg[dominant] * 1e-3) / 1e9
+    # a TRANSFORM is two launches (two HBM round trips above N = 2^14): its algorithmic bytes
+    # over the time of both kernels -- the figure the per-launch fraction does not show
+    fam = {"fwd": ("ntt_fwd_strided_pass", "ntt_fwd_tile_pass_bottom"),
+           "inv": ("ntt_inv_tile_pass_bottom", "ntt_inv_strided_pass")}
+    transform = {}
+    for direction, names in fam.items():
+        if all(k in kern_avg for k in names):
+            ms = sum(kern_avg[k] for k in names)
+            transform[direction] = {"ms": ms, "GBps_algorithmic": alg_bytes / (ms * 1e-3) / 1e9,
+                                    "frac_of_hbm_peak": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                    "frac_of_achievable": alg_bytes / (ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBPS}
+    kernel_ms_per_step = sum(kern_avg[k] * len(kern[k]) for k in kern) / args.steps
+    transform_frac = 2 * 16.0 * N * my_polys / (kernel_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS
 
     # counter-derived figures per launch of each kernel (HBM bytes: FETCH_SIZE / WRITE_SIZE in
     # separate passes with the gfx950 x2 read correction; VALU busy: SQ_ACTIVE_INST_VALU quad-
@@ -486,6 +725,7 @@ def main():
     # fraction of the 8 TB/s HBM peak (algorithmic bytes: SURVEY.md 8d / BASELINE.md 4).
     mult = None
     secondary = None
+    extras = {}
     copy_gbps = None
     if rank == 0 and not args.no_secondary:
         # what a plain device-to-device copy of the same batch sustains on this box (read + write
@@ -508,6 +748,26 @@ def main():
         del data
         torch.cuda.empty_cache()
         secondary = secondary_configs(hx, torch)
+        extras["host_path"] = host_path(hx)
+        if not args.no_cpu_baseline:
+            for key, cpu in cpu_per_call_baseline(hx).items():
+                extras["host_path"][key]["cpu_baseline_one_thread"] = cpu
+        extras["composites"] = composites(hx)
+        # the headline shape with the primes SEAL defaults to (60-bit)
+        extras["headline_60bit"] = dict(
+            secondary["headline_shape_other_moduli"]["60-bit prime (Harvey60 policy)"],
+            workload="in-place ForwardNTT(1,1) + InverseNTT(1,1), N=65536, batch=4096, "
+                     "60-bit prime (GeneratePrimes(1, 59, false, 65536))")
+        # the C-ABI's own multi-device launcher on whatever this box shows (one std::thread +
+        # stream + plans per visible GPU, one prime x 4096 polynomials each; verified against a
+        # single-device run): tests/cpp/multi_device.cpp
+        if os.path.exists(MULTI_DEVICE_BIN):
+            torch.cuda.empty_cache()
+            try:
+                extras["multi_device_threads"] = run_multi_device(
+                    range(torch.cuda.device_count()), "weak", 5, 6)
+            except SystemExit as e:
+                extras["multi_device_threads"] = {"error": str(e)[:300]}
     if rank == 0:
         out = {
             "metric": "Fwd+Inv NTTs/sec, N=65536 q~55b batch=4096",
@@ -537,10 +797,21 @@ def main():
                 "parallelism": (f"{args.scaling} scaling: flat (prime, polynomial) index sharded x{world}, "
                                 "no collectives")},
             "hbm_algorithmic_GBps": value * 16.0 * N / 1e9,
+            # the same loop held for >= 3 s (median HIP-event step of rank 0): the power-capped
+            # steady state
+            "sustained": sustained,
             "roofline": {
                 "bound": "hbm", "kernel": dominant, "achieved": achieved,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic, "traffic_source": counters_note,
+                # a whole transform = two launches: algorithmic bytes of the step's transforms /
+                # the event time of all its kernels / peak (per direction in `transform`); two HBM
+                # round trips are inherent above N = 2^14, so the structural ceiling of this
+                # figure is achievable / 2 / peak = 0.39
+                "transform_frac": transform_frac, "transform": transform,
+                "achievable_GBps": HBM_ACHIEVABLE_GBPS,
+                "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBPS,
+                "two_pass_ceiling_frac": HBM_ACHIEVABLE_GBPS / 2 / HBM_PEAK_GBPS,
                 "copy_GBps_measured": copy_gbps,
                 "frac_of_measured_copy": (achieved / copy_gbps) if copy_gbps else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
@@ -567,11 +838,12 @@ def main():
             out["eltwise_mult_mod"] = mult
         if secondary is not None:
             out["secondary"] = secondary
+        out.update(extras)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         elif world > 1:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     rv.close()
 
 

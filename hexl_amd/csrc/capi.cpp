@@ -457,7 +457,11 @@ int hexl_amd_ntt_create(hexl_amd_ntt** out, uint64_t degree, uint64_t modulus,
       hi.push_back(nt::multiply_factor(Rinv[i], shoup_bits, q));
     }
   }
-  InvLast il;
+  InvLast il{};
+  // the multiply-free N^-1 scaling of the last stage's sum branch (modarith.h)
+  il.c2 = (q - 1) >> p->log_n;
+  il.log_n = p->log_n;
+  il.mont_mask = (u32)(((policy == kPolicyLazy || policy == kPolicyHarvey60) ? 2 * n : n) - 1);
   il.n1 = nt::inverse_mod(n, q);
   il.n1w = nt::multiply_mod(il.n1, Rinv[1], q);
   if (policy == kPolicyFp64) {

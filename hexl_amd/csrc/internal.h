@@ -9,13 +9,6 @@
 
 namespace hexl_amd {
 
-// Scalars of the last inverse stage: n1 = N^-1 mod q, n1w = N^-1 * R[1]^-1,
-// each with its floor(x * 2^64 / q) companion
-// (hexl/ntt/ntt-radix-2.cpp:490-497).
-struct InvLast {
-  u64 n1, n1p, n1w, n1wp;
-};
-
 // Moduli below this bound use the Lazy arithmetic policy (modarith.h); their
 // device tables carry 63-bit Shoup factors.
 constexpr u64 kLazyModulusBound = 1ull << 56;

@@ -14,7 +14,7 @@
 //
 //   Strict (any q < 2^62): the reference's invariants -- forward values in
 //     [0,4q) with one conditional subtraction per butterfly, inverse values in
-//     [0,2q); 64-bit Shoup factors; ~37 instructions per butterfly.
+//     [0,2q); 64-bit Shoup factors; 23 instructions per butterfly (10 multiplies).
 //   Lazy (q < 2^56): the 64-bit word has >= 8 spare bits.  Values are kept
 //     DOUBLED (D = 2x) between the first load and the last store of a
 //     transform, Shoup factors carry 63 fractional bits, and the quotient
@@ -23,9 +23,9 @@
 //     v_mad_u64_u32 and 2 moves.  The forward network never subtracts
 //     conditionally (doubled values grow by at most 6q per stage: at most
 //     (8 + 6*17) q < 2^63) and is reduced once at the end; the inverse network
-//     skips the conditional subtractions inside each register subtree and
-//     restores [0,8q) at subtree exit.  14 (forward) / 15 (inverse)
-//     instructions per butterfly.
+//     tracks the range of every element at compile time and reduces only where
+//     the next use of a value would pass 2^63 (lazy_inverse.h).  14 (forward) /
+//     15 (inverse) instructions per butterfly.
 // All policies produce the same canonical outputs; lazy outputs stay inside the
 // reference's ranges ([0,4q) forward, [0,2q) inverse).
 #pragma once
@@ -122,6 +122,31 @@ inline ModConst make_mod_const(u64 q) {  // host only
   m.qd = (double)q;  // exact for q < 2^53; only read for q < 2^50
   m.qinv = 1.0 / m.qd;
   return m;
+}
+
+// Scalars of the last inverse stage: n1 = N^-1 mod q, n1w = N^-1 * R[1]^-1, each with its
+// Shoup companion (hexl/ntt/ntt-radix-2.cpp:490-497).
+// c2, log_n, mont_mask: the multiply-free N^-1 scaling of the sum branch (scale_by_inverse_degree).
+struct InvLast {
+  u64 n1, n1p, n1w, n1wp;
+  u64 c2;         // (q - 1) / N
+  u32 log_n;      // log2 N
+  u32 mont_mask;  // 2N - 1 where values are held doubled (Lazy, Harvey60), N - 1 otherwise
+};
+
+// s * N^-1 modulo q WITHOUT a modular product: a negacyclic modulus is q = 1 + N c2
+// (q == 1 mod 2N, hexl/ntt/ntt-internal.cpp:171-186), so q == 1 (mod N) and one Montgomery
+// step with radix N needs no multiplication by -q^-1:
+//     m = -s mod N,   t = (s + m q) / N = (s + m) / N + m c2,   t N == s (mod q).
+// Values held doubled (even numbers standing for their halves) take m = -s mod 2N: then 2N
+// divides s + m (q == 1 mod 2N) and t is even again.  t < s / N + q (m / N): below 2q (4q
+// doubled) whenever s < 2 N q -- every policy's s from N = 64 on.  A shift, a mask and ONE
+// 32 x 32-bit multiply-add (+ a 32-bit multiply for the high word of c2) instead of the nine
+// of a Shoup product: the sum branch of the last inverse stage (ntt-radix-2.cpp:490-509,
+// X' = (X + Y) N^-1), 16 of the 96 products of a 5-stage strided subtree.
+HX_HD u64 scale_by_inverse_degree(u64 s, const InvLast& il) {
+  const u32 mq = (0u - (u32)s) & il.mont_mask;
+  return ((s + mq) >> il.log_n) + (u64)mq * il.c2;
 }
 
 // x mod q for ANY 64-bit x: single-word Barrett with floor(2^64 / q)
@@ -443,19 +468,15 @@ HX_HD u64 fwd_finish(u64 x, const ModConst& m, bool canonical) {
   return canonical ? csub(csub(x, m.two_q), m.q) : x;
 }
 
-// Inverse (Gentleman-Sande) Harvey butterfly at depth `k` of a lazy run (k = 0
-// for the first stage after values were last bounded).
-// Strict: x,y in [0,2q) -> [0,2q).
-// Lazy (doubled): x,y < 8q*2^k -> x' < 8q*2^(k+1), y' in [0,6q); the offset added
-// before subtracting y is 8q*2^k.  BOUND restores x' < 8q (k must be 0).
-template <class A, bool BOUND = false>
-HX_HD void inv_butterfly(u64& x, u64& y, u64 W, u64 Wp, const ModConst& m, int k) {
+// Inverse (Gentleman-Sande) Harvey butterfly (hexl/ntt/ntt-default.hpp:112-125) of the policies
+// that keep the reference's invariant -- every value in [0,2q) (Harvey60: doubled, [0,4q)) with
+// one conditional subtraction per butterfly.  The Lazy policy's inverse network, which subtracts
+// only where its compile-time range bookkeeping says it must, is lazy_inverse.h.
+template <class A>
+HX_HD void inv_butterfly(u64& x, u64& y, u64 W, u64 Wp, const ModConst& m) {
+  static_assert(!A::kLazy && !A::kFp, "Lazy: lazy_inverse.h; Fp64: inv_butterfly_fp");
   const u64 s = x + y;
-  if (A::kLazy) {
-    const u64 d = x + (m.two_q << (k + 2)) - y;
-    x = BOUND ? csub_neg(s, m.neg_two_q << 2) : s;
-    y = mul_add_lazy2<false>(0, d, W, Wp, m.neg_two_q);
-  } else if (A::kH60) {  // doubled: x, y < 4q -> < 4q
+  if (A::kH60) {  // doubled: x, y < 4q -> < 4q
     const u64 d = x + m.four_q - y;  // < 8q
     x = csub_neg(s, m.neg_four_q);
     y = mul_add_lazy2<true>(0, d, W, Wp, m.neg_two_q);
@@ -472,28 +493,25 @@ HX_HD void inv_butterfly(u64& x, u64& y, u64 W, u64 Wp, const ModConst& m, int k
 
 // Last inverse stage with N^{-1} folded in (ntt-radix-2.cpp:490-509):
 // x' = (x+y) * n1, y' = (x-y) * n1W.  The sum needs no conditional subtraction
-// first because the lazy products accept it as it is.  Strict: [0,2q).  Lazy:
-// the exact quotient is used here, so the doubled results lie in [0,4q).
-template <class A>
-HX_HD void inv_butterfly_last(u64& x, u64& y, u64 n1, u64 n1p, u64 n1w, u64 n1wp,
-                              const ModConst& m, int k) {
+// first because the lazy products accept it as it is.  Strict: [0,2q).  Harvey60: the doubled
+// results lie in [0,4q).
+// MONT: the sum branch through scale_by_inverse_degree (N >= 64).
+template <class A, bool MONT = false>
+HX_HD void inv_butterfly_last(u64& x, u64& y, const InvLast& il, const ModConst& m) {
+  static_assert(!A::kLazy && !A::kFp, "Lazy: lazy_inverse.h; Fp64: inv_butterfly_last_fp");
   const u64 s = x + y;
-  if (A::kLazy) {
-    const u64 d = x + (m.two_q << (k + 2)) - y;
-    x = mul_add_lazy2<true>(0, s, n1, n1p, m.neg_two_q);
-    y = mul_add_lazy2<true>(0, d, n1w, n1wp, m.neg_two_q);
-  } else if (A::kH60) {  // s, d < 8q < 2^63; doubled results in [0,4q)
+  if (A::kH60) {  // s, d < 8q < 2^63
     const u64 d = x + m.four_q - y;
-    x = mul_add_lazy2<true>(0, s, n1, n1p, m.neg_two_q);
-    y = mul_add_lazy2<true>(0, d, n1w, n1wp, m.neg_two_q);
+    x = MONT ? scale_by_inverse_degree(s, il) : mul_add_lazy2<true>(0, s, il.n1, il.n1p, m.neg_two_q);
+    y = mul_add_lazy2<true>(0, d, il.n1w, il.n1wp, m.neg_two_q);
   } else if (A::kSmall) {
     const u32 d = (u32)x + (u32)m.two_q - (u32)y;
-    x = mul_small((u32)s, (u32)n1, (u32)n1p, (u32)m.q);
-    y = mul_small(d, (u32)n1w, (u32)n1wp, (u32)m.q);
+    x = mul_small((u32)s, (u32)il.n1, (u32)il.n1p, (u32)m.q);
+    y = mul_small(d, (u32)il.n1w, (u32)il.n1wp, (u32)m.q);
   } else {
     const u64 d = x + m.two_q - y;
-    x = mul_add_strict(0, s, n1, n1p, m.neg_q);
-    y = mul_add_strict(0, d, n1w, n1wp, m.neg_q);
+    x = MONT ? scale_by_inverse_degree(s, il) : mul_add_strict(0, s, il.n1, il.n1p, m.neg_q);
+    y = mul_add_strict(0, d, il.n1w, il.n1wp, m.neg_q);
   }
 }
 
@@ -507,18 +525,6 @@ HX_HD u64 inv_finish(u64 v, const ModConst& m, bool canonical) {
   }
   if (A::kSmall) return canonical ? csub32((u32)v, (u32)m.q) : v;
   return canonical ? csub(v, m.q) : v;
-}
-
-// Lazy policy, end of a lazy run: an element that was the sum in the last `lz`
-// stages of the run is < 8q * 2^lz (doubled); bring it back below 8q.  One
-// conditional subtraction for lz == 1; for longer runs the 8-bit quotient
-// estimate of fwd_finish (value < 128q) lands in [0,4q) in five instructions.
-template <int LZ>
-HX_HD u64 inv_ladder(u64 x, const ModConst& m) {
-  static_assert(LZ <= 4, "lazy run too long");
-  if (LZ == 0) return x;
-  if (LZ == 1) return csub_neg(x, m.neg_two_q << 2);
-  return lazy_estimate_reduce(x, m);
 }
 
 }  // namespace hexl_amd

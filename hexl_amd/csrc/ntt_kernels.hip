@@ -56,6 +56,7 @@
 #include <mutex>
 
 #include "internal.h"
+#include "lazy_inverse.h"
 #include "modarith.h"
 #include "tile_geometry.h"
 #include <cstddef>
@@ -173,20 +174,21 @@ __device__ __forceinline__ void bf_fwd(u64& x, u64& y, const TwT<A>& w, const Mo
   else
     fwd_butterfly<A>(x, y, w.x, w.y, m);
 }
-template <class A, bool BOUND>
-__device__ __forceinline__ void bf_inv(u64& x, u64& y, const TwT<A>& w, const ModConst& m, int k) {
+// (not the Lazy policy: its inverse network is lazy_inverse.h)
+template <class A>
+__device__ __forceinline__ void bf_inv(u64& x, u64& y, const TwT<A>& w, const ModConst& m) {
   if constexpr (A::kFp)
     inv_butterfly_fp(x, y, w, m);
   else
-    inv_butterfly<A, BOUND>(x, y, w.x, w.y, m, k);
+    inv_butterfly<A>(x, y, w.x, w.y, m);
 }
-template <class A>
-__device__ __forceinline__ void bf_inv_last(u64& x, u64& y, const InvLast& il, const ModConst& m,
-                                            int k) {
+// MONT: the sum branch without a modular product (scale_by_inverse_degree; Strict, Harvey60)
+template <class A, bool MONT>
+__device__ __forceinline__ void bf_inv_last(u64& x, u64& y, const InvLast& il, const ModConst& m) {
   if constexpr (A::kFp)
     inv_butterfly_last_fp(x, y, fp_bits_to_double(il.n1), fp_bits_to_double(il.n1w), m);
   else
-    inv_butterfly_last<A>(x, y, il.n1, il.n1p, il.n1w, il.n1wp, m, k);
+    inv_butterfly_last<A, (MONT && !A::kSmall)>(x, y, il, m);
 }
 // Fp64: full reduction of all E elements (end of a run of stages); nothing otherwise.
 template <class A, int E>
@@ -255,68 +257,46 @@ __device__ __forceinline__ void fwd_subtree(u64* x, const TwT<A>* wv, const ModC
   }
 }
 
-// number of leading zero bits of e seen as an R-bit number
-constexpr int leading_zeros(int e, int R) {
-  int n = 0;
-  for (int b = R - 1; b >= 0 && !((e >> b) & 1); --b) ++n;
-  return n;
-}
-
-template <int R, int E0, class A>
-struct InvLadder {
-  static __device__ __forceinline__ void run(u64* x, const ModConst& m) {
-    constexpr int kRun = R > 4 ? 4 : R;  // stages of the final lazy run
-    constexpr int kLz = leading_zeros(E0, R) < kRun ? leading_zeros(E0, R) : kRun;
-    x[E0] = inv_ladder<kLz>(x[E0], m);
-    InvLadder<R, E0 + 1, A>::run(x, m);
-  }
-};
-template <int R, class A>
-struct InvLadder<R, (1 << R), A> {
-  static __device__ __forceinline__ void run(u64*, const ModConst&) {}
-};
-
 // R inverse stages (deepest level first).  With LAST the v == 0 stage is the
 // root of the whole transform and folds N^-1 in (ntt-radix-2.cpp:490-509).
-// Lazy policy: no conditional subtraction inside the subtree, the bound 8q is
-// restored at exit (not needed after LAST, whose outputs are both lazy
-// products).  A lazy run is at most 4 stages deep (8q * 2^4 must stay below
-// 2^63 for q < 2^56); a 5-stage subtree bounds the sums of its first stage.
+// B, T (Lazy policy only): bound of the inputs and what the consumer of the outputs takes, in
+// units of q -- the subtree is then lazy_inverse.h's, which subtracts only where its
+// compile-time range bookkeeping says a value would pass 2^63.
 // Fp64: the sums double, so every kFpInvRun stages all elements are fully reduced,
 // and again at exit (not after LAST: the finish does it).
-template <int R, class A, bool LAST>
+// MONT (with LAST): the transform has at least 64 coefficients, the N^-1 scaling of the sum branch
+// is scale_by_inverse_degree (modarith.h).
+template <int R, class A, bool LAST, int B = kLazyHandOver, int T = kLazyHandOver, bool MONT = true>
 __device__ __forceinline__ void inv_subtree(u64* x, const TwT<A>* wv, const ModConst& m,
                                             const InvLast& il) {
-  constexpr int kBounded = (A::kLazy && R > 4) ? R - 4 : 0;
-  static_assert(R <= 5, "lazy inverse run too deep");
+  static_assert(R <= 5, "register subtrees are at most 5 stages deep");
+  if constexpr (A::kLazy) {
+    inv_subtree_lazy<R, B, T, LAST, MONT>(x, wv, m, il);
+    return;
+  } else {
 #pragma unroll
-  for (int v = R - 1; v >= 0; --v) {
-    const int half = 1 << (R - 1 - v);
-    const int t = R - 1 - v;  // execution order
-    const int k = t < kBounded ? 0 : t - kBounded;
+    for (int v = R - 1; v >= 0; --v) {
+      const int half = 1 << (R - 1 - v);
+      const int t = R - 1 - v;  // execution order
 #pragma unroll
-    for (int g = 0; g < (1 << v); ++g) {
-      if (LAST && v == 0) {
+      for (int g = 0; g < (1 << v); ++g) {
+        if (LAST && v == 0) {
 #pragma unroll
-        for (int j = 0; j < half; ++j) bf_inv_last<A>(x[j], x[j + half], il, m, k);
-      } else {
-        const TwT<A> w = wv[(1 << v) + g];
+          for (int j = 0; j < half; ++j) bf_inv_last<A, MONT>(x[j], x[j + half], il, m);
+        } else {
+          const TwT<A> w = wv[(1 << v) + g];
 #pragma unroll
-        for (int j = 0; j < half; ++j) {
-          if (t < kBounded)
-            bf_inv<A, true>(x[g * 2 * half + j], x[g * 2 * half + j + half], w, m, 0);
-          else
-            bf_inv<A, false>(x[g * 2 * half + j], x[g * 2 * half + j + half], w, m, k);
+          for (int j = 0; j < half; ++j)
+            bf_inv<A>(x[g * 2 * half + j], x[g * 2 * half + j + half], w, m);
         }
+        // Deep subtrees: stop the scheduler from interleaving every butterfly of a
+        // stage (it would keep all their temporaries live at once and spill).
+        if (R >= 4) __builtin_amdgcn_sched_barrier(0);
       }
-      // Deep subtrees: stop the scheduler from interleaving every butterfly of a
-      // stage (it would keep all their temporaries live at once and spill).
-      if (R >= 4) __builtin_amdgcn_sched_barrier(0);
+      if (A::kFp && (t + 1) % kFpInvRun == 0 && v > 0) fp_bound_all<A, (1 << R)>(x, m);
     }
-    if (A::kFp && (t + 1) % kFpInvRun == 0 && v > 0) fp_bound_all<A, (1 << R)>(x, m);
+    if (!LAST) fp_bound_all<A, (1 << R)>(x, m);
   }
-  if (A::kLazy && !LAST) InvLadder<R, 0, A>::run(x, m);
-  if (!LAST) fp_bound_all<A, (1 << R)>(x, m);
 }
 
 // One level of a subtree on its own, groups [G0, G1): used by the 5-stage strided
@@ -337,23 +317,29 @@ __device__ __forceinline__ void fwd_level(u64* x, const TwT<A>* wl, const ModCon
   }
 }
 
-// Inverse level V at lazy depth K; BOUND as in inv_butterfly; LAST folds N^-1 in
-// (then V == 0).
-template <int R, int V, int G0, int G1, class A, bool BOUND, bool LAST>
+// Inverse level V; LAST folds N^-1 in (then V == 0).  Lazy: the level of lazy_inverse.h's
+// schedule SC (execution stage R-1-V).
+// (only the 5-stage strided subtree comes here: N >= 2^13, the N^-1 scaling of the sum branch is
+// scale_by_inverse_degree)
+template <int R, int V, int G0, int G1, class A, bool LAST, class SC = void>
 __device__ __forceinline__ void inv_level(u64* x, const TwT<A>* wl, const ModConst& m,
-                                          const InvLast& il, int k) {
-  constexpr int half = 1 << (R - 1 - V);
+                                          const InvLast& il) {
+  if constexpr (A::kLazy) {
+    inv_level_lazy<SC, R, R - 1 - V, G0, G1, LAST, true>(x, wl, m, il);
+  } else {
+    constexpr int half = 1 << (R - 1 - V);
 #pragma unroll
-  for (int g = G0; g < G1; ++g)
+    for (int g = G0; g < G1; ++g)
 #pragma unroll
-    for (int j = 0; j < half; ++j) {
-      u64& a = x[g * 2 * half + j];
-      u64& b = x[g * 2 * half + j + half];
-      if (LAST)
-        bf_inv_last<A>(a, b, il, m, k);
-      else
-        bf_inv<A, BOUND>(a, b, wl[g - G0], m, k);
-    }
+      for (int j = 0; j < half; ++j) {
+        u64& a = x[g * 2 * half + j];
+        u64& b = x[g * 2 * half + j + half];
+        if (LAST)
+          bf_inv_last<A, true>(a, b, il, m);
+        else
+          bf_inv<A>(a, b, wl[g - G0], m);
+      }
+  }
 }
 
 template <int COUNT, class T>
@@ -385,25 +371,25 @@ template <class A, bool LAST>
 __device__ __forceinline__ void inv_subtree5_streamed(u64* x, const TwT<A>* __restrict__ tw,
                                                       u32 node, const ModConst& m,
                                                       const InvLast& il) {
-  // Lazy: the first stage bounds its sums (a lazy run is at most 4 stages deep),
-  // the remaining four run at depths 0..3.  Fp64: full reduction after the third
-  // stage and at exit.
-  constexpr bool kB = A::kLazy;
+  // Lazy: the schedule of a 5-stage subtree entered and (unless LAST) left below kLazyHandOver
+  // -- three quotient estimates where the sums of the deepest chains would pass the limit.
+  // Fp64: full reduction after the third stage and at exit.
+  using SC = InvSchedOf<5, kLazyHandOver, kLazyHandOver, LAST>;
   TwT<A> w0, w1[2], w2[4], w3[8], w4a[8], w4b[8];
   load_twiddle_run<8>(w4a, tw, node << 4);
   load_twiddle_run<8>(w4b, tw, (node << 4) + 8);
-  inv_level<5, 4, 0, 8, A, kB, false>(x, w4a, m, il, 0);
+  inv_level<5, 4, 0, 8, A, false, SC>(x, w4a, m, il);
   load_twiddle_run<8>(w3, tw, node << 3);
-  inv_level<5, 4, 8, 16, A, kB, false>(x, w4b, m, il, 0);
+  inv_level<5, 4, 8, 16, A, false, SC>(x, w4b, m, il);
   load_twiddle_run<4>(w2, tw, node << 2);
   load_twiddle_run<2>(w1, tw, node << 1);
   load_twiddle_run<1>(&w0, tw, node);
-  inv_level<5, 3, 0, 8, A, false, false>(x, w3, m, il, 0);
-  inv_level<5, 2, 0, 4, A, false, false>(x, w2, m, il, 1);
+  inv_level<5, 3, 0, 8, A, false, SC>(x, w3, m, il);
+  inv_level<5, 2, 0, 4, A, false, SC>(x, w2, m, il);
   fp_bound_all<A, 32>(x, m);
-  inv_level<5, 1, 0, 2, A, false, false>(x, w1, m, il, 2);
-  inv_level<5, 0, 0, 1, A, false, LAST>(x, &w0, m, il, 3);
-  if (A::kLazy && !LAST) InvLadder<5, 0, A>::run(x, m);
+  inv_level<5, 1, 0, 2, A, false, SC>(x, w1, m, il);
+  inv_level<5, 0, 0, 1, A, LAST, SC>(x, &w0, m, il);
+  if constexpr (A::kLazy) inv_exit_lazy<SC, 5>(x, m);
   if (!LAST) fp_bound_all<A, 32>(x, m);
 }
 
@@ -699,8 +685,9 @@ __device__ __forceinline__ void round_compute(u64* x, const TwT<A>* wv, const Mo
   for (int s = 0; s < SS; ++s) {
     if (FWD)
       fwd_subtree<r, A>(x + (s << r), wv + (s << r), m);
-    else
-      inv_subtree<r, A, LAST>(x + (s << r), wv + (s << r), m, il);
+    else  // (Lazy: entry bound and exit threshold of round j of this pass's chain)
+      inv_subtree<r, A, LAST, lazy_chain_entry(j, Rounds<S, CB>::NR, Rounds<S, CB>::R0, kRE),
+                  lazy_chain_thresh(j, Rounds<S, CB>::R0, kRE), (S >= 6)>(x + (s << r), wv + (s << r), m, il);
   }
   if (FWD && Rounds<S, CB>::fp_reduce_after(j)) fp_bound_all<A, kE>(x, m);
 }

@@ -2,19 +2,23 @@
 // the very functions the HIP kernels inline) against the oracle.
 //
 // The transform networks are replayed stage by stage with the device butterflies:
-// forward = plain radix-2 Cooley-Tukey order; inverse = Gentleman-Sande order cut
-// into lazy runs exactly like the kernels cut it (rounds of <= 3 stages in a tile
-// pass, <= 5 in a strided pass), tracking for every element the number of stages
-// since it was last bounded.  Every intermediate is checked against the range the
-// policy promises (doubled values < 2^63, run exit < 8q) and the outputs against
-// the oracle, bit for bit.
+// forward = plain radix-2 Cooley-Tukey order; inverse = Gentleman-Sande order.  The Lazy
+// policy's inverse is cut into passes and rounds exactly like the kernels cut it (a tile pass
+// of S stages = rounds of tile_geometry.h, strided passes of <= 5 stages) and every register
+// subtree is run through the SAME compile-time schedule the kernels are instantiated with
+// (lazy_inverse.h: make_inv_sched, lazy_chain_entry / _thresh), by an interpreter that checks
+// every intermediate against the bound the scheduler claims for it (and all of them against
+// 2^63), and through the templated device functions themselves, whose outputs must be
+// identical.  Outputs are checked against the oracle, bit for bit.
 //
 // Build/run: see tests/test_host_arith.py.
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
+#include "lazy_inverse.h"
 #include "modarith.h"
+#include "tile_geometry.h"
 
 extern "C" {
 #include "hexl_oracle.h"
@@ -27,7 +31,7 @@ static int g_cases = 0;
 #define EXPECT(c, ...)                 \
   do {                                 \
     if (!(c)) {                        \
-      if (g_fail < 20) {               \
+      if (g_fail < 400) {               \
         fprintf(stderr, __VA_ARGS__);  \
         fprintf(stderr, "\n");         \
       }                                \
@@ -99,7 +103,9 @@ static void check(u64 n, u64 q, const std::vector<int>& inv_runs, u64 in_mf_f, u
         EXPECT(r < 4 * q && r % q == ref[i], "fwd lazy mismatch at %llu", (unsigned long long)i);
     }
 
-    // ---------------- inverse
+    // ---------------- inverse (the Lazy policy's: check_lazy_inverse below)
+    if constexpr (A::kLazy) continue;
+    else {
     for (auto& v : in) v = rnd() % (in_mf_i * q);
     in[0] = in_mf_i * q - 1;
     in[1] = in_mf_i * q - 1;
@@ -107,51 +113,37 @@ static void check(u64 n, u64 q, const std::vector<int>& inv_runs, u64 in_mf_f, u
     ho_ntt_inverse_radix2(ref.data(), in.data(), n, q, Ri_stage.data(), Rip_stage.data(), in_mf_i,
                           1);
     for (u64 i = 0; i < n; ++i) x[i] = to_internal<A>(in[i], m);
-    std::vector<int> depth(n, 0);  // lazy stages since the element was last bounded
-    const u64 n1 = ho_inverse_mod(n, q), n1w = ho_multiply_mod(n1, V[1], q);
-    const u64 n1p = ho_multiply_factor(n1, shoup, q), n1wp = ho_multiply_factor(n1w, shoup, q);
+    InvLast il{};
+    il.n1 = ho_inverse_mod(n, q);
+    il.n1w = ho_multiply_mod(il.n1, V[1], q);
+    il.n1p = ho_multiply_factor(il.n1, shoup, q);
+    il.n1wp = ho_multiply_factor(il.n1w, shoup, q);
+    il.c2 = (q - 1) / n;
+    il.log_n = (u32)L;
+    il.mont_mask = (u32)((A::kH60 ? 2 * n : n) - 1);
     int stage = L - 1;  // heap level of the stage to run; deepest first
     for (size_t ri = 0; ri < inv_runs.size() && stage >= 0; ++ri) {
       int len = inv_runs[ri];
       if (len > stage + 1) len = stage + 1;
-      const int bounded = (A::kLazy && len > 4) ? len - 4 : 0;
       for (int tt = 0; tt < len; ++tt, --stage) {
-        const int k = tt < bounded ? 0 : tt - bounded;
         const u64 mgroups = 1ull << stage, t = n >> (stage + 1);
         for (u64 i = 0; i < mgroups; ++i)
           for (u64 j = 0; j < t; ++j) {
             const u64 ia = 2 * i * t + j, ib = ia + t;
-            if (A::kLazy) EXPECT(depth[ia] <= k && depth[ib] <= k, "inv depth bookkeeping");
             if (stage == 0) {
-              inv_butterfly_last<A>(x[ia], x[ib], n1, n1p, n1w, n1wp, m, k);
-            } else if (tt < bounded) {
-              inv_butterfly<A, true>(x[ia], x[ib], V[mgroups + i], Vp[mgroups + i], m, 0);
-              depth[ia] = 0;
-              depth[ib] = 0;
+              // (the multiply-free N^-1 scaling of the sum branch from N = 64 on, as in the kernels)
+              if (n >= 64 && !A::kSmall)
+                inv_butterfly_last<A, true>(x[ia], x[ib], il, m);
+              else
+                inv_butterfly_last<A, false>(x[ia], x[ib], il, m);
             } else {
-              inv_butterfly<A, false>(x[ia], x[ib], V[mgroups + i], Vp[mgroups + i], m, k);
-              depth[ia] = k + 1;
-              depth[ib] = 0;
+              inv_butterfly<A>(x[ia], x[ib], V[mgroups + i], Vp[mgroups + i], m);
             }
             EXPECT(x[ia] < lim && x[ib] < lim, "inv range: stage %d", stage);
           }
       }
-      if (stage >= 0 && A::kLazy) {  // run exit: ladder
-        for (u64 i = 0; i < n; ++i) {
-          switch (depth[i]) {
-            case 0: break;
-            case 1: x[i] = inv_ladder<1>(x[i], m); break;
-            case 2: x[i] = inv_ladder<2>(x[i], m); break;
-            case 3: x[i] = inv_ladder<3>(x[i], m); break;
-            case 4: x[i] = inv_ladder<4>(x[i], m); break;
-            default: EXPECT(false, "depth %d", depth[i]);
-          }
-          depth[i] = 0;
-          EXPECT(x[i] < 8 * q, "inv run exit bound");
-        }
-      } else if (stage >= 0) {
+      if (stage >= 0)
         for (u64 i = 0; i < n; ++i) EXPECT(x[i] < (A::kH60 ? 4 : 2) * q, "inv strict bound");
-      }
     }
     EXPECT(stage == -1, "runs do not cover the network");
     for (u64 i = 0; i < n; ++i) {
@@ -162,7 +154,197 @@ static void check(u64 n, u64 q, const std::vector<int>& inv_runs, u64 in_mf_f, u
       else
         EXPECT(r < 2 * q && r % q == ref[i], "inv lazy mismatch at %llu", (unsigned long long)i);
     }
+    }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lazy policy, inverse network: passes and rounds as the kernels cut them, every subtree through
+// the schedule the kernels use.
+struct HostTw {
+  u64 x, y;
+};
+
+// One subtree through schedule `sc` (entered below B q), the interpreter: the same operations as
+// inv_level_lazy / inv_exit_lazy, each intermediate checked against the scheduler's bookkeeping.
+static void run_sched(const InvSched& sc, int R, int B, bool last, bool mont, u64* x, const HostTw* wv,
+                      const ModConst& m, const InvLast& il) {
+  const int E = 1 << R;
+  const u64 q = m.q;
+  std::vector<u64> b(E, (u64)B);
+  for (int i = 0; i < E; ++i) EXPECT(x[i] < b[i] * q, "lazy inverse: entry bound %d", B);
+  for (int t = 0; t < R; ++t) {
+    const int half = 1 << t, v = R - 1 - t;
+    for (int g = 0; g < (1 << v); ++g)
+      for (int j = 0; j < half; ++j) {
+        const int i = g * 2 * half + j, k = i + half;
+        if (sc.pre[t][i]) {
+          x[i] = lazy_estimate_reduce(x[i], m);
+          b[i] = 4;
+          EXPECT(x[i] < 4 * q, "lazy inverse: estimate lands below 4q");
+        }
+        if (sc.pre[t][k]) {
+          x[k] = lazy_estimate_reduce(x[k], m);
+          b[k] = 4;
+          EXPECT(x[k] < 4 * q, "lazy inverse: estimate lands below 4q");
+        }
+        const u64 off = m.two_q << sc.off[t][i];
+        EXPECT(off >= b[k] * q || off >= x[k], "lazy inverse: offset covers the subtrahend");
+        EXPECT(x[k] <= off, "lazy inverse: difference would wrap");
+        const u64 sum = x[i] + x[k], d = x[i] + off - x[k];
+        EXPECT((b[i] + ((u64)2 << sc.off[t][i])) <= (u64)kLazyLimit, "lazy inverse: schedule passes the limit");
+        EXPECT(sum < (1ull << 63) && d < (1ull << 63), "lazy inverse: 2^63");
+        if (last && t == R - 1) {
+          x[i] = mont ? scale_by_inverse_degree(sum, il) : mul_add_lazy2<true>(0, sum, il.n1, il.n1p, m.neg_two_q);
+          x[k] = mul_add_lazy2<true>(0, d, il.n1w, il.n1wp, m.neg_two_q);
+          b[i] = b[k] = 4;
+          EXPECT((x[i] & 1) == 0 && (x[k] & 1) == 0, "lazy inverse: doubled values are even");
+        } else {
+          x[i] = sum;
+          x[k] = mul_add_lazy2<false>(0, d, wv[(1 << v) + g].x, wv[(1 << v) + g].y, m.neg_two_q);
+          b[i] = b[i] + b[k];
+          b[k] = 6;
+        }
+        EXPECT(x[i] < b[i] * q && x[k] < b[k] * q, "lazy inverse: stage bound (R %d t %d)", R, t);
+      }
+  }
+  for (int i = 0; i < E; ++i) {
+    if (sc.post[i] < 0) x[i] = lazy_estimate_reduce(x[i], m);
+    else if (sc.post[i] > 0) x[i] = lazy_csub(x[i], m, sc.post[i]);
+    EXPECT(x[i] < (u64)sc.out[i] * q, "lazy inverse: exit bound %d of element %d", sc.out[i], i);
+  }
+}
+
+// The templated device functions on the same subtree: (R, B, T, LAST, MONT) must be one of the
+// instantiations below -- the set the chains of every tile geometry and the strided passes use.
+#define LAZY_INSTANCES(X)                                                                          \
+  X(2, 32, 12) X(1, 64, 12) X(1, 12, 12) X(2, 12, 12) X(3, 12, 12) X(4, 12, 12) X(5, 12, 12)                                  \
+  X(3, 12, 16) X(3, 16, 16) X(3, 16, 32) X(3, 16, 64) X(2, 24, 12) X(1, 24, 12) X(1, 16, 12) X(3, 16, 12) \
+  X(4, 12, 8) X(4, 8, 8) X(4, 8, 32) X(2, 16, 12) X(3, 12, 32) X(3, 12, 64) X(4, 12, 32) X(4, 8, 12) X(4, 12, 64) X(4, 8, 64)
+static bool run_template(int R, int B, int T, bool last, bool mont, u64* x, const HostTw* wv,
+                         const ModConst& m, const InvLast& il) {
+#define X(RR, BB, TT)                                                                    \
+  if (R == RR && B == BB && T == TT) {                                                   \
+    if (last && mont) inv_subtree_lazy<RR, BB, TT, true, true>(x, wv, m, il);            \
+    else if (last) inv_subtree_lazy<RR, BB, TT, true, false>(x, wv, m, il);              \
+    else inv_subtree_lazy<RR, BB, TT, false, false>(x, wv, m, il);                       \
+    return true;                                                                         \
+  }
+  LAZY_INSTANCES(X)
+#undef X
+  return false;
+}
+
+struct LazyPass {
+  int stages;   // S
+  bool tile;    // tile pass (rounds of tile_geometry.h) or one strided subtree
+};
+
+static void round_shape(int S, int& rounds, int& r0, int& re) {
+  re = re_of(S);
+  rounds = (S + re - 1) / re;
+  r0 = S - (rounds - 1) * re;
+}
+
+static void check_lazy_inverse(u64 n, u64 q, const std::vector<LazyPass>& passes, u64 in_mf) {
+  int L = 0;
+  while ((1ull << L) < n) ++L;
+  std::vector<u64> R(n), Rp(n), Ri_stage(n), Rip_stage(n);
+  ho_ntt_tables(n, q, ho_minimal_primitive_root(2 * n, q), R.data(), Rp.data(), Ri_stage.data(),
+                Rip_stage.data());
+  std::vector<HostTw> V(n);
+  for (u64 i = 1; i < n; ++i) {
+    V[i].x = ho_inverse_mod(R[i], q);
+    V[i].y = ho_multiply_factor(V[i].x, 63, q);
+  }
+  const ModConst m = make_mod_const(q);
+  InvLast il{};
+  il.n1 = ho_inverse_mod(n, q);
+  il.n1w = ho_multiply_mod(il.n1, V[1].x, q);
+  il.n1p = ho_multiply_factor(il.n1, 63, q);
+  il.n1wp = ho_multiply_factor(il.n1w, 63, q);
+  il.c2 = (q - 1) / n;
+  il.log_n = (u32)L;
+  il.mont_mask = (u32)(2 * n - 1);
+  ++g_cases;
+  std::vector<u64> in(n), ref(n), x(n);
+  for (auto& v : in) v = rnd() % (in_mf * q);
+  in[0] = in_mf * q - 1;
+  in[1] = in_mf * q - 1;
+  in[2] = 0;
+  for (u64 i = 3; i < n && i < 64; i += 3) in[i] = in_mf * q - 1 - (rnd() & 3);  // large everywhere
+  ho_ntt_inverse_radix2(ref.data(), in.data(), n, q, Ri_stage.data(), Rip_stage.data(), in_mf, 1);
+  for (u64 i = 0; i < n; ++i) x[i] = to_internal<Lazy>(in[i], m);
+  int done = 0;  // stages run so far (deepest first)
+  for (size_t pi = 0; pi < passes.size(); ++pi) {
+    const LazyPass& p = passes[pi];
+    const bool pass_last = done + p.stages == L;
+    EXPECT(done + p.stages <= L, "passes longer than the network");
+    int rounds = 1, r0 = p.stages, re = p.stages;
+    if (p.tile) round_shape(p.stages, rounds, r0, re);
+    int in_pass = 0;
+    for (int j = rounds - 1; j >= 0; --j) {
+      const int r = (j == 0) ? r0 : re;
+      const int B = p.tile ? lazy_chain_entry(j, rounds, r0, re) : kLazyHandOver;
+      const int T = p.tile ? lazy_chain_thresh(j, r0, re) : kLazyHandOver;
+      const bool last = pass_last && j == 0;
+      const bool mont = last && (p.tile ? p.stages >= 6 : true);
+      const InvSched sc = make_inv_sched(r, B, kLazyLimit, T, last);
+      EXPECT(sc.peak <= kLazyLimit && (last || sc.max_out <= T), "schedule (r %d B %d T %d)", r, B, T);
+      // the subtrees of this round: heap levels [top, top + r), top = L - done - in_pass - r
+      const int top = L - done - in_pass - r;
+      const u64 cols = n >> (top + r);
+      const int E = 1 << r;
+      std::vector<u64> a(E), c(E);
+      std::vector<HostTw> wv(2 * E);
+      bool have_template = true;
+      for (u64 h = 0; h < (1ull << top); ++h)
+        for (u64 col = 0; col < cols; ++col) {
+          for (int e = 0; e < E; ++e) a[e] = c[e] = x[(h * E + e) * cols + col];
+          for (int v = 0; v < r; ++v)
+            for (int g = 0; g < (1 << v); ++g) wv[(1 << v) + g] = V[(((1ull << top) + h) << v) + g];
+          run_sched(sc, r, B, last, mont, a.data(), wv.data(), m, il);
+          if (col < 4 || col + 2 > cols) {  // the device templates on a sample of the subtrees
+            have_template = run_template(r, B, T, last, mont, c.data(), wv.data(), m, il);
+            if (have_template)
+              for (int e = 0; e < E; ++e) EXPECT(a[e] == c[e], "template != interpreter (r %d B %d T %d)", r, B, T);
+          }
+          for (int e = 0; e < E; ++e) x[(h * E + e) * cols + col] = a[e];
+        }
+      EXPECT(have_template, "no inv_subtree_lazy<%d, %d, %d> instance in the test: add it to LAZY_INSTANCES", r, B, T);
+      in_pass += r;
+    }
+    done += p.stages;
+    if (!pass_last)
+      for (u64 i = 0; i < n; ++i) EXPECT(x[i] < (u64)kLazyHandOver * q, "lazy inverse: hand-over bound between passes");
+  }
+  EXPECT(done == L, "passes do not cover the network");
+  for (int canonical = 0; canonical < 2; ++canonical)
+    for (u64 i = 0; i < n; ++i) {
+      const u64 r = inv_finish<Lazy>(x[i], m, canonical);
+      if (canonical)
+        EXPECT(r == ref[i], "lazy inv canonical mismatch at %llu", (unsigned long long)i);
+      else
+        EXPECT(r < 2 * q && r % q == ref[i], "lazy inv lazy-output mismatch at %llu", (unsigned long long)i);
+    }
+}
+
+// the plan the library picks for degree 2^L (ntt_kernels.hip: make_plan), as passes in inverse order
+static std::vector<LazyPass> library_passes(int L, bool one_kernel_14 = true) {
+  if (L <= 12 || L == 13 || (L == 14 && one_kernel_14)) return {{L, true}};
+  int bottom = L <= 16 ? 11 : 12;
+  if (L == 18 || L == 19) bottom = L - 5;
+  std::vector<LazyPass> p = {{bottom, true}};
+  int top = L - bottom;
+  if (top <= 5) {
+    p.push_back({top, false});
+  } else {
+    const int passes = (top + 3) / 4, base = top / passes, extra = top % passes;
+    std::vector<int> sizes;
+    for (int i = 0; i < passes; ++i) sizes.push_back(base + (i < extra ? 1 : 0));
+    for (int i = passes - 1; i >= 0; --i) p.push_back({sizes[i], false});  // inverse order
+  }
+  return p;
 }
 
 // Fp64 policy (2^30 <= q < 2^50): exact integers in doubles, balanced twiddles.  The
@@ -371,6 +553,31 @@ int main() {
         }
         check<Strict>(c.n, primes[pi], runs, 4, 2);
       }
+  }
+  // Lazy inverse: every degree's plan, moduli at both ends of the range, both input factors
+  for (int L = 1; L <= 17; ++L) {
+    for (int bits : {32, 44, 54, 55}) {
+      size_t got = ho_generate_primes(primes, 1, bits, 1, 1ull << L);
+      got += ho_generate_primes(primes + got, 1, bits, 0, 1ull << L);  // walking down from 2^(bits+1)
+      for (size_t pi = 0; pi < got; ++pi) {
+        if (primes[pi] < (1ull << 32) || primes[pi] >= (1ull << 56)) continue;
+        if (L >= 15 && bits != 55 && pi) continue;  // (keep the run time down)
+        check_lazy_inverse(1ull << L, primes[pi], library_passes(L), 2);
+        check_lazy_inverse(1ull << L, primes[pi], library_passes(L), 1);
+        if (L == 14) check_lazy_inverse(1ull << L, primes[pi], library_passes(L, false), 2);
+      }
+    }
+  }
+  {  // the three-pass and big-tile plans in small: same pass shapes on a 2^18 / 2^20 network are
+     // too slow here; their round and pass shapes are covered by these
+    const size_t got = ho_generate_primes(primes, 1, 55, 0, 1ull << 16);
+    if (got) {
+      check_lazy_inverse(1ull << 16, primes[0], {{12, true}, {4, false}}, 2);
+      check_lazy_inverse(1ull << 16, primes[0], {{13, true}, {3, false}}, 2);
+      check_lazy_inverse(1ull << 15, primes[0], {{14, true}, {1, false}}, 2);
+      check_lazy_inverse(1ull << 16, primes[0], {{10, true}, {2, false}, {4, false}}, 2);
+      check_lazy_inverse(1ull << 14, primes[0], {{9, true}, {5, false}}, 2);
+    }
   }
   // Small policy: q < 2^30, up to the bound (GeneratePrimes(., 29, false, .) walks down from 2^30)
   {

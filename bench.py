@@ -50,9 +50,9 @@ HBM_ACHIEVABLE_GBPS = 6290.0  # same guide: 6.29 TB/s measured with a float4 cop
 # per wave, shader clock): collected with rocprofv3 --pmc by tools/collect_profiles.sh, written
 # by tools/summarize_profiles.py together with a hash of the kernel sources they were measured
 # on.  They are NOT collected in this run; a profile of other sources is not reported.
-COUNTER_PROFILE = "r3_counters.json"
-KERNEL_SOURCES = ("ntt_kernels.hip", "modarith.h", "tile_geometry.h", "internal.h")
-# what keeps each kernel family below the HBM roofline (profiles/r3_pmc_summary.md)
+COUNTER_PROFILE = "r4_counters.json"
+KERNEL_SOURCES = ("ntt_kernels.hip", "modarith.h", "lazy_inverse.h", "tile_geometry.h", "internal.h")
+# what keeps each kernel family below the HBM roofline (profiles/r4_pmc_summary.md)
 KERNEL_LIMITER = {"ntt_fwd_strided_pass": "hbm", "ntt_inv_strided_pass": "hbm",
                   "ntt_fwd_tile_pass_bottom": "valu-issue + latency",
                   "ntt_inv_tile_pass_bottom": "valu-issue + latency"}
@@ -358,6 +358,8 @@ def sustained_run(torch, step, polys, seconds=3.0):
     """The same step loop for >= `seconds`: the power-capped steady state (a burst from idle
     runs up to 15 % off it) and long enough for an outside sampler to see the
     GPU busy.  Every step is bracketed by HIP events on the launch stream; queued 64 at a time."""
+    if seconds <= 0:  # (profile runs: BENCH_SUSTAINED_S=0)
+        return None
     torch.cuda.synchronize()
     ms, t0 = [], time.perf_counter()
     while time.perf_counter() - t0 < seconds:

@@ -566,21 +566,10 @@ def profile_stop():
     return out
 
 
-PLAN_FUSED, PLAN_SPLIT, PLAN_TILED, PLAN_MIXED = 0, 1, 2, 3
-
-
-def has_experiments():
-    """True when the loaded library was built with -DHEXL_AMD_EXPERIMENTS (the measured-and-
-    not-adopted plans: fused, tiled, mixed; tools/build_variant.sh exp -DHEXL_AMD_EXPERIMENTS,
-    HEXL_AMD_LIB=tools/libhexl_amd_exp.so)."""
-    return lib.hexl_amd_set_tuning(b"experiments", 1) == 0
-
-
 def set_tuning(key, value):
-    """Tuning / diagnostic knobs of the transform launch logic (include/hexl_amd.h):
-    "tile13", "fp64" and "h60" (both read at plan creation); in experiments builds also "plan"
-    (PLAN_FUSED / PLAN_SPLIT / PLAN_TILED / PLAN_MIXED), "fused_window", "fused_min_batch",
-    "fused_wg_per_cu", "mixed_chunk".  Results never depend on them."""
+    """Tuning knobs (include/hexl_amd.h documents them): "fp64", "h60" (both read when a plan is
+    created), "tile13", "bigtile", "host_bounce_kb", "host_pipeline_min_mb", "host_chunk_mb".
+    The library reads no environment variable; results never depend on the knobs."""
     _check(lib.hexl_amd_set_tuning(key.encode(), int(value)))
 
 

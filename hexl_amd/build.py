@@ -91,6 +91,16 @@ def build(verbose=False):
                    "-D__HIP_PLATFORM_AMD__", "-shared", shim_src, "-o", dbg, f"-L{LIB}",
                    "-lhexl_amd", "-Wl,-rpath,$ORIGIN"]
             subprocess.check_call(cmd)
+    # the static flavour: the reference's DEFAULT build is a static library (CMakeLists.txt:61
+    # HEXL_SHARED_LIB OFF -> hexl/CMakeLists.txt:53-57 add_library(hexl STATIC ...)): libhexl.a =
+    # the shim + the C-ABI + the kernels (every object carries its own gfx950 code object and
+    # registers it at start-up: no device link step), to be linked with libamdhip64
+    if shim_objs:
+        static = os.path.join(LIB, "libhexl.a")
+        if not _newer(static, shim_objs + core_objs):
+            if os.path.exists(static):
+                os.remove(static)
+            subprocess.check_call(["ar", "rcs", static] + shim_objs + core_objs)
     if verbose:
         print("built", core, "and", shim if shim_objs else "(no shim yet)")
     return core

@@ -4,6 +4,7 @@
 // no CPU fallback -- if HIP is unusable every compute entry point fails.
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -807,7 +808,7 @@ int hexl_amd_ntt_inverse_rns(const hexl_amd_ntt* const* plans, uint64_t num_plan
 }
 
 // Host buffers (what an unmodified intel::hexl caller hands over): stage to the device,
-// transform, copy back.  Optionally (HEXL_AMD_HOST_PIPELINE_MIN_MB=<size>) large calls are
+// transform, copy back.  Optionally (set_tuning "host_pipeline_min_mb") large calls are
 // cut into chunks that alternate between two streams, each with its own device staging
 // buffer, the caller's pages pinned for the duration of the call (hipHostRegister), so
 // that the H2D copy of chunk k+1 runs under the kernels and the D2H copy of chunk k.
@@ -815,31 +816,28 @@ int hexl_amd_ntt_inverse_rns(const hexl_amd_ntt* const* plans, uint64_t num_plan
 // and 53 GB/s in both directions together, from pageable memory as fast as from pinned
 // (tools/pcie_probe.py), so the plain sequence below already runs at the link rate
 // (54-55 GB/s in+out, tools/host_path_rate.py) and pipelining gains nothing.
-static size_t host_pipeline_min_bytes() {
-  static const size_t v = [] {
-    const char* e = getenv("HEXL_AMD_HOST_PIPELINE_MIN_MB");
-    return e && atol(e) > 0 ? (size_t)atol(e) << 20 : ~(size_t)0;
-  }();
-  return v;
-}
-static size_t host_chunk_bytes() {
-  static const size_t v = [] {
-    const char* e = getenv("HEXL_AMD_HOST_CHUNK_MB");
-    return (size_t)(e && atol(e) > 0 ? atol(e) : 16) << 20;
-  }();
-  return v;
-}
-
+// Knobs of the host path (hexl_amd_set_tuning; no environment variable is read).
+static std::atomic<size_t> g_host_pipeline_min_bytes{~(size_t)0};  // "host_pipeline_min_mb": off
+static std::atomic<size_t> g_host_chunk_bytes{(size_t)16 << 20};   // "host_chunk_mb"
 // Largest call (bytes of operand) that goes through the mapped bounce buffer: beyond it the
 // host-side copies cost as much as the DMA they replace (measured: N = 65536, 512 KiB: 82 us
 // against 88 staged; N = 131072: 185 against 144; reading only the operand through the buffer:
-// 80 / 142).  HEXL_AMD_HOST_BOUNCE_KB overrides; 0 switches the bounce path off.
-static size_t host_bounce_max_bytes() {
-  static const size_t v = [] {
-    const char* e = getenv("HEXL_AMD_HOST_BOUNCE_KB");
-    return (size_t)(e ? atol(e) : 256) << 10;
-  }();
-  return v;
+// 80 / 142).  "host_bounce_kb"; 0 switches the bounce path off.
+static std::atomic<size_t> g_host_bounce_max_bytes{(size_t)256 << 10};
+static size_t host_pipeline_min_bytes() { return g_host_pipeline_min_bytes.load(); }
+static size_t host_chunk_bytes() { return g_host_chunk_bytes.load(); }
+static size_t host_bounce_max_bytes() { return g_host_bounce_max_bytes.load(); }
+static bool set_host_tuning(const char* key, uint64_t value) {
+  if (strcmp(key, "host_bounce_kb") == 0 && value <= (1u << 20)) {
+    g_host_bounce_max_bytes = (size_t)value << 10;
+  } else if (strcmp(key, "host_pipeline_min_mb") == 0 && value <= (1u << 20)) {
+    g_host_pipeline_min_bytes = value ? (size_t)value << 20 : ~(size_t)0;
+  } else if (strcmp(key, "host_chunk_mb") == 0 && value >= 1 && value <= (1u << 14)) {
+    g_host_chunk_bytes = (size_t)value << 20;
+  } else {
+    return false;
+  }
+  return true;
 }
 
 static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t* operand,
@@ -1610,6 +1608,7 @@ int hexl_amd_release_workspaces(void) {
 
 int hexl_amd_set_tuning(const char* key, uint64_t value) {
   if (!key) return fail(HEXL_AMD_ERR_INVALID_ARG, "key == nullptr");
+  if (set_host_tuning(key, value)) return HEXL_AMD_OK;
   if (set_tuning(key, value) != 0)
     return fail(HEXL_AMD_ERR_INVALID_ARG, "unknown tuning key or value out of range: %s", key);
   return HEXL_AMD_OK;

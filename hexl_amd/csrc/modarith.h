@@ -176,7 +176,7 @@ HX_HD u32 mul_hi32(u32 a, u32 b) { return (u32)(((u64)a * b) >> 32); }
 // in ONE instruction with the zero as an inline constant: D.lo = S0[op_sel[0]] = S.hi,
 // D.hi = S1[op_sel[1]] = 0.
 HX_HD u64 high_word(u64 S) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(HEXL_AMD_NO_PK_MOV)
+#if defined(__HIP_DEVICE_COMPILE__)
   u64 r;
   asm("v_pk_mov_b32 %0, %1, 0 op_sel:[1,0]" : "=v"(r) : "v"(S));
   return r;

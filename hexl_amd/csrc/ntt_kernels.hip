@@ -30,8 +30,9 @@
 //                   heap level log2(N) - S ("bottom" stages; N <= 2^14 is this
 //                   kernel alone, one HBM round trip: a 64 KiB tile for N = 2^13,
 //                   a 128 KiB tile with 16 elements per thread for N = 2^14);
-//       CB = TL - S all 2^S rows x 2^CB adjacent columns of one polynomial ("top"
-//                   stages of the HEXL_AMD_PLAN=tiled alternative).
+//       CB = TL - S all 2^S rows x 2^CB adjacent columns of one polynomial ("top" stages:
+//                   the geometry is general, but no plan instantiates it -- the two-tile-pass
+//                   plan it served measured 4 % slower, experiments/).
 //     LDS slots are XOR-swizzled so that every ds_read_b64 / ds_write_b64 pattern
 //     of every round is bank-conflict free (SQ_LDS_BANK_CONFLICT = 0); the swizzle
 //     is linear over XOR, so an element's address is its thread's base address
@@ -43,8 +44,7 @@
 //
 // Values stay lazy as in the reference's Harvey butterflies
 // (hexl/ntt/ntt-default.hpp:28-42, :112-125); see modarith.h for the five
-// arithmetic policies.  Below the kernels: fused_pass (both passes in one
-// persistent launch: measured slower, opt-in), the multi-plan variants
+// arithmetic policies.  Below the kernels: the multi-plan variants
 // (polynomials of several moduli in one launch: RNS limbs, KeySwitch), and the
 // host-side planning.  Canonical outputs (output_mod_factor == 1) are bit-identical to the
 // reference; lazy outputs are congruent and inside the reference's ranges.
@@ -75,7 +75,7 @@
 #else
 #define HX_TU_POLICY(p) (HEXL_AMD_TU == (p))
 #define HX_TU_DISPATCH (HEXL_AMD_TU < 0)
-#if defined(HEXL_AMD_PHASE_PROFILE) || defined(HEXL_AMD_FUSED_STATS)
+#if defined(HEXL_AMD_PHASE_PROFILE)
 #error "developer builds with device-side diagnostics are single translation units"
 #endif
 #endif
@@ -122,15 +122,11 @@ constexpr u32 kReduceFirst = 8;
 // exactly once, and marking the accesses so is worth 4-6 % on the HBM-bound strided
 // pass and 3 % on the forward tile pass (measured; on the inverse tile pass it is
 // neutral and slows the strided pass that follows, so it is not used there).
-// kL2 (loads only) = agent-scope relaxed atomic load, `global_load ... sc1`: served
-// by the XCD's L2, never by the CU's vector L1 -- how the second phase of
-// fused_pass reads what another CU of the same XCD has just written.
-enum : int { kPlain = 0, kStream = 1, kL2 = 2 };
+enum : int { kPlain = 0, kStream = 1 };
 
 template <int KIND>
 __device__ __forceinline__ u64 ld_global(const u64* p) {
   if (KIND == kStream) return __builtin_nontemporal_load(p);
-  if (KIND == kL2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return *p;
 }
 template <int KIND>
@@ -661,12 +657,7 @@ __device__ __forceinline__ void round_twiddles(T* wv, const T* __restrict__ tw, 
     // sub-block-and-group index of the run: the bits of vt above the gap, minus
     // the column bits (which do not select a twiddle)
     u32 node = level + (((g.tile_blk0 << u) + vt_high<w, TL, RD::kRE>(s, tid)) & (level - 1));
-#ifndef HX_EXP_NO_SCALAR_TW  // developer experiment: per-lane loads for every twiddle
     if (w >= 6) node = __builtin_amdgcn_readfirstlane(node);  // uniform across the wave
-#endif
-#ifdef HX_EXP_UNIFORM_TW  // developer experiment (WRONG results): no per-lane twiddle traffic
-    node = __builtin_amdgcn_readfirstlane(node);
-#endif
     load_twiddles<r, CTW>(wv + (s << r), tw, node);
   }
 }
@@ -677,10 +668,6 @@ __device__ __forceinline__ void round_compute(u64* x, const TwT<A>* wv, const Mo
   constexpr int kRE = re_of(S), kE = el_of(S);
   constexpr int r = Rounds<S, CB>::r(j);
   constexpr int SS = kE >> r;
-#ifdef HX_EXP_NOCOMPUTE  // developer experiment: data movement only
-  if constexpr (!A::kFp) x[0] += wv[1].x;
-  return;
-#endif
 #pragma unroll
   for (int s = 0; s < SS; ++s) {
     if (FWD)
@@ -744,67 +731,6 @@ __device__ __forceinline__ void handover() {
   }
 }
 
-// Developer experiment (-DHEXL_AMD_XLANE=1, tools/xlane_ab.py): the
-// hand-over between the two in-wave rounds whose gaps are 2^6 and 2^3 done in registers with
-// the cross-lane instructions instead of through LDS.  Element p = (h | a | b | l) (3-bit
-// fields a = p[6..8], b = p[3..5]) is register a of lane (b, l) in the gap-2^6 round and
-// register b of lane (a, l) in the gap-2^3 round: an 8 x 8 transpose between the register
-// index and lane bits 3..5, three exchange steps -- register bit k <-> lane bit 3 + k -- each
-// swapping x[r | 2^k] of the lanes with the bit clear against x[r] of their partners:
-//   lane bit 5: v_permlane32_swap (lanes 32-63 of vdst <-> lanes 0-31 of src), 8 per step;
-//   lane bit 4: v_permlane16_swap (odd rows of vdst <-> even rows of src), 8 per step;
-//   lane bit 3: no swap instruction: two v_mov_b32 row_ror:8 with bank masks and a copy, 24.
-// 40 VALU instructions (+ hazard nops) against 8 ds_write_b64 + 8 ds_read_b64 + 7 v_xor.
-#ifndef HEXL_AMD_XLANE
-#define HEXL_AMD_XLANE 0
-#endif
-__device__ __forceinline__ void xlane_swap_bit(u32& lo_r, u32& hi_r /* x[r | 2^k] */, u32& lo_0,
-                                               u32& hi_0 /* x[r] */, int k) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  if (k == 2) {
-    auto a = __builtin_amdgcn_permlane32_swap(lo_0, lo_r, false, false);
-    lo_0 = a[0]; lo_r = a[1];
-    auto b = __builtin_amdgcn_permlane32_swap(hi_0, hi_r, false, false);
-    hi_0 = b[0]; hi_r = b[1];
-  } else if (k == 1) {
-    auto a = __builtin_amdgcn_permlane16_swap(lo_0, lo_r, false, false);
-    lo_0 = a[0]; lo_r = a[1];
-    auto b = __builtin_amdgcn_permlane16_swap(hi_0, hi_r, false, false);
-    hi_0 = b[0]; hi_r = b[1];
-  } else {  // lanes 8-15 of each row take x[r | 1] of lanes 0-7, which take their x[r]
-    const u32 t_lo = lo_0, t_hi = hi_0;
-    lo_0 = __builtin_amdgcn_update_dpp(lo_0, lo_r, 0x128 /* row_ror:8 */, 0xF, 0xC, false);
-    hi_0 = __builtin_amdgcn_update_dpp(hi_0, hi_r, 0x128, 0xF, 0xC, false);
-    lo_r = __builtin_amdgcn_update_dpp(lo_r, t_lo, 0x128, 0xF, 0x3, false);
-    hi_r = __builtin_amdgcn_update_dpp(hi_r, t_hi, 0x128, 0xF, 0x3, false);
-  }
-#endif
-}
-__device__ __forceinline__ void xlane_transpose8(u64* x) {
-  u32 lo[8], hi[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    lo[e] = (u32)x[e];
-    hi[e] = (u32)(x[e] >> 32);
-  }
-#pragma unroll
-  for (int k = 2; k >= 0; --k)
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-      if (!((r >> k) & 1)) xlane_swap_bit(lo[r | (1 << k)], hi[r | (1 << k)], lo[r], hi[r], k);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) x[e] = ((u64)hi[e] << 32) | lo[e];
-}
-// whether the hand-over between rounds J and J + 1 (forward order) is done across lanes
-template <int S, int CB, int J>
-constexpr bool xlane_boundary() {
-  using RD = Rounds<S, CB>;
-  // (J >= 1: round 0 of the forward pass / the last round of the inverse are handled in
-  // tile_body, straight from / to global memory)
-  return HEXL_AMD_XLANE && re_of(S) == 3 && J >= 1 && J + 1 < RD::NR && RD::r(J) == 3 &&
-         RD::r(J + 1) == 3 && RD::w(J) == 6 && RD::w(J + 1) == 3;
-}
-
 // forward rounds J .. NR-1: LDS -> registers -> subtree -> same LDS slots.
 // `pre` holds the twiddles of round J when Rounds::pre_fwd(J).
 template <int S, int CB, int TL, int J, class A, bool CTW = false>
@@ -820,16 +746,11 @@ __device__ __forceinline__ void fwd_mid_rounds(u64* x, u64* lds, const TwT<A>* t
       round_twiddles<S, CB, TL, J, CTW>(wv, tw, tid, g);
       w = wv;
     }
-    // (cross-lane experiment: the values arrived in registers / leave in registers)
-    if constexpr (!xlane_boundary<S, CB, J - 1>()) lds_load_round<S, CB, TL, J>(x, lds, tid);
+    lds_load_round<S, CB, TL, J>(x, lds, tid);
     if constexpr (RD::pre_fwd(J + 1)) round_twiddles<S, CB, TL, J + 1, CTW>(wn, tw, tid, g);
     round_compute<S, CB, J, A, true, false>(x, w, m, il);
-    if constexpr (xlane_boundary<S, CB, J>()) {
-      xlane_transpose8(x);
-    } else {
-      lds_store_round<S, CB, TL, J>(x, lds, tid);
-      handover<RD::w(J), RD::r(J) == kRE>();
-    }
+    lds_store_round<S, CB, TL, J>(x, lds, tid);
+    handover<RD::w(J), RD::r(J) == kRE>();
     HX_STAMP(3 + J);
     fwd_mid_rounds<S, CB, TL, J + 1, A, CTW>(x, lds, tw, tid, g, m, il, wn);
   }
@@ -852,16 +773,12 @@ __device__ __forceinline__ void inv_mid_rounds(u64* x, u64* lds, const TwT<A>* t
       round_twiddles<S, CB, TL, J, CTW>(wv, tw, tid, g);
       w = wv;
     }
-    if constexpr (!xlane_boundary<S, CB, J>()) lds_load_round<S, CB, TL, J>(x, lds, tid);
+    lds_load_round<S, CB, TL, J>(x, lds, tid);
     if constexpr (RD::pre_inv(J - 1)) round_twiddles<S, CB, TL, J - 1, CTW>(J == 1 ? pre0 : wn, tw, tid, g);
     round_compute<S, CB, J, A, false, false>(x, w, m, il);
-    if constexpr (xlane_boundary<S, CB, J - 1>()) {
-      xlane_transpose8(x);  // (the exchange is its own inverse)
-    } else {
-      lds_store_round<S, CB, TL, J>(x, lds, tid);
-      // the next (shallower) round J-1 regroups across waves iff its gap exceeds a wave
-      handover<RD::w(J - 1), RD::r(J - 1) == kRE>();
-    }
+    lds_store_round<S, CB, TL, J>(x, lds, tid);
+    // the next (shallower) round J-1 regroups across waves iff its gap exceeds a wave
+    handover<RD::w(J - 1), RD::r(J - 1) == kRE>();
     HX_STAMP(3 + (RD::NR - 1 - J));
     inv_mid_rounds<S, CB, TL, J - 1, A, CTW>(x, lds, tw, tid, g, m, il, wn, pre0);
   }
@@ -898,15 +815,11 @@ __device__ __forceinline__ void fetch_tile(u64* x, const u64* in, u32 tid, const
   for (int i = 0; i < kE; ++i) {
     const u32 p0 = xfer_p0<ROUND0, S, CB, TL>(tid, i);
     const u32 dp = xfer_dp<ROUND0, S, CB>(i);
-#ifdef HX_EXP_NOMEM  // developer experiment: no global traffic
-    x[i] = (u64)(p0 + dp) * 0x9E3779B97F4A7C15ULL >> 10;
-#else
     const u64* src = in + tile_uniform_offset<CB>(g, dp);
     if (GUARD)
       x[i] = (g.base + p0 + dp < total) ? load_global<LDK>(src, tile_byte_offset<CB>(g, p0)) : 0;
     else
       x[i] = load_global<LDK>(src, tile_byte_offset<CB>(g, p0));
-#endif
   }
   if constexpr (!CONVERT) return;
   if (flags & kFirstPass) {
@@ -936,12 +849,8 @@ __device__ __forceinline__ void store_elem(u64* out, u32 tid, int i, u64 v,
                                            const TileGeom& g, u64 total) {
   const u32 p0 = xfer_p0<ROUND0, S, CB, TL>(tid, i);
   const u32 dp = xfer_dp<ROUND0, S, CB>(i);
-#ifdef HX_EXP_NOMEM
-  if (v == 0x123456789ULL) out[g.base + p0 + dp] = v;  // keeps the value live, ~never stores
-#else
   if (!GUARD || g.base + p0 + dp < total)
     store_global<STK>(out + tile_uniform_offset<CB>(g, dp), tile_byte_offset<CB>(g, p0), v);
-#endif
 }
 
 // End of a forward tile pass: the 512-element run this wave owns after the last round goes
@@ -1127,15 +1036,6 @@ tile_pass_multi(u64* out, const u64* in, MultiCtx mc, u32 log_n, u32 flags, u64 
       lds, out, in, FWD ? mc.tw_fwd[k] : mc.tw_inv[k], m, log_n, flags, total, il, blockIdx.x);
 }
 
-#ifdef HEXL_AMD_EXPERIMENTS
-// The plans that were built, verified bit-exact, measured and NOT adopted (mixed_pass,
-// fused_pass, the two-tile-pass "tiled" plan): compiled only with -DHEXL_AMD_EXPERIMENTS
-// (tools/build_variant.sh exp -DHEXL_AMD_EXPERIMENTS); the default build holds what make_plan
-// can select.
-#define HX_EXP_SECTION 1
-#include "ntt_experiments.inc"
-#undef HX_EXP_SECTION
-#endif
 
 // ---------------------------------------------------------------------------
 // Host-side planning and launch
@@ -1271,59 +1171,24 @@ static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2
   return hipGetLastError();
 }
 
-// Plan of one transform: an optional top tile_pass of `top_tile` stages (or
-// `n_strided` register-only passes), then a bottom tile_pass of `bottom` stages;
-// `tl` = log2 of the tile size both tile passes use.
+// Plan of one transform: `n_strided` register-only passes, then a bottom tile_pass of `bottom`
+// stages on tiles of 2^tl elements.  Degrees up to 2^12 (and 2^13, 2^14 on their big tiles) are
+// the tile pass alone: one launch, one HBM round trip; above, one strided pass (two for 2^20)
+// plus the tile pass.  (The plans that were built, measured and not adopted -- both passes in one
+// persistent launch, two LDS-tiled launches, mixed launches over chunks -- are archived under
+// experiments/.)
 struct Plan {
-  int tl;      // tile size (log2) of the tile passes
-  int top_tile;
+  int tl;      // tile size (log2) of the tile pass
   int n_strided;
   int strided[8];
   int bottom;
 };
 
-// Default for N >= 2^13: register-only strided pass(es) + an 11- or 12-stage
-// bottom tile_pass, two launches (kPlanSplit).  Builds with -DHEXL_AMD_EXPERIMENTS also hold
-// the plans that were measured and not adopted (ntt_experiments.inc): HEXL_AMD_PLAN=fused
-// runs the two passes as ONE persistent launch for N = 2^15, 2^16 (fused_pass; bit-exact,
-// 10 % slower than two launches), HEXL_AMD_PLAN=tiled selects two LDS-tiled
-// kernels (6 + 10 stages on 1024-element tiles for N = 2^16; 4 % slower), HEXL_AMD_PLAN=mixed
-// the chunk pipeline of mixed launches (as fast as two launches).
-enum PlanMode { kPlanFused = 0, kPlanSplit = 1, kPlanTiled = 2, kPlanMixed = 3 };
-static u32 env_u32(const char* name, u32 dflt) {
-  const char* e = getenv(name);
-  if (!e || !*e) return dflt;
-  const long v = atol(e);
-  return v > 0 ? (u32)v : dflt;
-}
-// Process-wide tuning state: defaults from the environment, changeable at run time
-// through hexl_amd_set_tuning (tests compare the plans in one process).
+// Process-wide tuning state (hexl_amd_set_tuning; include/hexl_amd.h documents the keys).  The
+// library reads no environment variable: every knob has a compiled-in default and changes only
+// through that call.  Results never depend on it.
 struct Tuning {
-  std::atomic<u32> plan, fused_window, fused_min_batch, fused_wg_per_cu, fp64, tile13, mixed_chunk, h60;
-  Tuning() {
-#ifdef HEXL_AMD_EXPERIMENTS
-    const char* e = getenv("HEXL_AMD_PLAN");
-    plan = (e && strcmp(e, "tiled") == 0)   ? kPlanTiled
-           : (e && strcmp(e, "fused") == 0) ? kPlanFused
-           : (e && strcmp(e, "mixed") == 0) ? kPlanMixed
-                                            : kPlanSplit;
-#else
-    plan = kPlanSplit;
-#endif
-    mixed_chunk = env_u32("HEXL_AMD_MIXED_CHUNK", 512);
-    // Slots (polynomials) an XCD may have in flight between the first phase-1 claim
-    // and the last phase-2 claim; the smallest batch the fused launch is used for;
-    // workgroups per CU of the persistent grid (0 = occupancy query).
-    fused_window = env_u32("HEXL_AMD_FUSED_WINDOW", 10);
-    fused_min_batch = env_u32("HEXL_AMD_FUSED_MIN_BATCH", 64);
-    fused_wg_per_cu = env_u32("HEXL_AMD_FUSED_WG_PER_CU", 0);
-    const char* f = getenv("HEXL_AMD_FP64");
-    fp64 = (f && f[0] == '0') ? 0 : (f && f[0] == '2') ? 2 : 1;
-    const char* h = getenv("HEXL_AMD_H60");
-    h60 = (h && h[0] == '0') ? 0 : 1;
-    const char* t13 = getenv("HEXL_AMD_TILE13");
-    tile13 = (t13 && t13[0] == '0') ? 0 : (t13 && t13[0] == '1') ? 1 : 2;
-  }
+  std::atomic<u32> fp64{1}, h60{1}, tile13{2}, bigtile{1};
 };
 Tuning& tuning();  // one per process: defined by the dispatch unit
 #if HX_TU_DISPATCH
@@ -1333,30 +1198,14 @@ Tuning& tuning() {
 }
 int set_tuning(const char* key, u64 value) {
   Tuning& t = tuning();
-#ifdef HEXL_AMD_EXPERIMENTS
-  if (strcmp(key, "experiments") == 0 && value == 1) return 0;  // "is this an experiments build?"
-  if (strcmp(key, "plan") == 0 && value <= kPlanMixed) t.plan = (u32)value;
-  else if (strcmp(key, "mixed_chunk") == 0 && value >= 1 && value < (1u << 20)) t.mixed_chunk = (u32)value;
-  else if (strcmp(key, "fused_window") == 0 && value < (1u << 16)) t.fused_window = (u32)value;
-  else if (strcmp(key, "fused_min_batch") == 0 && value >= 1) t.fused_min_batch = (u32)value;
-  else if (strcmp(key, "fused_wg_per_cu") == 0) t.fused_wg_per_cu = (u32)value;
-#else
-  // (the default build holds the split plan only; the other plan keys are refused)
-  if (strcmp(key, "plan") == 0 && value == kPlanSplit) t.plan = (u32)value;
-#endif
-  else if (strcmp(key, "fp64") == 0 && value <= 2) t.fp64 = (u32)value;
+  if (strcmp(key, "fp64") == 0 && value <= 2) t.fp64 = (u32)value;
   else if (strcmp(key, "tile13") == 0 && value <= 2) t.tile13 = (u32)value;
   else if (strcmp(key, "h60") == 0 && value <= 1) t.h60 = (u32)value;
+  else if (strcmp(key, "bigtile") == 0 && value <= 1) t.bigtile = (u32)value;
   else return -1;
   return 0;
 }
 #endif  // HX_TU_DISPATCH
-#ifdef HEXL_AMD_EXPERIMENTS
-static PlanMode plan_mode() { return (PlanMode)tuning().plan.load(); }
-static bool plan_strided_requested() { return plan_mode() != kPlanTiled; }
-static u32 fused_window() { return tuning().fused_window.load(); }
-static u64 fused_min_batch() { return tuning().fused_min_batch.load(); }
-#endif
 
 static Plan make_plan(int L, bool allow_tile13 = true, u64 batch = ~0ull) {
   Plan p{};
@@ -1380,30 +1229,15 @@ static Plan make_plan(int L, bool allow_tile13 = true, u64 batch = ~0ull) {
     p.bottom = 13;
     return p;
   }
-#ifdef HEXL_AMD_EXPERIMENTS
-  if (plan_strided_requested())
-#endif
   {
     // 11 bottom stages on 2048-element tiles up to N = 2^16 (strided pass of <= 5
     // stages: both kernels then carry a comparable share of the arithmetic), 12 on
-    // 4096-element tiles above.  (Experiments builds: HEXL_AMD_BOTTOM=11|12 overrides.)
+    // 4096-element tiles above.
     p.bottom = L <= 16 ? 11 : 12;
     // N = 2^18, 2^19: five strided stages + the 13- / 14-stage tile pass on the 64 / 128 KiB
     // tiles of the one-kernel plans -- two HBM round trips instead of three (3 + 3 + 12,
-    // 4 + 3 + 12 stages); round 3.  HEXL_AMD_BIGTILE=0: the three-pass plans (A/B runs).
-    static const bool big_tile = [] {
-      const char* e = getenv("HEXL_AMD_BIGTILE");
-      return !(e && e[0] == '0');
-    }();
-    if (big_tile && (L == 18 || L == 19)) p.bottom = L - 5;
-#ifdef HEXL_AMD_EXPERIMENTS
-    static const int bottom_override = [] {
-      const char* e = getenv("HEXL_AMD_BOTTOM");
-      return e ? atoi(e) : 0;
-    }();
-    if ((bottom_override == 11 || bottom_override == 12) && L - bottom_override >= 1)
-      p.bottom = bottom_override;
-#endif
+    // 4 + 3 + 12 stages); round 3.  set_tuning("bigtile", 0): the three-pass plans.
+    if (tuning().bigtile.load() && (L == 18 || L == 19)) p.bottom = L - 5;
     p.tl = p.bottom;
     int top = L - p.bottom;
     if (top <= 5) {
@@ -1415,20 +1249,6 @@ static Plan make_plan(int L, bool allow_tile13 = true, u64 batch = ~0ull) {
     }
     return p;
   }
-#ifdef HEXL_AMD_EXPERIMENTS  // the "tiled" plan: two LDS-tiled kernels
-  if (L <= 16) {  // 1024-element tiles: top <= 6 stages, bottom <= 10
-    p.tl = 10;
-    const int half = (L + 1) / 2;
-    p.bottom = half > L - 6 ? half : L - 6;
-    p.top_tile = L - p.bottom;
-    return p;
-  }
-  // 4096-element tiles: 8-stage top, bottom 9..12
-  p.tl = 12;
-  p.top_tile = 8;
-  p.bottom = L - 8;
-  return p;
-#endif
 }
 
 template <bool FWD, class A>
@@ -1447,11 +1267,6 @@ static hipError_t launch_bottom_tl(int tl, int S, u64* out, const u64* in, const
   return launch_bottom<FWD, 12, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc);
 }
 
-#ifdef HEXL_AMD_EXPERIMENTS
-#define HX_EXP_SECTION 2
-#include "ntt_experiments.inc"
-#undef HX_EXP_SECTION
-#endif
 
 // One transform of `batch` polynomials on stream `st`.
 template <class A>
@@ -1462,16 +1277,6 @@ static hipError_t forward_seq(const NttTables& t, const Plan& p, u64* result, co
   InvLast il{};
   hipError_t e;
   u32 first = kFirstPass;  // consumed by whichever pass runs first
-#ifdef HEXL_AMD_EXPERIMENTS
-  if (p.top_tile) {
-    if (mc) return hipErrorNotSupported;
-    e = launch_top_tl<true, A>(p.tl, p.top_tile, result, src, t.fwd, t.mod,
-                               t.log_n, first, batch, il, st);
-    if (e != hipSuccess) return e;
-    src = result;
-    first = 0;
-  }
-#endif
   u32 a0 = 0;
   for (int i = 0; i < p.n_strided; ++i) {
     e = launch_strided<true, A>(p.strided[i], result, src, t.fwd, t.mod, t.log_n, a0, first,
@@ -1491,8 +1296,7 @@ static hipError_t inverse_seq(const NttTables& t, const Plan& p, u64* result, co
                               u64 batch, u64 out_mf, hipStream_t st,
                               const MultiCtx* mc = nullptr) {
   const u32 fin = out_mf == 1 ? 2 : 1;
-  const bool only = !p.top_tile && p.n_strided == 0;
-  if (mc && p.top_tile) return hipErrorNotSupported;
+  const bool only = p.n_strided == 0;
   hipError_t e = launch_bottom_tl<false, A>(p.tl, p.bottom, result, operand, t.inv, t.mod, t.log_n,
                                             kFirstPass | (only ? fin : 0), batch, t.inv_last, st,
                                             mc);
@@ -1504,11 +1308,6 @@ static hipError_t inverse_seq(const NttTables& t, const Plan& p, u64* result, co
                                  i == 0 ? fin : 0, batch, t.inv_last, st, mc);
     if (e != hipSuccess) return e;
   }
-#ifdef HEXL_AMD_EXPERIMENTS
-  if (p.top_tile)
-    return launch_top_tl<false, A>(p.tl, p.top_tile, result, result, t.inv,
-                                   t.mod, t.log_n, fin, batch, t.inv_last, st);
-#endif
   return hipSuccess;
 }
 
@@ -1521,18 +1320,6 @@ template <bool FWD, class A>
 static hipError_t transform_impl(const NttTables& t, u64* result, const u64* operand, u64 batch,
                                  u64 out_mf, hipStream_t st) {
   const Plan p = make_plan((int)t.log_n, true, batch);
-#ifdef HEXL_AMD_EXPERIMENTS
-  if constexpr (!A::kH60) {  // (fused_pass is not instantiated for the Harvey60 policy)
-    if (plan_mode() == kPlanFused && p.n_strided == 1 && p.bottom == 11 && !p.top_tile &&
-        p.strided[0] >= 4 && batch >= fused_min_batch() && batch < (1ull << 23))
-      return launch_fused<FWD, A>(p.strided[0], t, result, operand, batch, out_mf == 1 ? 2 : 1, st);
-  }
-  if constexpr (A::kLazy || A::kFp) {  // the policies mixed_pass is instantiated for
-    if (plan_mode() == kPlanMixed && t.log_n == 16 && batch >= 2 * (u64)tuning().mixed_chunk.load() &&
-        batch < (1ull << 24))
-      return launch_mixed<FWD, A>(t, result, operand, batch, out_mf, st);
-  }
-#endif
   return FWD ? forward_seq<A>(t, p, result, operand, batch, out_mf, st)
              : inverse_seq<A>(t, p, result, operand, batch, out_mf, st);
 }
@@ -1542,9 +1329,6 @@ static hipError_t multi_impl(bool forward, const NttTables& t0, const MultiCtx& 
                              u64* result, const u64* operand, u64 out_mf, hipStream_t st) {
   // the multi-plan kernels: 11 / 12 bottom stages, or the whole of N = 8192 / 16384
   Plan p = make_plan((int)t0.log_n, /*allow_tile13=*/true, polys);
-#ifdef HEXL_AMD_EXPERIMENTS
-  if (plan_mode() == kPlanTiled) return hipErrorNotSupported;
-#endif
   return forward ? forward_seq<A>(t0, p, result, operand, polys, out_mf, st, &mc)
                  : inverse_seq<A>(t0, p, result, operand, polys, out_mf, st, &mc);
 }
@@ -1618,7 +1402,7 @@ hipError_t ntt_inverse_launch(const NttTables& t, u64* result, const u64* operan
 
 bool ntt_is_single_kernel(const NttTables& t, u64 batch) {
   const Plan p = make_plan((int)t.log_n, true, batch);
-  return p.n_strided == 0 && p.top_tile == 0;
+  return p.n_strided == 0;
 }
 #endif  // HX_TU_DISPATCH
 
@@ -1630,11 +1414,7 @@ bool ntt_is_single_kernel(const NttTables& t, u64 batch) {
 // would leave half-transformed data behind).  Mirrors the shape checks of launch_strided /
 // launch_bottom.
 static bool multi_plan_supported(u32 log_n, u64 polys) {
-#ifdef HEXL_AMD_EXPERIMENTS
-  if (plan_mode() == kPlanTiled) return false;
-#endif
   const Plan p = make_plan((int)log_n, /*allow_tile13=*/true, polys);
-  if (p.top_tile) return false;
   if (p.bottom < 11 || p.bottom > 14 || p.tl != p.bottom || log_n < (u32)p.tl) return false;
   u32 a0 = 0;
   for (int i = 0; i < p.n_strided; ++i) {

@@ -8,16 +8,10 @@
 
 namespace hexl_amd {
 
-#ifndef HEXL_AMD_RE
-#define HEXL_AMD_RE 3
-#endif
 // log2 elements per thread: 3 (8 elements, rounds of 3 stages) for every tile pass but the
 // 14-stage one of N = 2^14, whose 128 KiB tile is one 1024-thread workgroup per CU with 16
 // elements per thread (rounds of 4 stages, 4 waves per SIMD, <= 128 VGPRs).
-#ifndef HEXL_AMD_RE12  // developer experiment: elements per thread of the 12-stage tile pass
-#define HEXL_AMD_RE12 HEXL_AMD_RE
-#endif
-constexpr int re_of(int S) { return S >= 14 ? 4 : S == 12 ? HEXL_AMD_RE12 : HEXL_AMD_RE; }
+constexpr int re_of(int S) { return S >= 14 ? 4 : 3; }
 constexpr int el_of(int S) { return 1 << re_of(S); }
 constexpr int kMaxTileLog = 14;
 

@@ -6,6 +6,10 @@
     <prefix>/lib/libhexl.so, libhexl_amd.so, libhexl_debug.so (the HEXL_DEBUG flavour: the
                                                 reference's debug builds name theirs hexl_debug,
                                                 hexl/CMakeLists.txt:68-72; target HEXL::hexl_debug)
+    <prefix>/lib/libhexl.a                      the static flavour (shim + C-ABI + kernels in one
+                                                archive): the reference's DEFAULT build is static
+                                                (CMakeLists.txt:61 HEXL_SHARED_LIB OFF ->
+                                                hexl/CMakeLists.txt:53-57)
     <prefix>/lib/cmake/hexl-1.2.5/HEXLConfig.cmake, HEXLConfigVersion.cmake, HEXLTargets.cmake
     <prefix>/lib/pkgconfig/hexl.pc
 
@@ -14,7 +18,12 @@ OpenFHE do) or `pkg-config --cflags --libs hexl` resolve to this build unchanged
 The package version is the reference's, 1.2.5 with ExactVersion compatibility
 (hexl/CMakeLists.txt:180-183), because that is what its consumers ask for.
 
-    python -m hexl_amd.install <prefix>
+Which of the two `HEXL::hexl` is follows the reference's switch: `install(prefix)` /
+`python -m hexl_amd.install <prefix>` gives the shared library (HEXL_SHARED_LIB=ON), `install(prefix,
+static=True)` / `--static` the static archive (the reference's default); the other flavour is
+always there as HEXL::hexl_static / HEXL::hexl_shared.
+
+    python -m hexl_amd.install <prefix> [--static]
 """
 import os
 import shutil
@@ -51,14 +60,30 @@ if(NOT TARGET HEXL::hexl_amd)
         IMPORTED_NO_SONAME TRUE
         INTERFACE_INCLUDE_DIRECTORIES "${_hexl_prefix}/include")
 endif()
-if(NOT TARGET HEXL::hexl)
-    add_library(HEXL::hexl SHARED IMPORTED)
-    set_target_properties(HEXL::hexl PROPERTIES
+if(NOT TARGET HEXL::hexl_shared)
+    add_library(HEXL::hexl_shared SHARED IMPORTED)
+    set_target_properties(HEXL::hexl_shared PROPERTIES
         IMPORTED_LOCATION "${_hexl_prefix}/lib/libhexl.so"
         IMPORTED_NO_SONAME TRUE
         INTERFACE_INCLUDE_DIRECTORIES "${_hexl_prefix}/include"
         INTERFACE_COMPILE_FEATURES cxx_std_17
         INTERFACE_LINK_LIBRARIES HEXL::hexl_amd)
+endif()
+if(NOT TARGET HEXL::hexl_static AND EXISTS "${_hexl_prefix}/lib/libhexl.a")
+    # shim + C-ABI + kernels in one archive (the reference's default: a static library,
+    # hexl/CMakeLists.txt:53-57); the HIP runtime is the one dependency left
+    find_library(_hexl_hip amdhip64 HINTS %(rocm_lib)s ENV ROCM_PATH PATH_SUFFIXES lib)
+    add_library(HEXL::hexl_static STATIC IMPORTED)
+    set_target_properties(HEXL::hexl_static PROPERTIES
+        IMPORTED_LOCATION "${_hexl_prefix}/lib/libhexl.a"
+        INTERFACE_INCLUDE_DIRECTORIES "${_hexl_prefix}/include"
+        INTERFACE_COMPILE_FEATURES cxx_std_17
+        INTERFACE_LINK_LIBRARIES "${_hexl_hip};pthread;dl")
+endif()
+if(NOT TARGET HEXL::hexl)
+    # HEXL_SHARED_LIB of this install tree: %(shared_lib)s
+    add_library(HEXL::hexl INTERFACE IMPORTED)
+    set_target_properties(HEXL::hexl PROPERTIES INTERFACE_LINK_LIBRARIES HEXL::hexl_%(flavour)s)
 endif()
 if(NOT TARGET HEXL::hexl_debug AND EXISTS "${_hexl_prefix}/lib/libhexl_debug.so")
     # the debug flavour: element-wise bound checks that throw (HEXL_CHECK_BOUNDS)
@@ -94,15 +119,20 @@ Name: Intel HEXL (hexl_amd, MI355X-native hot path)
 Version: %(version)s
 Description: Drop-in for the NTT and element-wise modular arithmetic of Intel HEXL on AMD MI355X.
 
-Libs: -L${libdir} -lhexl -lhexl_amd
+Libs: -L${libdir} -lhexl %(pc_libs)s
+Libs.private: -L%(rocm_lib)s -lamdhip64 -lpthread -ldl
 Cflags: -I${includedir}
 """
 
 
-def install(prefix):
+def install(prefix, static=False):
     prefix = os.path.abspath(prefix)
     major, minor, patch = VERSION.split(".")
-    subst = dict(version=VERSION, major=major, minor=minor, patch=patch, prefix=prefix)
+    rocm_lib = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
+    subst = dict(version=VERSION, major=major, minor=minor, patch=patch, prefix=prefix,
+                 rocm_lib=rocm_lib, flavour="static" if static else "shared",
+                 shared_lib="OFF" if static else "ON",
+                 pc_libs=f"-L{rocm_lib} -lamdhip64 -lpthread -ldl" if static else "-lhexl_amd")
     inc = os.path.join(prefix, "include")
     lib = os.path.join(prefix, "lib")
     cmk = os.path.join(lib, "cmake", "hexl-" + VERSION)
@@ -117,17 +147,21 @@ def install(prefix):
         if not os.path.exists(src):
             raise RuntimeError(f"{src} is missing: run python hexl_amd/build.py first")
         shutil.copy(src, lib)
-    dbg = os.path.join(HERE, "lib", "libhexl_debug.so")
-    if os.path.exists(dbg):
-        shutil.copy(dbg, lib)
+    for name in ("libhexl_debug.so", "libhexl.a"):
+        src = os.path.join(HERE, "lib", name)
+        if os.path.exists(src):
+            shutil.copy(src, lib)
+        elif static and name == "libhexl.a":
+            raise RuntimeError(f"{src} is missing: run python hexl_amd/build.py first")
     open(os.path.join(cmk, "HEXLConfig.cmake"), "w").write(CONFIG % subst)
-    open(os.path.join(cmk, "HEXLTargets.cmake"), "w").write(TARGETS)
+    open(os.path.join(cmk, "HEXLTargets.cmake"), "w").write(TARGETS % subst)
     open(os.path.join(cmk, "HEXLConfigVersion.cmake"), "w").write(VERSION_FILE % subst)
     open(os.path.join(pkg, "hexl.pc"), "w").write(PKGCONFIG % subst)
     return prefix
 
 
 if __name__ == "__main__":
-    if len(sys.argv) != 2:
+    args = [a for a in sys.argv[1:] if a != "--static"]
+    if len(args) != 1:
         sys.exit(__doc__)
-    print("installed to", install(sys.argv[1]))
+    print("installed to", install(args[0], static="--static" in sys.argv[1:]))

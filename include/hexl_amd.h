@@ -437,30 +437,29 @@ int hexl_amd_profile_start(int max_records);
 int hexl_amd_profile_stop(int* num_records);
 int hexl_amd_profile_get(int i, const char** name, float* ms);
 
-/* Tuning / diagnostic knobs of the transform launch logic (process-wide; the
- * HEXL_AMD_* environment variables give the defaults).  Results never depend on
- * them, only speed.  Keys:
- *   "plan"             1 = split (default: strided pass + tile pass, two
- *                      launches), 0 = fused (N = 2^15, 2^16: both passes in one
- *                      persistent launch, the intermediate read back from the
- *                      XCD's L2; slower, kept as an experiment), 2 = tiled (two
- *                      LDS-tiled launches), 3 = mixed (N = 2^16, batches of at least two
- *                      chunks: workgroups of chunk i's first pass and chunk i-1's second
- *                      pass share a launch; as fast as two launches, kept as an experiment)
- *   "mixed_chunk"      polynomials per chunk of the mixed plan (default 512)
- *   "fused_window"     polynomials one XCD keeps in flight (>= 1)
- *   "fused_min_batch"  smallest batch the fused launch is used for (>= 1)
- *   "fused_wg_per_cu"  persistent workgroups per CU (0 = occupancy query)
- *   "fp64"             1 (default) = plans for 2^30 <= q < 2^50 use the Fp64 arithmetic
- *                      policy (exact integers in doubles), 0 = the integer Lazy policy;
- *                      read when a plan is created
+/* Tuning knobs (process-wide, thread-safe: atomics).  The library reads NO environment
+ * variable; every knob has a compiled-in default and changes only through this call.  Results
+ * never depend on them, only speed.  Unknown keys / out-of-range values return
+ * HEXL_AMD_ERR_INVALID_ARG.  Keys:
+ *   "fp64"             1 (default) = plans for 2^30 <= q < 2^50 use the Fp64 arithmetic policy
+ *                      (exact integers in doubles), 0 = the integer Lazy policy, 2 = Fp64 also
+ *                      below 2^30; read when a plan is created
  *   "h60"              1 (default) = plans for 2^56 <= q < 2^60 + 2^28 use the Harvey60 arithmetic
- *                      policy (Harvey ranges on doubled values, 19/20-instruction
- *                      butterflies), 0 = the Strict policy; read when a plan is created
+ *                      policy (Harvey ranges on doubled values, 19/20-instruction butterflies),
+ *                      0 = the Strict policy; read when a plan is created
  *   "tile13"           which degrees above 4096 run as ONE kernel on an LDS tile holding the
  *                      whole polynomial (one HBM round trip instead of two): 2 (default) =
  *                      N = 8192 (64 KiB tile) and N = 16384 (128 KiB tile, batches >= 192),
- *                      1 = N = 8192 only, 0 = neither */
+ *                      1 = N = 8192 only, 0 = neither
+ *   "bigtile"          1 (default) = N = 2^18, 2^19 as five strided stages + a 13- / 14-stage
+ *                      tile pass (two HBM round trips), 0 = three passes (3 + 3 + 12, 4 + 3 + 12)
+ *   "host_bounce_kb"   largest host-pointer call (KiB of operand) that runs on the per-thread
+ *                      pinned, device-mapped bounce buffer instead of staged copies (default 256;
+ *                      0 = never)
+ *   "host_pipeline_min_mb"  host-pointer calls of at least this size are cut into chunks that
+ *                      alternate between two streams (default 0 = off: on this pool the link
+ *                      moves as much in one direction as in both)
+ *   "host_chunk_mb"    chunk size of that pipeline (default 16) */
 int hexl_amd_set_tuning(const char* key, uint64_t value);
 
 /* Device scratch of the composite entry points (KeySwitch, the experimental one-launch

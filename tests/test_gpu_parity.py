@@ -742,81 +742,6 @@ def test_ntt_single_kernel_plans(hx, ho, logn, bits):
         hx.set_tuning("tile13", 2)
 
 
-@pytest.mark.parametrize("logn", [15, 16])
-@pytest.mark.parametrize("bits", [28, 45, 54, 60])
-def test_ntt_fused_plan_matches_split_plan(hx, logn, bits):
-    """The one-launch plan (fused_pass: persistent workgroups, per-XCD tickets, the
-    intermediate handed from the strided phase to the tile phase through the XCD's L2)
-    gives the same bits as the default two-launch plan -- canonical and lazy outputs,
-    in place and out of place, batches that do and do not fill the chip."""
-    import torch
-    if not hx.has_experiments():
-        pytest.skip("needs a -DHEXL_AMD_EXPERIMENTS build (HEXL_AMD_LIB=tools/libhexl_amd_exp.so)")
-    n = 1 << logn
-    q = hx.GeneratePrimes(1, bits, True, n)[0]
-    ntt = hx.NTT(n, q)
-    try:
-        hx.set_tuning("fused_min_batch", 1)
-        for batch in (1, 67, 640):
-            x = torch.empty((batch, n), dtype=torch.int64, device="cuda")
-            hx.fill_splitmix(x, n, batch, 11 + logn, q)
-            for fwd in (True, False):
-                fn = ntt.ComputeForward if fwd else ntt.ComputeInverse
-                for out_mf in ((1, 4) if fwd else (1, 2)):
-                    res = {}
-                    for plan in (hx.PLAN_SPLIT, hx.PLAN_FUSED):
-                        hx.set_tuning("plan", plan)
-                        a = x.clone()
-                        fn(a, a, 1, out_mf)
-                        b = torch.full_like(x, -1)
-                        fn(b, x, 1, out_mf)
-                        assert torch.equal(a, b)
-                        res[plan] = a
-                    assert torch.equal(res[hx.PLAN_SPLIT], res[hx.PLAN_FUSED])
-    finally:
-        hx.set_tuning("plan", hx.PLAN_SPLIT)
-        hx.set_tuning("fused_min_batch", 64)
-
-
-@pytest.mark.parametrize("bits", [54, 49])
-def test_ntt_mixed_plan_matches_split_plan(hx, bits):
-    """The mixed plan (N = 2^16: workgroups of chunk i's first pass and of chunk i-1's
-    second pass in one launch) gives the same bits as the default two-launch plan -- full,
-    ragged and single-chunk pipelines, canonical and lazy outputs, in place and out of place."""
-    import torch
-    if not hx.has_experiments():
-        pytest.skip("needs a -DHEXL_AMD_EXPERIMENTS build (HEXL_AMD_LIB=tools/libhexl_amd_exp.so)")
-    n = 65536
-    q = hx.GeneratePrimes(1, bits, True, n)[0]
-    ntt = hx.NTT(n, q)
-    try:
-        for chunk, batch in ((4, 8), (4, 11), (3, 7), (16, 64)):
-            hx.set_tuning("mixed_chunk", chunk)
-            x = torch.empty((batch, n), dtype=torch.int64, device="cuda")
-            hx.fill_splitmix(x, n, batch, 5 + chunk, q)
-            for fwd in (True, False):
-                fn = ntt.ComputeForward if fwd else ntt.ComputeInverse
-                for out_mf in ((1, 4) if fwd else (1, 2)):
-                    res = {}
-                    for plan in (hx.PLAN_SPLIT, hx.PLAN_MIXED):
-                        hx.set_tuning("plan", plan)
-                        a = x.clone()
-                        fn(a, a, 1, out_mf)
-                        b = torch.full_like(x, -1)
-                        fn(b, x, 1, out_mf)
-                        assert torch.equal(a, b)
-                        res[plan] = a
-                    got, want = res[hx.PLAN_MIXED], res[hx.PLAN_SPLIT]
-                    if out_mf == 1:
-                        assert torch.equal(got, want)
-                    else:  # lazy outputs: same residues, inside the reference's range
-                        assert int(got.min()) >= 0 and int(got.max()) < out_mf * q
-                        assert torch.equal(got % q, want % q)
-    finally:
-        hx.set_tuning("plan", hx.PLAN_SPLIT)
-        hx.set_tuning("mixed_chunk", 512)
-
-
 def test_ntt_headline_full_size_properties(hx, ho):
     """BASELINE configs[2] at full size: N=65536, 55-bit q, batch=4096 (2 GiB).
     Size-independent properties on the device plus oracle spot checks."""
@@ -1242,49 +1167,6 @@ def test_key_switch_batch_vs_oracle(hx, ho, n, D, K, C, T, bits):
     assert np.array_equal(host(hx, d_res), want)
 
 
-def test_key_switch_batch_under_the_fused_plan(hx, ho):
-    """Round-2 advisor finding: KeySwitch holds its stream's sequence lock while it enqueues and
-    its inverse transforms (T * C >= fused_min_batch polynomials of N = 32768) took the same
-    lock again inside the one-launch fused plan -- a self-deadlock on a non-recursive mutex.
-    The lock is recursive now; the call must return, bit-exact.  (Experiments builds only:
-    the default build has no fused plan to select.)"""
-    import threading
-    if not hx.has_experiments():
-        pytest.skip("needs a -DHEXL_AMD_EXPERIMENTS build (HEXL_AMD_LIB=tools/libhexl_amd_exp.so)")
-    n, D, K, C, T = 32768, 2, 3, 2, 33  # T * C = 66 >= 64
-    rng = np.random.default_rng(5)
-    moduli = [int(q) for q in ho.generate_primes(K, 54, True, n)]
-    keys = [np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
-                            for _ in range(C) for i in range(K)]) for _ in range(D)]
-    msf = [int(rng.integers(1, moduli[i], dtype=np.uint64)) for i in range(D)]
-    targets = [np.concatenate([rng.integers(0, moduli[j], n, dtype=np.uint64) for j in range(D)])
-               for _ in range(T)]
-    results = [np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
-                               for _ in range(C) for i in range(D)]) for _ in range(T)]
-    d_keys = [dev(hx, k) for k in keys]
-    d_t = dev(hx, np.concatenate(targets))
-    want = dev(hx, np.concatenate(results))
-    hx.KeySwitchBatch(want, d_t, T, n, D, K, D + 1, C, moduli, d_keys, msf)  # split plan
-    check = ho.key_switch(results[0], targets[0], n, D, K, D + 1, C, moduli, keys, msf)
-    assert np.array_equal(host(hx, want)[:check.size], check)
-    got = dev(hx, np.concatenate(results))
-    done = []
-
-    def run():
-        hx.KeySwitchBatch(got, d_t, T, n, D, K, D + 1, C, moduli, d_keys, msf)
-        done.append(True)
-
-    try:
-        hx.set_tuning("plan", hx.PLAN_FUSED)
-        th = threading.Thread(target=run, daemon=True)
-        th.start()
-        th.join(120)
-        assert done, "KeySwitchBatch under the fused plan did not return (sequence lock)"
-    finally:
-        hx.set_tuning("plan", hx.PLAN_SPLIT)
-    assert np.array_equal(host(hx, got), host(hx, want))
-
-
 def test_workspaces_can_be_released(hx, ho):
     """Scratch of the composites is cached per (device, stream); the release entry points give
     it back, and a later call simply allocates again."""
@@ -1444,8 +1326,9 @@ def test_key_switch_rejects_bad_arguments(hx, ho):
 # ---------------------------------------------------------------- maximum degree
 @pytest.mark.parametrize("log_n,bits", [(18, 54), (19, 61), (20, 54), (20, 29), (19, 49), (18, 59)])
 def test_ntt_maximum_degrees(hx, ho, log_n, bits):
-    """N up to 2^20 = NTT::MaxDegreeBits() (hexl/include/hexl/ntt/ntt.hpp:197): plans with two
-    strided passes in front of the tile pass, all five arithmetic policies."""
+    """N up to 2^20 = NTT::MaxDegreeBits() (hexl/include/hexl/ntt/ntt.hpp:197), all five
+    arithmetic policies: 2^18 / 2^19 as five strided stages + the 13- / 14-stage tile pass of the
+    one-kernel plans, 2^20 as two strided passes in front of a 12-stage tile pass."""
     n = 1 << log_n
     q = ho.generate_primes(1, bits, True, n)[0]
     x = ho.fill_splitmix(n, log_n * 31 + bits, q)
@@ -1456,3 +1339,38 @@ def test_ntt_maximum_degrees(hx, ho, log_n, bits):
     assert np.array_equal(host(hx, d), want)
     gnt.ComputeInverse(d, d, 1, 1)
     assert np.array_equal(host(hx, d), x)
+
+
+@pytest.mark.parametrize("bigtile", [1, 0])
+@pytest.mark.parametrize("log_n,bits", [(18, 54), (19, 54), (19, 28), (18, 49), (19, 60)])
+def test_ntt_big_degrees_both_plans(hx, ho, log_n, bits, bigtile):
+    """N = 2^18, 2^19 under both plans the library holds for them -- set_tuning("bigtile", 1):
+    5 strided stages + one 13- / 14-stage tile pass (two HBM round trips); 0: three passes
+    (3 + 3 + 12, 4 + 3 + 12) -- several polynomials per call, every legal (input, output) factor
+    pair, against the oracle (round-3 advisor: the big-tile plan had only (1, 1) on <= 4
+    polynomials, the three-pass plan no test at all once the default changed)."""
+    n = 1 << log_n
+    q = ho.generate_primes(1, bits, True, n)[0]
+    ont, batch = ho.NTT(n, q), 5
+    try:
+        hx.set_tuning("bigtile", bigtile)
+        gnt = hx.NTT(n, q)
+        for in_mf, out_mf in ((1, 1), (4, 4), (2, 1)):
+            x = np.stack([ho.fill_splitmix(n, 900 + 10 * log_n + b, in_mf * q) for b in range(batch)])
+            d = dev(hx, x)
+            gnt.ComputeForward(d, d, in_mf, out_mf)
+            got = host(hx, d)
+            for b in (0, batch - 1):  # (the oracle takes ~0.1 s per polynomial here)
+                want = ont.forward(x[b], in_mf, 1)
+                assert (got[b] < np.uint64(out_mf * q)).all() and np.array_equal(got[b] % np.uint64(q), want)
+        for in_mf, out_mf in ((1, 1), (2, 2), (2, 1)):
+            x = np.stack([ho.fill_splitmix(n, 950 + 10 * log_n + b, in_mf * q) for b in range(batch)])
+            d = dev(hx, x)
+            out = dev(hx, np.zeros_like(x))
+            gnt.ComputeInverse(out, d, in_mf, out_mf)  # out of place
+            got = host(hx, out)
+            for b in (0, batch - 1):
+                want = ont.inverse(x[b], in_mf, 1)
+                assert (got[b] < np.uint64(out_mf * q)).all() and np.array_equal(got[b] % np.uint64(q), want)
+    finally:
+        hx.set_tuning("bigtile", 1)

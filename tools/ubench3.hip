@@ -44,9 +44,14 @@ __global__ void __launch_bounds__(256) k(u64* out, const ulonglong2* tw, ModCons
         for (int j = 0; j < half; ++j) {
           if (FWD)
             fwd_butterfly<A>(x[g * 2 * half + j], x[g * 2 * half + j + half], ww.x, ww.y, m);
-          else
-            inv_butterfly<A>(x[g * 2 * half + j], x[g * 2 * half + j + half], ww.x, ww.y, m,
-                             v);
+          else if constexpr (A::kLazy) {  // (one butterfly of lazy_inverse.h's network, offset 8q)
+            u64& a = x[g * 2 * half + j];
+            u64& b = x[g * 2 * half + j + half];
+            const u64 d = a + (m.two_q << 2) - b;
+            a = a + b;
+            b = mul_add_lazy2<false>(0, d, ww.x, ww.y, m.neg_two_q);
+          } else
+            inv_butterfly<A>(x[g * 2 * half + j], x[g * 2 * half + j + half], ww.x, ww.y, m);
         }
       }
     }

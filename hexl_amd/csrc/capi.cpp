@@ -234,14 +234,16 @@ static int pointer_kind(const void* p, void** dev_alias, int* owner = nullptr) {
 // zero-copy paths: they stage it instead of faulting on the device); 1 likewise for device
 // memory; otherwise 0.
 static int range_kind(const void* p, size_t bytes, void** dev_alias) {
-  const int k = pointer_kind(p, dev_alias);
-  if (k == 0 || bytes <= 1) return k;
-  void* last_alias = nullptr;
-  const int kl = pointer_kind((const char*)p + bytes - 1, &last_alias);
-  if (kl != k || (char*)last_alias - (char*)*dev_alias != (ptrdiff_t)(bytes - 1)) {
-    if (dev_alias) *dev_alias = nullptr;
-    return 0;
+  void *first = nullptr, *last = nullptr;
+  int k = pointer_kind(p, &first);
+  if (k != 0 && bytes > 1) {
+    const int kl = pointer_kind((const char*)p + bytes - 1, &last);
+    if (kl != k || (char*)last - (char*)first != (ptrdiff_t)(bytes - 1)) {
+      k = 0;
+      first = nullptr;
+    }
   }
+  if (dev_alias) *dev_alias = first;
   return k;
 }
 

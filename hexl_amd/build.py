@@ -18,11 +18,11 @@ OBJ = os.path.join(HERE, "lib", "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-# ntt_kernels.hip is compiled once per arithmetic policy (-DHEXL_AMD_TU=0..4: the kernels of
+# ntt_kernels.hip is compiled once per arithmetic policy (-DHEXL_AMD_TU=0..6: the kernels of
 # that policy) plus once for the dispatch and the process-wide state (-DHEXL_AMD_TU=-1): the
 # template instantiations are disjoint between policies and compile in parallel.
 NTT_UNITS = [("ntt_kernels.hip", f"-DHEXL_AMD_TU={tu}", f"ntt_kernels.tu{tu if tu >= 0 else 'd'}")
-             for tu in (2, 3, 4, 1, 0, -1)]  # the slowest units first
+             for tu in (2, 5, 6, 3, 4, 1, 0, -1)]  # the slowest units first
 CORE_SOURCES = NTT_UNITS + ["eltwise_kernels.hip", "keyswitch_kernels.hip", "capi.cpp",
                             "number_theory.cpp", "workspace.cpp"]
 SHIM_SOURCES = ["hexl_shim.cpp"]
@@ -68,7 +68,7 @@ def _compile(unit):
 def build(verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     srcs = CORE_SOURCES + [s for s in SHIM_SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
+    with ThreadPoolExecutor(max_workers=min(12, os.cpu_count() or 4)) as ex:
         objs = dict(zip(srcs, ex.map(_compile, srcs)))
     core = os.path.join(LIB, "libhexl_amd.so")
     core_objs = [objs[s] for s in CORE_SOURCES]

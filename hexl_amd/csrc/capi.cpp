@@ -437,8 +437,10 @@ int hexl_amd_ntt_create(hexl_amd_ntt** out, uint64_t degree, uint64_t modulus,
   // fractional bits under the Small / Lazy and Harvey60 / Strict arithmetic policy -- or, under Fp64,
   // one double per twiddle: the value balanced into (-q/2, q/2].
   const int policy = choose_policy(q);
-  const u64 shoup_bits =
-      policy == kPolicySmall ? 32 : (policy == kPolicyLazy || policy == kPolicyHarvey60) ? 63 : 64;
+  // (doubled values: the Lazy family and Harvey60)
+  const bool doubled = policy == kPolicyLazy || policy == kPolicyLazy32 || policy == kPolicyLazy16 ||
+                       policy == kPolicyHarvey60;
+  const u64 shoup_bits = policy == kPolicySmall ? 32 : doubled ? 63 : 64;
   auto balanced = [q](u64 w) { return w > q / 2 ? -(double)(q - w) : (double)w; };
   auto bits_of = [](double d) {
     u64 b;
@@ -464,7 +466,7 @@ int hexl_amd_ntt_create(hexl_amd_ntt** out, uint64_t degree, uint64_t modulus,
   // the multiply-free N^-1 scaling of the last stage's sum branch (modarith.h)
   il.c2 = (q - 1) >> p->log_n;
   il.log_n = p->log_n;
-  il.mont_mask = (u32)(((policy == kPolicyLazy || policy == kPolicyHarvey60) ? 2 * n : n) - 1);
+  il.mont_mask = (u32)((doubled ? 2 * n : n) - 1);
   il.n1 = nt::inverse_mod(n, q);
   il.n1w = nt::multiply_mod(il.n1, Rinv[1], q);
   if (policy == kPolicyFp64) {

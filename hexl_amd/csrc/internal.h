@@ -12,6 +12,11 @@ namespace hexl_amd {
 // Moduli below this bound use the Lazy arithmetic policy (modarith.h); their
 // device tables carry 63-bit Shoup factors.
 constexpr u64 kLazyModulusBound = 1ull << 56;
+// The bounded members of the Lazy family (modarith.h: LazyT): floor(2^63 / q) >= 32 below 2^58,
+// >= 16 below 2^59.  From 2^59 on -- where SEAL's and OpenFHE's 60-bit primes sit -- no stage
+// can go without a conditional subtraction and Harvey60 is the cheapest.
+constexpr u64 kLazy32ModulusBound = 1ull << 58;
+constexpr u64 kLazy16ModulusBound = 1ull << 59;
 // Moduli below this bound use the Small policy (32-bit arithmetic); their device
 // tables carry 32-bit Shoup factors.
 constexpr u64 kSmallModulusBound = 1ull << 30;
@@ -33,7 +38,9 @@ enum ArithPolicy : int {
   kPolicyLazy = 2,
   kPolicyStrict = 3,
   kPolicyHarvey60 = 4,
-  kNumPolicies = 5
+  kPolicyLazy32 = 5,
+  kPolicyLazy16 = 6,
+  kNumPolicies = 7
 };
 int choose_policy(u64 q);  // ntt_kernels.hip
 

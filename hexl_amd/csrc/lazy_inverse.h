@@ -19,7 +19,7 @@
 //     take (`post`: one conditional subtraction where that is enough, else the estimate).
 // In a tile pass the consumer is the next round, whose threads each hold 2^r elements that sat at
 // ONE position of this round's subtrees (different lanes: different positions), so the round is
-// scheduled for the largest bound any position leaves; T = kLazyLimit >> r keeps its sums in
+// scheduled for the largest bound any position leaves; T = limit >> r keeps its sums in
 // range without reductions of its own.  Between passes (in HBM) and from the caller every value
 // is below kLazyHandOver = 12 (doubled; the caller's input_mod_factor <= 2 gives < 4).
 // 11-stage tile pass: 7 estimates per thread instead of 72 instructions of ladders; 5-stage
@@ -35,8 +35,11 @@
 
 namespace hexl_amd {
 
-constexpr int kLazyLimit = 128;
+constexpr int kLazyLimit = 128;    // the Lazy policy's (q < 2^56)
 constexpr int kLazyHandOver = 12;
+// The other members of the family (modarith.h: LazyT<LIMIT>) run the same network scheduled for
+// their smaller limit; what a pass hands over shrinks with it.
+constexpr int lazy_handover(int limit) { return limit >= 128 ? kLazyHandOver : limit >= 32 ? 8 : 4; }
 constexpr int kLazyMaxR = 5;  // deepest register subtree (the 5-stage strided pass)
 
 // Schedule of an R-stage inverse subtree over E = 2^R elements; stages in execution order
@@ -128,11 +131,11 @@ constexpr InvSched make_inv_sched(int R, int B, int limit, int T, bool last) {
 }
 
 // The schedule as a type: static data evaluated once, read only in constant expressions.
-template <int R, int B, int T, bool LAST>
+template <int R, int B, int T, bool LAST, int LIMIT = kLazyLimit>
 struct InvSchedOf {
   static_assert(R >= 1 && R <= kLazyMaxR, "register subtrees are at most 5 stages deep");
-  static constexpr InvSched value = make_inv_sched(R, B, kLazyLimit, T, LAST);
-  static_assert(value.peak <= kLazyLimit, "lazy inverse schedule exceeds the 2^63 budget");
+  static constexpr InvSched value = make_inv_sched(R, B, LIMIT, T, LAST);
+  static_assert(value.peak <= LIMIT, "lazy inverse schedule exceeds the 2^63 budget");
   static_assert(LAST || value.max_out <= T, "lazy inverse schedule misses its exit threshold");
 };
 
@@ -193,9 +196,9 @@ HX_HD void inv_exit_lazy(u64* x, const ModConst& m) {
 
 // R inverse stages on x[0 .. 2^R), deepest level first; wv[2^v + g] = twiddle of group g at
 // depth v (the layout load_twiddles fills).  B: bound of the inputs; T: what the consumer takes.
-template <int R, int B, int T, bool LAST, bool MONT = false, class TW>
+template <int R, int B, int T, bool LAST, bool MONT = false, int LIMIT = kLazyLimit, class TW>
 HX_HD void inv_subtree_lazy(u64* x, const TW* wv, const ModConst& m, const InvLast& il) {
-  using SC = InvSchedOf<R, B, T, LAST>;
+  using SC = InvSchedOf<R, B, T, LAST, LIMIT>;
   static_for<R>([&](auto tc) __attribute__((always_inline)) {
     constexpr int t = decltype(tc)::value, v = R - 1 - t;
     inv_level_lazy<SC, R, t, 0, (1 << v), LAST, MONT>(x, wv + (1 << v), m, il);
@@ -212,14 +215,16 @@ HX_HD void inv_subtree_lazy(u64* x, const TW* wv, const ModConst& m, const InvLa
 // inverse executes NR-1 .. 0): entry bound and exit threshold of round j.  `rounds` = NR,
 // `r0` = stages of round 0, `re` = stages of the others; the pass is entered with values below
 // kLazyHandOver and, unless it ends the transform, left with values below it.
-constexpr int lazy_chain_thresh(int j, int r0, int re) {
-  return j == 0 ? kLazyHandOver : (kLazyLimit >> (j == 1 ? r0 : re));
+constexpr int lazy_chain_thresh(int j, int r0, int re, int limit = kLazyLimit) {
+  if (j == 0) return lazy_handover(limit);
+  const int t = limit >> (j == 1 ? r0 : re);
+  return t < 8 ? 8 : t;  // (below 8 the next round reduces on entry where it has to instead)
 }
-constexpr int lazy_chain_entry(int j, int rounds, int r0, int re) {
-  if (j == rounds - 1) return kLazyHandOver;
+constexpr int lazy_chain_entry(int j, int rounds, int r0, int re, int limit = kLazyLimit) {
+  if (j == rounds - 1) return lazy_handover(limit);
   // what round j + 1 (>= 1: `re` stages) leaves
-  return make_inv_sched(re, lazy_chain_entry(j + 1, rounds, r0, re), kLazyLimit,
-                        lazy_chain_thresh(j + 1, r0, re), false)
+  return make_inv_sched(re, lazy_chain_entry(j + 1, rounds, r0, re, limit), limit,
+                        lazy_chain_thresh(j + 1, r0, re, limit), false)
       .max_out;
 }
 

@@ -263,13 +263,31 @@ struct Strict {  // any q < 2^62; tables hold floor(W * 2^64 / q); plain values
   static constexpr bool kSmall = false;
   static constexpr bool kFp = false;
   static constexpr bool kH60 = false;
+  static constexpr int kLimit = 0;
+  static constexpr bool kExact = false;
 };
-struct Lazy {  // q < 2^56; tables hold floor(W * 2^63 / q); doubled values
+// The Lazy family: doubled values, 63-bit Shoup factors, no conditional subtraction per
+// butterfly.  kLimit = what floor(2^63 / q) is at least for the moduli the member serves: every
+// (doubled) value stays below kLimit * q.  kExact: the forward product keeps the lowest partial
+// product (T2 < 4q instead of < 6q: one instruction more, a third less growth).
+//   Lazy   (kLimit 128, q < 2^56)  forward: never reduced before the finish
+//   Lazy32 (kLimit 32,  2^56 <= q < 2^58)  forward: the x operands of a stage lose 16q by one
+//          sign-tested subtraction whenever the next growth would pass 32q (every other stage)
+//   Lazy16 (kLimit 16,  2^58 <= q < 2^59)  the same with 8q and the exact product (alternate
+//          stages): 17 instructions per forward butterfly where Harvey60 has 19
+// The inverse network of every member is lazy_inverse.h's, scheduled for its limit.
+template <int LIMIT, bool EXACT>
+struct LazyT {
   static constexpr bool kLazy = true;
   static constexpr bool kSmall = false;
   static constexpr bool kFp = false;
   static constexpr bool kH60 = false;
+  static constexpr int kLimit = LIMIT;
+  static constexpr bool kExact = EXACT;
 };
+typedef LazyT<128, false> Lazy;
+typedef LazyT<32, false> Lazy32;
+typedef LazyT<16, true> Lazy16;
 // 2^56 <= q < 2^60 + 2^28 (where SEAL's and OpenFHE's 60-bit primes live, and the smallest
 // primes above 2^60 that the reference's tests and benchmarks generate): the reference's
 // Harvey invariants -- forward values in [0,4q), inverse values in [0,2q), one conditional
@@ -284,6 +302,8 @@ struct Harvey60 {
   static constexpr bool kSmall = false;
   static constexpr bool kFp = false;
   static constexpr bool kH60 = true;
+  static constexpr int kLimit = 0;
+  static constexpr bool kExact = false;
 };
 // q < 2^30 (the reference's 32-bit path, hexl/ntt/ntt-internal.cpp:218-226,
 // :279-287): every value of the Strict invariants is below 4q < 2^32, so the
@@ -295,6 +315,8 @@ struct Small {
   static constexpr bool kSmall = true;
   static constexpr bool kFp = false;
   static constexpr bool kH60 = false;
+  static constexpr int kLimit = 0;
+  static constexpr bool kExact = false;
 };
 
 // 2^30 <= q < 2^50 (the moduli the reference sends to its IFMA-52 / FP64-assisted
@@ -324,6 +346,8 @@ struct Fp64 {
   static constexpr bool kSmall = false;
   static constexpr bool kFp = true;
   static constexpr bool kH60 = false;
+  static constexpr int kLimit = 0;
+  static constexpr bool kExact = false;
 };
 constexpr int kFpFwdRun = 7;
 constexpr int kFpInvRun = 3;
@@ -408,9 +432,15 @@ HX_HD u64 fp_bound(u64 v, const ModConst& m) {
 template <class A>
 HX_HD void fwd_butterfly(u64& x, u64& y, u64 W, u64 Wp, const ModConst& m) {
   if (A::kLazy) {
-    const u64 xs = mul_add_lazy2<false>(x, y, W, Wp, m.neg_two_q);
-    y = (x << 1) + m.six_q - xs;
-    x = xs;
+    if (A::kExact) {  // x < B q -> x', y' < (B + 4) q;  y' = 2x + 4q - x'
+      const u64 xs = mul_add_lazy2<true>(x, y, W, Wp, m.neg_two_q);
+      y = (x << 1) + m.four_q - xs;
+      x = xs;
+    } else {
+      const u64 xs = mul_add_lazy2<false>(x, y, W, Wp, m.neg_two_q);
+      y = (x << 1) + m.six_q - xs;
+      x = xs;
+    }
   } else if (A::kH60) {  // doubled: x, y < 8q -> < 8q
     const u64 tx = csub_neg(x, m.neg_four_q);                       // < 4q
     const u64 xs = mul_add_lazy2<true>(tx, y, W, Wp, m.neg_two_q);  // tx + T2, T2 < 4q

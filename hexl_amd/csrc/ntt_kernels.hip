@@ -113,6 +113,11 @@ constexpr u32 kFirstPass = 4;
 // Bit 3 (with bit 2): the input words are arbitrary 64-bit values and are reduced modulo q
 // on load (multi-plan launches with a source map, see MultiMap).
 constexpr u32 kReduceFirst = 8;
+// Bits 8 and up (forward passes of the bounded members of the Lazy family only, modarith.h): bit
+// 8 + s set = the x operands of stage s of this pass lose kLimit/2 * q by one sign-tested
+// subtraction before the stage (the host walks the bound of the values through the whole network
+// and marks the stages whose growth would otherwise pass kLimit * q: forward_stage_masks).
+constexpr u32 kStageMaskShift = 8;
 
 // Global access as wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte
 // offset: `global_load/store v, v_off, s[base]`, no 64-bit vector address math and
@@ -233,13 +238,51 @@ __device__ __forceinline__ void load_twiddles(T* wv, const T* __restrict__ tw, u
     }
 }
 
-// R forward stages on x[0 .. 2^R): stage v pairs elements 2^(R-1-v) apart.
+// Bounded members of the Lazy family: the x operands of a stage whose bit is set in `smask` are
+// brought below kLimit/2 * q first (a uniform branch: the mask is a kernel argument).
+template <class A>
+constexpr bool bounded_lazy() { return A::kLazy && A::kLimit < kLazyLimit; }
+template <class A>
+constexpr int bounded_lazy_shift() {  // kLimit/2 * q = 2q << shift
+  int s = 0;
+  while ((4 << s) < A::kLimit) ++s;
+  return s;
+}
+template <int R, int V, int G0, int G1, class A>
+__device__ __forceinline__ void fwd_bound_level(u64* x, const ModConst& m, u32 smask) {
+  if constexpr (bounded_lazy<A>()) {
+    if (smask & (1u << V)) {
+      constexpr int half = 1 << (R - 1 - V);
+#pragma unroll
+      for (int g = G0; g < G1; ++g)
+#pragma unroll
+        for (int j = 0; j < half; ++j) {
+          x[g * 2 * half + j] = lazy_csub(x[g * 2 * half + j], m, bounded_lazy_shift<A>());
+          // (32 elements per thread: keep the scheduler from issuing all the additions before
+          // the first selection -- their sums would all be live at once and spill)
+          if (R >= 5 && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+  }
+}
+
+// R forward stages on x[0 .. 2^R): stage v pairs elements 2^(R-1-v) apart.  smask: see
+// fwd_bound_level (bit v = stage v of this subtree).
 template <int R, class A>
-__device__ __forceinline__ void fwd_subtree(u64* x, const TwT<A>* wv, const ModConst& m) {
+__device__ __forceinline__ void fwd_subtree(u64* x, const TwT<A>* wv, const ModConst& m, u32 smask = 0) {
   static_assert(R <= kFpFwdRun, "Fp64 forward run too long");
 #pragma unroll
   for (int v = 0; v < R; ++v) {
     const int half = 1 << (R - 1 - v);
+    if constexpr (bounded_lazy<A>()) {
+      if (smask & (1u << v)) {
+#pragma unroll
+        for (int g = 0; g < (1 << v); ++g)
+#pragma unroll
+          for (int j = 0; j < half; ++j)
+            x[g * 2 * half + j] = lazy_csub(x[g * 2 * half + j], m, bounded_lazy_shift<A>());
+      }
+    }
 #pragma unroll
     for (int g = 0; g < (1 << v); ++g) {
       const TwT<A> w = wv[(1 << v) + g];
@@ -262,12 +305,14 @@ __device__ __forceinline__ void fwd_subtree(u64* x, const TwT<A>* wv, const ModC
 // and again at exit (not after LAST: the finish does it).
 // MONT (with LAST): the transform has at least 64 coefficients, the N^-1 scaling of the sum branch
 // is scale_by_inverse_degree (modarith.h).
-template <int R, class A, bool LAST, int B = kLazyHandOver, int T = kLazyHandOver, bool MONT = true>
+// (B = T = 0: what a pass hands over under the policy's limit)
+template <int R, class A, bool LAST, int B = 0, int T = 0, bool MONT = true>
 __device__ __forceinline__ void inv_subtree(u64* x, const TwT<A>* wv, const ModConst& m,
                                             const InvLast& il) {
   static_assert(R <= 5, "register subtrees are at most 5 stages deep");
   if constexpr (A::kLazy) {
-    inv_subtree_lazy<R, B, T, LAST, MONT>(x, wv, m, il);
+    constexpr int kHand = lazy_handover(A::kLimit);
+    inv_subtree_lazy<R, (B ? B : kHand), (T ? T : kHand), LAST, MONT, A::kLimit>(x, wv, m, il);
     return;
   } else {
 #pragma unroll
@@ -338,48 +383,63 @@ __device__ __forceinline__ void inv_level(u64* x, const TwT<A>* wl, const ModCon
   }
 }
 
-template <int COUNT, class T>
+// CTW: through the constant address space (see load_twiddles): in the multi-plan kernels the
+// table pointer comes out of a kernel-argument array and is not `__restrict__`, and without it
+// all 31 wave-uniform twiddles of a 5-stage subtree came through the vector memory path into
+// VGPRs (121-126 VGPRs, ~30 SGPRs; the bounded members of the Lazy family spilled).
+template <int COUNT, bool CTW = false, class T>
 __device__ __forceinline__ void load_twiddle_run(T* w, const T* __restrict__ tw, u32 first) {
 #pragma unroll
-  for (int i = 0; i < COUNT; ++i) w[i] = tw[first + i];
+  for (int i = 0; i < COUNT; ++i) {
+    if constexpr (CTW)
+      w[i] = load_twiddle(tw, first + i);
+    else
+      w[i] = tw[first + i];
+  }
 }
 
 // The 5-stage subtrees of the strided pass, twiddles streamed (see fwd_level).
-template <class A>
+template <class A, bool CTW = false>
 __device__ __forceinline__ void fwd_subtree5_streamed(u64* x, const TwT<A>* __restrict__ tw,
-                                                      u32 node, const ModConst& m) {
+                                                      u32 node, const ModConst& m, u32 smask) {
   TwT<A> w0, w1[2], w2[4], w3[8], w4a[8], w4b[8];
-  load_twiddle_run<1>(&w0, tw, node);
-  load_twiddle_run<2>(w1, tw, node << 1);
-  load_twiddle_run<4>(w2, tw, node << 2);
-  load_twiddle_run<8>(w3, tw, node << 3);
+  load_twiddle_run<1, CTW>(&w0, tw, node);
+  load_twiddle_run<2, CTW>(w1, tw, node << 1);
+  load_twiddle_run<4, CTW>(w2, tw, node << 2);
+  load_twiddle_run<8, CTW>(w3, tw, node << 3);
+  fwd_bound_level<5, 0, 0, 1, A>(x, m, smask);
   fwd_level<5, 0, 0, 1, A>(x, &w0, m);
+  fwd_bound_level<5, 1, 0, 2, A>(x, m, smask);
   fwd_level<5, 1, 0, 2, A>(x, w1, m);
+  fwd_bound_level<5, 2, 0, 4, A>(x, m, smask);
   fwd_level<5, 2, 0, 4, A>(x, w2, m);
-  load_twiddle_run<8>(w4a, tw, node << 4);
+  load_twiddle_run<8, CTW>(w4a, tw, node << 4);
+  fwd_bound_level<5, 3, 0, 8, A>(x, m, smask);
   fwd_level<5, 3, 0, 8, A>(x, w3, m);
-  load_twiddle_run<8>(w4b, tw, (node << 4) + 8);
+  load_twiddle_run<8, CTW>(w4b, tw, (node << 4) + 8);
+  fwd_bound_level<5, 4, 0, 16, A>(x, m, smask);
   fwd_level<5, 4, 0, 8, A>(x, w4a, m);
   fwd_level<5, 4, 8, 16, A>(x, w4b, m);
 }
 
-template <class A, bool LAST>
+template <class A, bool LAST, bool CTW = false>
 __device__ __forceinline__ void inv_subtree5_streamed(u64* x, const TwT<A>* __restrict__ tw,
                                                       u32 node, const ModConst& m,
                                                       const InvLast& il) {
   // Lazy: the schedule of a 5-stage subtree entered and (unless LAST) left below kLazyHandOver
   // -- three quotient estimates where the sums of the deepest chains would pass the limit.
   // Fp64: full reduction after the third stage and at exit.
-  using SC = InvSchedOf<5, kLazyHandOver, kLazyHandOver, LAST>;
+  constexpr int kLim = A::kLazy ? A::kLimit : kLazyLimit;
+  using SC = InvSchedOf<5, lazy_handover(kLim), lazy_handover(kLim), LAST, kLim>;
   TwT<A> w0, w1[2], w2[4], w3[8], w4a[8], w4b[8];
-  load_twiddle_run<8>(w4a, tw, node << 4);
-  load_twiddle_run<8>(w4b, tw, (node << 4) + 8);
+  load_twiddle_run<8, CTW>(w4a, tw, node << 4);
+  load_twiddle_run<8, CTW>(w4b, tw, (node << 4) + 8);
   inv_level<5, 4, 0, 8, A, false, SC>(x, w4a, m, il);
-  load_twiddle_run<8>(w3, tw, node << 3);
+  load_twiddle_run<8, CTW>(w3, tw, node << 3);
   inv_level<5, 4, 8, 16, A, false, SC>(x, w4b, m, il);
-  load_twiddle_run<4>(w2, tw, node << 2);
-  load_twiddle_run<2>(w1, tw, node << 1);
-  load_twiddle_run<1>(&w0, tw, node);
+  load_twiddle_run<4, CTW>(w2, tw, node << 2);
+  load_twiddle_run<2, CTW>(w1, tw, node << 1);
+  load_twiddle_run<1, CTW>(&w0, tw, node);
   inv_level<5, 3, 0, 8, A, false, SC>(x, w3, m, il);
   inv_level<5, 2, 0, 4, A, false, SC>(x, w2, m, il);
   fp_bound_all<A, 32>(x, m);
@@ -481,14 +541,14 @@ __device__ __forceinline__ void strided_body(u64* out, const u64* in,
 
   if (FWD) {
     if constexpr (R < 5)
-      fwd_subtree<R, A>(x, wv, m);
+      fwd_subtree<R, A>(x, wv, m, flags >> kStageMaskShift);
     else
-      fwd_subtree5_streamed<A>(x, twa, node, m);
+      fwd_subtree5_streamed<A, CTW>(x, twa, node, m, flags >> kStageMaskShift);
   } else {
     if constexpr (R < 5)
       inv_subtree<R, A, LAST>(x, wv, m, il);
     else
-      inv_subtree5_streamed<A, LAST>(x, twa, node, m, il);
+      inv_subtree5_streamed<A, LAST, CTW>(x, twa, node, m, il);
   }
   // The finish kind is uniform: three straight-line store loops behind scalar branches, each
   // element finished right in front of its store (a select per element costs 3 instructions
@@ -577,6 +637,8 @@ template <class A>
 constexpr int policy_id() {
   return A::kSmall ? kPolicySmall
          : A::kFp  ? kPolicyFp64
+         : (A::kLazy && A::kLimit == 32) ? kPolicyLazy32
+         : (A::kLazy && A::kLimit == 16) ? kPolicyLazy16
          : A::kLazy ? kPolicyLazy
          : A::kH60  ? kPolicyHarvey60
                     : kPolicyStrict;
@@ -596,7 +658,9 @@ strided_pass_multi(u64* out, const u64* in, MultiCtx mc, u32 log_n, u32 a0, u32 
   const ModConst m = pd->mod;
   const InvLast il = pd->il;
   in = multi_source(mc, poly, log_n, in, flags);
-  strided_body<FWD, R, A, LAST, kStream, kStream, true, true>(
+  // (data first -- see strided_body -- except where the 5-stage forward subtree of a bounded
+  // member of the Lazy family has no registers to spare for it)
+  strided_body<FWD, R, A, LAST, kStream, kStream, !(FWD && R >= 5 && bounded_lazy<A>()), true>(
       out, in, FWD ? mc.tw_fwd[k] : mc.tw_inv[k], m, log_n, a0, flags, bid, il);
 }
 
@@ -662,19 +726,22 @@ __device__ __forceinline__ void round_twiddles(T* wv, const T* __restrict__ tw, 
   }
 }
 
+// fmask (forward, bounded members of the Lazy family): stage mask of the pass, bit s = stage s
 template <int S, int CB, int j, class A, bool FWD, bool LAST>
 __device__ __forceinline__ void round_compute(u64* x, const TwT<A>* wv, const ModConst& m,
-                                              const InvLast& il) {
+                                              const InvLast& il, u32 fmask = 0) {
   constexpr int kRE = re_of(S), kE = el_of(S);
   constexpr int r = Rounds<S, CB>::r(j);
   constexpr int SS = kE >> r;
 #pragma unroll
   for (int s = 0; s < SS; ++s) {
     if (FWD)
-      fwd_subtree<r, A>(x + (s << r), wv + (s << r), m);
+      fwd_subtree<r, A>(x + (s << r), wv + (s << r), m, fmask >> Rounds<S, CB>::u(j));
     else  // (Lazy: entry bound and exit threshold of round j of this pass's chain)
-      inv_subtree<r, A, LAST, lazy_chain_entry(j, Rounds<S, CB>::NR, Rounds<S, CB>::R0, kRE),
-                  lazy_chain_thresh(j, Rounds<S, CB>::R0, kRE), (S >= 6)>(x + (s << r), wv + (s << r), m, il);
+      inv_subtree<r, A, LAST,
+                  lazy_chain_entry(j, Rounds<S, CB>::NR, Rounds<S, CB>::R0, kRE, A::kLazy ? A::kLimit : kLazyLimit),
+                  lazy_chain_thresh(j, Rounds<S, CB>::R0, kRE, A::kLazy ? A::kLimit : kLazyLimit), (S >= 6)>(
+          x + (s << r), wv + (s << r), m, il);
   }
   if (FWD && Rounds<S, CB>::fp_reduce_after(j)) fp_bound_all<A, kE>(x, m);
 }
@@ -736,7 +803,7 @@ __device__ __forceinline__ void handover() {
 template <int S, int CB, int TL, int J, class A, bool CTW = false>
 __device__ __forceinline__ void fwd_mid_rounds(u64* x, u64* lds, const TwT<A>* tw, u32 tid,
                                                const TileGeom& g, const ModConst& m,
-                                               const InvLast& il, const TwT<A>* pre) {
+                                               const InvLast& il, const TwT<A>* pre, u32 fmask) {
   constexpr int kRE = re_of(S), kE = el_of(S);
   using RD = Rounds<S, CB>;
   if constexpr (J < RD::NR) {
@@ -748,11 +815,11 @@ __device__ __forceinline__ void fwd_mid_rounds(u64* x, u64* lds, const TwT<A>* t
     }
     lds_load_round<S, CB, TL, J>(x, lds, tid);
     if constexpr (RD::pre_fwd(J + 1)) round_twiddles<S, CB, TL, J + 1, CTW>(wn, tw, tid, g);
-    round_compute<S, CB, J, A, true, false>(x, w, m, il);
+    round_compute<S, CB, J, A, true, false>(x, w, m, il, fmask);
     lds_store_round<S, CB, TL, J>(x, lds, tid);
     handover<RD::w(J), RD::r(J) == kRE>();
     HX_STAMP(3 + J);
-    fwd_mid_rounds<S, CB, TL, J + 1, A, CTW>(x, lds, tw, tid, g, m, il, wn);
+    fwd_mid_rounds<S, CB, TL, J + 1, A, CTW>(x, lds, tw, tid, g, m, il, wn, fmask);
   }
 }
 
@@ -933,13 +1000,13 @@ __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
       if constexpr (RD::pre_fwd(1)) round_twiddles<S, CB, TL, 1, CTW>(wn, tw, tid, g);
       HX_PROFILE_WAIT_VMEM();
       HX_STAMP(1);
-      round_compute<S, CB, 0, A, true, false>(x, wv, m, il);
+      round_compute<S, CB, 0, A, true, false>(x, wv, m, il, flags >> kStageMaskShift);
       HX_STAMP(2);
       lds_store_round<S, CB, TL, 0>(x, lds, tid);
       handover<RD::w(0), RD::r(0) == kRE>();
       HX_STAMP(3);
     }
-    fwd_mid_rounds<S, CB, TL, 1, A, CTW>(x, lds, tw, tid, g, m, il, wn);
+    fwd_mid_rounds<S, CB, TL, 1, A, CTW>(x, lds, tw, tid, g, m, il, wn, flags >> kStageMaskShift);
     // copy-out of the run this wave owns after the last round (w = CB <= 6):
     // 512 tile-contiguous elements, 64 per access; final reduction fused
     // (the finish kind is uniform: three straight-line copies of the copy-out behind scalar
@@ -1188,7 +1255,7 @@ struct Plan {
 // library reads no environment variable: every knob has a compiled-in default and changes only
 // through that call.  Results never depend on it.
 struct Tuning {
-  std::atomic<u32> fp64{1}, h60{1}, tile13{2}, bigtile{1};
+  std::atomic<u32> fp64{1}, h60{1}, tile13{2}, bigtile{1}, lazy_family{1};
 };
 Tuning& tuning();  // one per process: defined by the dispatch unit
 #if HX_TU_DISPATCH
@@ -1202,6 +1269,7 @@ int set_tuning(const char* key, u64 value) {
   else if (strcmp(key, "tile13") == 0 && value <= 2) t.tile13 = (u32)value;
   else if (strcmp(key, "h60") == 0 && value <= 1) t.h60 = (u32)value;
   else if (strcmp(key, "bigtile") == 0 && value <= 1) t.bigtile = (u32)value;
+  else if (strcmp(key, "lazy_family") == 0 && value <= 1) t.lazy_family = (u32)value;
   else return -1;
   return 0;
 }
@@ -1278,17 +1346,35 @@ static hipError_t forward_seq(const NttTables& t, const Plan& p, u64* result, co
   hipError_t e;
   u32 first = kFirstPass;  // consumed by whichever pass runs first
   u32 a0 = 0;
+  // Bounded members of the Lazy family: the bound of the (doubled) values walked through the
+  // network -- 8q from the caller (input_mod_factor <= 4), +6q per stage (+4q with the exact
+  // product) -- and the stages marked whose x operands must lose kLimit/2 * q first.
+  int bound = 8;
+  auto stage_mask = [&bound](int stages) -> u32 {
+    u32 mask = 0;
+    if constexpr (bounded_lazy<A>()) {
+      constexpr int grow = A::kExact ? 4 : 6;
+      for (int s = 0; s < stages; ++s) {
+        if (bound + grow > A::kLimit) {
+          mask |= 1u << s;
+          bound = A::kLimit / 2;
+        }
+        bound += grow;
+      }
+    }
+    return mask << kStageMaskShift;
+  };
   for (int i = 0; i < p.n_strided; ++i) {
-    e = launch_strided<true, A>(p.strided[i], result, src, t.fwd, t.mod, t.log_n, a0, first,
-                                batch, il, st, mc);
+    e = launch_strided<true, A>(p.strided[i], result, src, t.fwd, t.mod, t.log_n, a0,
+                                first | stage_mask(p.strided[i]), batch, il, st, mc);
     if (e != hipSuccess) return e;
     a0 += p.strided[i];
     src = result;
     first = 0;
   }
   const u32 fin = out_mf == 1 ? 2 : 1;
-  return launch_bottom_tl<true, A>(p.tl, p.bottom, result, src, t.fwd, t.mod, t.log_n, fin | first,
-                                   batch, il, st, mc);
+  return launch_bottom_tl<true, A>(p.tl, p.bottom, result, src, t.fwd, t.mod, t.log_n,
+                                   fin | first | stage_mask(p.bottom), batch, il, st, mc);
 }
 
 template <class A>
@@ -1344,6 +1430,8 @@ HX_POLICY_ENTRY_DECL(fp64)
 HX_POLICY_ENTRY_DECL(lazy)
 HX_POLICY_ENTRY_DECL(strict)
 HX_POLICY_ENTRY_DECL(harvey60)
+HX_POLICY_ENTRY_DECL(lazy32)
+HX_POLICY_ENTRY_DECL(lazy16)
 #undef HX_POLICY_ENTRY_DECL
 
 #define HX_POLICY_ENTRY_DEF(NAME, A)                                                            \
@@ -1371,9 +1459,15 @@ HX_POLICY_ENTRY_DEF(strict, Strict)
 #if HX_TU_POLICY(4)
 HX_POLICY_ENTRY_DEF(harvey60, Harvey60)
 #endif
+#if HX_TU_POLICY(5)
+HX_POLICY_ENTRY_DEF(lazy32, Lazy32)
+#endif
+#if HX_TU_POLICY(6)
+HX_POLICY_ENTRY_DEF(lazy16, Lazy16)
+#endif
 #undef HX_POLICY_ENTRY_DEF
 static_assert(kPolicySmall == 0 && kPolicyFp64 == 1 && kPolicyLazy == 2 && kPolicyStrict == 3 &&
-                  kPolicyHarvey60 == 4,
+                  kPolicyHarvey60 == 4 && kPolicyLazy32 == 5 && kPolicyLazy16 == 6,
               "the HX_TU_POLICY numbers above are the ArithPolicy values");
 
 #if HX_TU_DISPATCH
@@ -1386,6 +1480,8 @@ static hipError_t transform_dispatch(bool forward, const NttTables& t, u64* resu
     case kPolicyLazy: return transform_entry_lazy(forward, t, result, operand, batch, out_mf, st);
     case kPolicyHarvey60:
       return transform_entry_harvey60(forward, t, result, operand, batch, out_mf, st);
+    case kPolicyLazy32: return transform_entry_lazy32(forward, t, result, operand, batch, out_mf, st);
+    case kPolicyLazy16: return transform_entry_lazy16(forward, t, result, operand, batch, out_mf, st);
     default: return transform_entry_strict(forward, t, result, operand, batch, out_mf, st);
   }
 }
@@ -1461,6 +1557,10 @@ hipError_t ntt_multi_launch(bool forward, const NttTables* const* tabs, u32 num_
     e = multi_entry_lazy(forward, t0, mc, polys, result, operand, out_mf, st);
   if (have[kPolicyHarvey60] && e == hipSuccess)
     e = multi_entry_harvey60(forward, t0, mc, polys, result, operand, out_mf, st);
+  if (have[kPolicyLazy32] && e == hipSuccess)
+    e = multi_entry_lazy32(forward, t0, mc, polys, result, operand, out_mf, st);
+  if (have[kPolicyLazy16] && e == hipSuccess)
+    e = multi_entry_lazy16(forward, t0, mc, polys, result, operand, out_mf, st);
   if (have[kPolicyStrict] && e == hipSuccess)
     e = multi_entry_strict(forward, t0, mc, polys, result, operand, out_mf, st);
   // past the check above a refusal can only come after launches were made: a hard error,
@@ -1479,6 +1579,11 @@ int choose_policy(u64 q) {
   // (the Lazy policy's quotient estimates shift the HIGH word of a value: q >= 2^32; with the
   // Fp64 policy switched off the moduli between 2^30 and 2^32 take the Harvey60 policy)
   if (q >= (1ull << 32) && q < kLazyModulusBound) return kPolicyLazy;
+  // the bounded members of the Lazy family ("lazy_family" = 0: Harvey60 from 2^56 on)
+  if (tuning().lazy_family.load() != 0) {
+    if (q >= kLazyModulusBound && q < kLazy32ModulusBound) return kPolicyLazy32;
+    if (q >= kLazy32ModulusBound && q < kLazy16ModulusBound) return kPolicyLazy16;
+  }
   // HEXL_AMD_H60=0: 2^56 <= q < 2^60 + 2^28 on the Strict policy (A/B runs)
   if (q < kHarvey60ModulusBound && tuning().h60.load() != 0) return kPolicyHarvey60;
   return kPolicyStrict;

@@ -444,9 +444,14 @@ int hexl_amd_profile_get(int i, const char** name, float* ms);
  *   "fp64"             1 (default) = plans for 2^30 <= q < 2^50 use the Fp64 arithmetic policy
  *                      (exact integers in doubles), 0 = the integer Lazy policy, 2 = Fp64 also
  *                      below 2^30; read when a plan is created
- *   "h60"              1 (default) = plans for 2^56 <= q < 2^60 + 2^28 use the Harvey60 arithmetic
- *                      policy (Harvey ranges on doubled values, 19/20-instruction butterflies),
- *                      0 = the Strict policy; read when a plan is created
+ *   "lazy_family"      1 (default) = plans for 2^56 <= q < 2^58 / 2^58 <= q < 2^59 use the bounded
+ *                      members of the Lazy arithmetic family (doubled values kept below 32q / 16q:
+ *                      a sign-tested subtraction on the stages the host marks instead of one per
+ *                      butterfly), 0 = Harvey60 from 2^56 on; read when a plan is created
+ *   "h60"              1 (default) = plans for moduli from 2^59 (2^56 with "lazy_family" 0) to
+ *                      2^60 + 2^28 use the Harvey60 arithmetic policy (Harvey ranges on doubled
+ *                      values, 19/20-instruction butterflies), 0 = the Strict policy; read when a
+ *                      plan is created
  *   "tile13"           which degrees above 4096 run as ONE kernel on an LDS tile holding the
  *                      whole polynomial (one HBM round trip instead of two): 2 (default) =
  *                      N = 8192 (64 KiB tile) and N = 16384 (128 KiB tile, batches >= 192),

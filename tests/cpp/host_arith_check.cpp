@@ -77,17 +77,38 @@ static void check(u64 n, u64 q, const std::vector<int>& inv_runs, u64 in_mf_f, u
     in[n - 1] = in_mf_f * q - 1;
     ho_ntt_forward_radix2(ref.data(), in.data(), n, q, R.data(), Rp.data(), in_mf_f, 1);
     for (u64 i = 0; i < n; ++i) x[i] = to_internal<A>(in[i], m);
+    // Lazy family: the bound of the doubled values walked like the library's host code walks it
+    // (ntt_kernels.hip: forward_seq) -- 8q from the caller, + 6q per stage (+ 4q with the exact
+    // product); a bounded member subtracts kLimit/2 * q from the x operands of a stage whose
+    // growth would pass kLimit * q
+    u64 fbound = 8;
+    const u64 grow = A::kExact ? 4 : 6;
     for (int s = 0; s < L; ++s) {
       const u64 mgroups = 1ull << s, t = n >> (s + 1);
+      bool subtract = false;
+      if (A::kLazy) {
+        if (A::kLimit < kLazyLimit && fbound + grow > (u64)A::kLimit) {
+          subtract = true;
+          fbound = A::kLimit / 2;
+        }
+        fbound += grow;
+        EXPECT(fbound <= (u64)(A::kLazy ? A::kLimit : 0), "fwd lazy: bound %llu passes the limit", (unsigned long long)fbound);
+      }
+      int csub_shift = 0;
+      while (A::kLazy && (4 << csub_shift) < A::kLimit) ++csub_shift;
       for (u64 i = 0; i < mgroups; ++i)
         for (u64 j = 0; j < t; ++j) {
           u64& a = x[2 * i * t + j];
           u64& b = x[2 * i * t + j + t];
+          if (subtract) {
+            EXPECT(a < (u64)A::kLimit * q, "fwd lazy: conditional subtraction out of its range");
+            a = lazy_csub(a, m, csub_shift);
+            EXPECT(a < (u64)(A::kLimit / 2) * q, "fwd lazy: conditional subtraction result");
+          }
           fwd_butterfly<A>(a, b, W[mgroups + i], Wp[mgroups + i], m);
           EXPECT(a < lim && b < lim, "fwd range: stage %d", s);
           if (A::kLazy)
-            EXPECT(a < (8 + 6 * (u64)(s + 1)) * q && b < (8 + 6 * (u64)(s + 1)) * q,
-                   "fwd lazy bound: stage %d", s);
+            EXPECT(a < fbound * q && b < fbound * q, "fwd lazy bound: stage %d", s);
           else if (A::kH60)  // Harvey's [0,4q) on doubled values
             EXPECT(a < 8 * q && b < 8 * q, "fwd harvey60 bound: stage %d", s);
           else
@@ -167,8 +188,8 @@ struct HostTw {
 
 // One subtree through schedule `sc` (entered below B q), the interpreter: the same operations as
 // inv_level_lazy / inv_exit_lazy, each intermediate checked against the scheduler's bookkeeping.
-static void run_sched(const InvSched& sc, int R, int B, bool last, bool mont, u64* x, const HostTw* wv,
-                      const ModConst& m, const InvLast& il) {
+static void run_sched(const InvSched& sc, int limit, int R, int B, bool last, bool mont, u64* x,
+                      const HostTw* wv, const ModConst& m, const InvLast& il) {
   const int E = 1 << R;
   const u64 q = m.q;
   std::vector<u64> b(E, (u64)B);
@@ -192,7 +213,7 @@ static void run_sched(const InvSched& sc, int R, int B, bool last, bool mont, u6
         EXPECT(off >= b[k] * q || off >= x[k], "lazy inverse: offset covers the subtrahend");
         EXPECT(x[k] <= off, "lazy inverse: difference would wrap");
         const u64 sum = x[i] + x[k], d = x[i] + off - x[k];
-        EXPECT((b[i] + ((u64)2 << sc.off[t][i])) <= (u64)kLazyLimit, "lazy inverse: schedule passes the limit");
+        EXPECT((b[i] + ((u64)2 << sc.off[t][i])) <= (u64)limit, "lazy inverse: schedule passes the limit");
         EXPECT(sum < (1ull << 63) && d < (1ull << 63), "lazy inverse: 2^63");
         if (last && t == R - 1) {
           x[i] = mont ? scale_by_inverse_degree(sum, il) : mul_add_lazy2<true>(0, sum, il.n1, il.n1p, m.neg_two_q);
@@ -217,18 +238,27 @@ static void run_sched(const InvSched& sc, int R, int B, bool last, bool mont, u6
 
 // The templated device functions on the same subtree: (R, B, T, LAST, MONT) must be one of the
 // instantiations below -- the set the chains of every tile geometry and the strided passes use.
+// (limit, R, B, T)
 #define LAZY_INSTANCES(X)                                                                          \
-  X(2, 32, 12) X(1, 64, 12) X(1, 12, 12) X(2, 12, 12) X(3, 12, 12) X(4, 12, 12) X(5, 12, 12)                                  \
-  X(3, 12, 16) X(3, 16, 16) X(3, 16, 32) X(3, 16, 64) X(2, 24, 12) X(1, 24, 12) X(1, 16, 12) X(3, 16, 12) \
-  X(4, 12, 8) X(4, 8, 8) X(4, 8, 32) X(2, 16, 12) X(3, 12, 32) X(3, 12, 64) X(4, 12, 32) X(4, 8, 12) X(4, 12, 64) X(4, 8, 64)
-static bool run_template(int R, int B, int T, bool last, bool mont, u64* x, const HostTw* wv,
+  X(128, 2, 32, 12) X(128, 1, 64, 12) X(128, 1, 12, 12) X(128, 2, 12, 12) X(128, 3, 12, 12)         \
+  X(128, 4, 12, 12) X(128, 5, 12, 12) X(128, 3, 12, 16) X(128, 3, 16, 16) X(128, 3, 16, 32)         \
+  X(128, 3, 16, 64) X(128, 2, 24, 12) X(128, 1, 24, 12) X(128, 1, 16, 12) X(128, 3, 16, 12)         \
+  X(128, 4, 12, 8) X(128, 4, 8, 8) X(128, 4, 8, 32) X(128, 2, 16, 12) X(128, 3, 12, 32)             \
+  X(128, 3, 12, 64) X(128, 4, 12, 32) X(128, 4, 8, 12) X(128, 4, 12, 64) X(128, 4, 8, 64)           \
+  LAZY_INSTANCES_BOUNDED(X)
+#define LAZY_INSTANCES_BOUNDED(X)                                                                  \
+  X(32, 1, 8, 8) X(32, 2, 8, 8) X(32, 3, 8, 8) X(32, 4, 8, 8) X(32, 5, 8, 8) X(32, 1, 16, 8)        \
+  X(32, 3, 8, 16) X(32, 4, 8, 16) X(32, 2, 16, 8) X(32, 4, 16, 8)                                   \
+  X(16, 1, 4, 4) X(16, 2, 4, 4) X(16, 3, 4, 4) X(16, 4, 4, 4) X(16, 5, 4, 4) X(16, 3, 4, 8)         \
+  X(16, 3, 8, 8) X(16, 2, 8, 4) X(16, 1, 8, 4) X(16, 3, 8, 4) X(16, 4, 4, 8) X(16, 4, 8, 8) X(16, 4, 8, 4)
+static bool run_template(int limit, int R, int B, int T, bool last, bool mont, u64* x, const HostTw* wv,
                          const ModConst& m, const InvLast& il) {
-#define X(RR, BB, TT)                                                                    \
-  if (R == RR && B == BB && T == TT) {                                                   \
-    if (last && mont) inv_subtree_lazy<RR, BB, TT, true, true>(x, wv, m, il);            \
-    else if (last) inv_subtree_lazy<RR, BB, TT, true, false>(x, wv, m, il);              \
-    else inv_subtree_lazy<RR, BB, TT, false, false>(x, wv, m, il);                       \
-    return true;                                                                         \
+#define X(LL, RR, BB, TT)                                                                    \
+  if (limit == LL && R == RR && B == BB && T == TT) {                                        \
+    if (last && mont) inv_subtree_lazy<RR, BB, TT, true, true, LL>(x, wv, m, il);            \
+    else if (last) inv_subtree_lazy<RR, BB, TT, true, false, LL>(x, wv, m, il);              \
+    else inv_subtree_lazy<RR, BB, TT, false, false, LL>(x, wv, m, il);                       \
+    return true;                                                                             \
   }
   LAZY_INSTANCES(X)
 #undef X
@@ -246,7 +276,8 @@ static void round_shape(int S, int& rounds, int& r0, int& re) {
   r0 = S - (rounds - 1) * re;
 }
 
-static void check_lazy_inverse(u64 n, u64 q, const std::vector<LazyPass>& passes, u64 in_mf) {
+static void check_lazy_inverse(u64 n, u64 q, const std::vector<LazyPass>& passes, u64 in_mf,
+                               int limit = kLazyLimit) {
   int L = 0;
   while ((1ull << L) < n) ++L;
   std::vector<u64> R(n), Rp(n), Ri_stage(n), Rip_stage(n);
@@ -285,12 +316,12 @@ static void check_lazy_inverse(u64 n, u64 q, const std::vector<LazyPass>& passes
     int in_pass = 0;
     for (int j = rounds - 1; j >= 0; --j) {
       const int r = (j == 0) ? r0 : re;
-      const int B = p.tile ? lazy_chain_entry(j, rounds, r0, re) : kLazyHandOver;
-      const int T = p.tile ? lazy_chain_thresh(j, r0, re) : kLazyHandOver;
+      const int B = p.tile ? lazy_chain_entry(j, rounds, r0, re, limit) : lazy_handover(limit);
+      const int T = p.tile ? lazy_chain_thresh(j, r0, re, limit) : lazy_handover(limit);
       const bool last = pass_last && j == 0;
       const bool mont = last && (p.tile ? p.stages >= 6 : true);
-      const InvSched sc = make_inv_sched(r, B, kLazyLimit, T, last);
-      EXPECT(sc.peak <= kLazyLimit && (last || sc.max_out <= T), "schedule (r %d B %d T %d)", r, B, T);
+      const InvSched sc = make_inv_sched(r, B, limit, T, last);
+      EXPECT(sc.peak <= limit && (last || sc.max_out <= T), "schedule (limit %d r %d B %d T %d)", limit, r, B, T);
       // the subtrees of this round: heap levels [top, top + r), top = L - done - in_pass - r
       const int top = L - done - in_pass - r;
       const u64 cols = n >> (top + r);
@@ -303,20 +334,21 @@ static void check_lazy_inverse(u64 n, u64 q, const std::vector<LazyPass>& passes
           for (int e = 0; e < E; ++e) a[e] = c[e] = x[(h * E + e) * cols + col];
           for (int v = 0; v < r; ++v)
             for (int g = 0; g < (1 << v); ++g) wv[(1 << v) + g] = V[(((1ull << top) + h) << v) + g];
-          run_sched(sc, r, B, last, mont, a.data(), wv.data(), m, il);
+          run_sched(sc, limit, r, B, last, mont, a.data(), wv.data(), m, il);
           if (col < 4 || col + 2 > cols) {  // the device templates on a sample of the subtrees
-            have_template = run_template(r, B, T, last, mont, c.data(), wv.data(), m, il);
+            have_template = run_template(limit, r, B, T, last, mont, c.data(), wv.data(), m, il);
             if (have_template)
               for (int e = 0; e < E; ++e) EXPECT(a[e] == c[e], "template != interpreter (r %d B %d T %d)", r, B, T);
           }
           for (int e = 0; e < E; ++e) x[(h * E + e) * cols + col] = a[e];
         }
-      EXPECT(have_template, "no inv_subtree_lazy<%d, %d, %d> instance in the test: add it to LAZY_INSTANCES", r, B, T);
+      EXPECT(have_template, "no inv_subtree_lazy<%d, %d, %d, ., ., %d> instance in the test: add X(%d, %d, %d, %d) to LAZY_INSTANCES",
+             r, B, T, limit, limit, r, B, T);
       in_pass += r;
     }
     done += p.stages;
     if (!pass_last)
-      for (u64 i = 0; i < n; ++i) EXPECT(x[i] < (u64)kLazyHandOver * q, "lazy inverse: hand-over bound between passes");
+      for (u64 i = 0; i < n; ++i) EXPECT(x[i] < (u64)lazy_handover(limit) * q, "lazy inverse: hand-over bound between passes");
   }
   EXPECT(done == L, "passes do not cover the network");
   for (int canonical = 0; canonical < 2; ++canonical)
@@ -565,6 +597,32 @@ int main() {
         check_lazy_inverse(1ull << L, primes[pi], library_passes(L), 2);
         check_lazy_inverse(1ull << L, primes[pi], library_passes(L), 1);
         if (L == 14) check_lazy_inverse(1ull << L, primes[pi], library_passes(L, false), 2);
+      }
+    }
+  }
+  // The bounded members of the Lazy family: 2^56 <= q < 2^58 (limit 32), 2^58 <= q < 2^59
+  // (limit 16), primes at both ends of each range; forward through check<>, inverse through the
+  // library's plans
+  for (int L : {1, 3, 6, 10, 11, 12, 13, 14, 15, 16, 17}) {
+    for (int bits : {56, 57, 58}) {
+      size_t got = ho_generate_primes(primes, 1, bits, 1, 1ull << L);       // just above 2^bits
+      got += ho_generate_primes(primes + got, 1, bits, 0, 1ull << L);      // just below 2^(bits+1)
+      for (size_t pi = 0; pi < got; ++pi) {
+        const u64 q = primes[pi];
+        if (q < (1ull << 56) || q >= (1ull << 59)) continue;
+        const int limit = q < (1ull << 58) ? 32 : 16;
+        if (L >= 15 && pi) continue;
+        check_lazy_inverse(1ull << L, q, library_passes(L), 2, limit);
+        check_lazy_inverse(1ull << L, q, library_passes(L), 1, limit);
+        if (L <= 13 || (L == 16 && pi == 0)) {
+          if (limit == 32) {
+            check<Lazy32>(1ull << L, q, run_sets[0], 4, 2);
+            check<Lazy32>(1ull << L, q, run_sets[0], 1, 1);
+          } else {
+            check<Lazy16>(1ull << L, q, run_sets[0], 4, 2);
+            check<Lazy16>(1ull << L, q, run_sets[0], 1, 1);
+          }
+        }
       }
     }
   }

@@ -21,7 +21,7 @@ MAX_ELEMS = 1 << 21  # per case: keeps the scalar oracle below ~0.2 s
 
 # GeneratePrimes bit sizes (q in [2^b, 2^(b+1))) on both sides of the policy boundaries
 # (q < 2^30, 2^50, 2^56) and up to the API's limit (q < 2^62)
-BITS = [20, 27, 28, 29, 30, 35, 44, 48, 49, 50, 53, 54, 55, 56, 58, 59, 60, 61]
+BITS = [20, 27, 28, 29, 30, 35, 44, 48, 49, 50, 53, 54, 55, 56, 57, 58, 59, 60, 61]
 
 
 @pytest.fixture(scope="module")

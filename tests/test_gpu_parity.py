@@ -132,16 +132,16 @@ SWEEP_N = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384,
 
 
 @pytest.mark.parametrize("n", SWEEP_N)
-@pytest.mark.parametrize("bits", [27, 33, 49, 54, 60, 61])
+@pytest.mark.parametrize("bits", [27, 33, 49, 54, 56, 58, 60, 61])
 def test_ntt_vs_oracle(hx, ho, n, bits):
     """Random inputs, all legal (in_mf, out_mf), in-place and out-of-place,
     small and large moduli (pattern of test/test-ntt-avx512.cpp:169-398 and
-    test/test-ntt.cpp:406-478).  61-bit primes exercise the generic 64-bit
-    path, <= 54-bit ones the q < 2^55 path."""
+    test/test-ntt.cpp:406-478): one bit size per arithmetic policy -- Small, Fp64 (33, 49), Lazy,
+    Lazy32 (just above 2^56), Lazy16 (just above 2^58), Harvey60, Strict."""
     import torch
     q = ho.generate_primes(1, bits, bits % 2 == 0, n)[0]
     batch = 3 if n <= 16384 else 2
-    if n > 8192 and bits in (27, 33, 60):
+    if n > 8192 and bits in (27, 33, 56, 58, 60):
         batch = 1  # keeps the oracle's share of the sweep small
     ont, gnt = ho.NTT(n, q), hx.NTT(n, q)
     x = np.stack([ho.fill_splitmix(n, bits * 1000 + n + b, q) for b in range(batch)])
@@ -317,7 +317,8 @@ def _mixed_primes(ho, n, bits_list):
     (4096, [54, 54], [0, 1], 1, 12),
     (8192, [54, 45, 54], [0, 1, 2], 1, 9),                 # period 3, Lazy + Fp64 mixed
     (65536, [54] * 8, list(range(8)), 1, 16),              # configs[3]'s 8 primes, interleaved
-    (16384, [28, 54, 45, 60, 61, 54, 45, 59], list(range(8)), 1, 24),  # all five policies
+    (16384, [28, 54, 45, 60, 61, 54, 45, 59], list(range(8)), 1, 24),  # five policies
+    (65536, [56, 54, 58, 57, 59], list(range(5)), 1, 10),              # the Lazy family + Harvey60
     (4096, [54, 49, 60], [0, 1, 2, 1], 2, 19),             # inner 2, a plan used twice, ragged end
     (32768, [54, 54, 54], [2, 0, 1], 3, 10),               # permuted table, last slot cut short
     (2048, [54, 45], [0, 1], 1, 6),                        # below the multi-plan degrees: run by run
@@ -682,12 +683,14 @@ def test_ntt_harvey60_policy_matches_strict_policy(hx, n, batch, bits, small_end
     import torch
     q = hx.GeneratePrimes(1, bits, small_end, n)[0]
     try:
+        hx.set_tuning("lazy_family", 0)  # (below 2^59 the bounded Lazy members come first)
         hx.set_tuning("h60", 0)
         strict = hx.NTT(n, q)
         hx.set_tuning("h60", 1)
         h60 = hx.NTT(n, q)
     finally:
         hx.set_tuning("h60", 1)
+        hx.set_tuning("lazy_family", 1)
     x = torch.empty((batch, n), dtype=torch.int64, device="cuda")
     for in_mf in (1, 2, 4):
         hx.fill_splitmix(x, n, batch, 81, in_mf * q)
@@ -704,6 +707,58 @@ def test_ntt_harvey60_policy_matches_strict_policy(hx, n, batch, bits, small_end
         assert torch.equal(a, b)
         h60.ComputeInverse(x, x, in_mf, 2)  # in place, lazy output range
         assert int(x.min()) >= 0 and int(x.max()) < 2 * q and torch.equal(x % q, a)
+
+
+@pytest.mark.parametrize("n,batch,bits,small_end", [
+    (64, 7, 56, True), (4096, 64, 56, True), (4096, 33, 57, False), (1 << 13, 5, 56, False),
+    (1 << 14, 200, 57, True), (1 << 14, 3, 57, False), (65536, 64, 56, True), (65536, 16, 57, False),
+    (1 << 17, 8, 57, True), (1 << 20, 1, 57, False), (1 << 18, 2, 56, True),           # Lazy32: [2^56, 2^58)
+    (64, 7, 58, True), (4096, 64, 58, True), (4096, 33, 58, False), (1 << 13, 5, 58, False),
+    (1 << 14, 200, 58, True), (65536, 64, 58, True), (65536, 16, 58, False), (1 << 17, 8, 58, True),
+    (1 << 20, 1, 58, False), (1 << 19, 2, 58, True)])                                  # Lazy16: [2^58, 2^59)
+def test_ntt_bounded_lazy_policies_match_strict_policy(hx, n, batch, bits, small_end):
+    """2^56 <= q < 2^59: the bounded members of the Lazy family (modarith.h LazyT: doubled values
+    that stay below 32q / 16q -- the forward network subtracts 16q / 8q from the x operands of
+    the stages the host marks, the inverse network runs lazy_inverse.h's schedule for the smaller
+    limit) against the Strict policy on the same inputs, bit for bit, at both ends of each range,
+    one-kernel, two-pass and three-pass plans, every legal factor pair."""
+    import torch
+    q = hx.GeneratePrimes(1, bits, small_end, n)[0]
+    assert (1 << 56) <= q < (1 << 59)
+    try:
+        hx.set_tuning("lazy_family", 0)
+        hx.set_tuning("h60", 0)
+        strict = hx.NTT(n, q)
+    finally:
+        hx.set_tuning("h60", 1)
+        hx.set_tuning("lazy_family", 1)
+    lazy = hx.NTT(n, q)
+    x = torch.empty((batch, n), dtype=torch.int64, device="cuda")
+    for in_mf in (1, 2, 4):
+        hx.fill_splitmix(x, n, batch, 91, in_mf * q)
+        a, b = torch.empty_like(x), torch.empty_like(x)
+        strict.ComputeForward(a, x, in_mf, 1)
+        lazy.ComputeForward(b, x, in_mf, 1)
+        assert torch.equal(a, b)
+        lazy.ComputeForward(b, x, in_mf, 4)
+        assert int(b.min()) >= 0 and int(b.max()) < 4 * q and torch.equal(b % q, a)
+    for in_mf in (1, 2):
+        hx.fill_splitmix(x, n, batch, 92, in_mf * q)
+        strict.ComputeInverse(a, x, in_mf, 1)
+        lazy.ComputeInverse(b, x, in_mf, 1)
+        assert torch.equal(a, b)
+        lazy.ComputeInverse(x, x, in_mf, 2)  # in place, lazy output range
+        assert int(x.min()) >= 0 and int(x.max()) < 2 * q and torch.equal(x % q, a)
+    # adversarial inputs: every coefficient at the top of its range
+    for in_mf in (1, 4):
+        x.fill_(in_mf * q - 1)
+        strict.ComputeForward(a, x, in_mf, 1)
+        lazy.ComputeForward(b, x, in_mf, 1)
+        assert torch.equal(a, b)
+    x.fill_(2 * q - 1)
+    strict.ComputeInverse(a, x, 2, 1)
+    lazy.ComputeInverse(b, x, 2, 1)
+    assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("logn", [13, 14])

@@ -309,6 +309,7 @@ def secondary_configs(hx, torch):
     x = torch.empty((b, n), dtype=torch.int64, device="cuda")
     other = {}
     for label, bits in (("30-bit prime (Small policy)", 29), ("50-bit prime (Fp64 policy)", 49),
+                        ("57-bit prime (Lazy32 policy)", 56), ("59-bit prime (Lazy16 policy)", 58),
                         ("60-bit prime (Harvey60 policy)", 59), ("62-bit prime (Strict policy)", 61)):
         q = hx.GeneratePrimes(1, bits, False, n)[0]
         ntt = hx.NTT(n, q)

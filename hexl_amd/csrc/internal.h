@@ -25,8 +25,9 @@ constexpr u64 kSmallModulusBound = 1ull << 30;
 // doubles, one-word balanced twiddles).
 constexpr u64 kFp64ModulusBound = 1ull << 50;
 
-// Moduli in [kLazyModulusBound, kHarvey60ModulusBound) use the Harvey60 policy (Harvey ranges
-// on doubled values; 63-bit Shoup factors like Lazy).  Its products need the high word of
+// Moduli in [kLazy16ModulusBound, kHarvey60ModulusBound) -- from kLazyModulusBound with the
+// bounded Lazy members switched off -- use the Harvey60 policy (Harvey ranges on doubled values;
+// 63-bit Shoup factors like Lazy).  Its products need the high word of
 // a doubled value (< 8q) to stay <= 2^31, i.e. 8q <= 2^63 + 2^31: the bound sits 2^28 above
 // 2^60, which takes in the smallest primes above 2^60 -- what GeneratePrimes(., 60, true, .)
 // returns, the reference's "61-bit" test and benchmark moduli (BASELINE configs[4]).

@@ -10,7 +10,8 @@
 // (hexl/include/hexl/number-theory/number-theory.hpp:127-141 MultiplyModLazy,
 // :195-205 BarrettReduce64, :214-258 ReduceMod; hexl/ntt/ntt-default.hpp:28-42
 // and :112-125 for the two Harvey butterflies).  Range policies of the 64-bit integer
-// arithmetic (Small, Harvey60 and Fp64 are described at their structs below):
+// arithmetic (Small, Harvey60, Fp64 and the bounded members of the Lazy family -- Lazy32 and
+// Lazy16, 2^56 <= q < 2^59 -- are described at their structs below):
 //
 //   Strict (any q < 2^62): the reference's invariants -- forward values in
 //     [0,4q) with one conditional subtraction per butterfly, inverse values in

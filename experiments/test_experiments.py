@@ -1,12 +1,9 @@
 """Parity tests of the plans that were built, measured and NOT adopted (fused_pass: both passes
 in one persistent launch; mixed launches over chunks; the recursive sequence lock under the fused
-plan).  They need a library built from the archived sources -- experiments/ntt_experiments.inc
-included into hexl_amd/csrc/ntt_kernels.hip as it stood at commit 55a090c with
--DHEXL_AMD_EXPERIMENTS (tools/build_variant.sh exp -DHEXL_AMD_EXPERIMENTS at that commit), loaded
-through HEXL_AMD_LIB -- and are not part of `pytest tests/` (the product build has no such plan
-to select).  Kept for the record of what was verified bit-exact before being set aside:
-    git worktree add /tmp/r3 55a090c && SRC_ROOT=/tmp/r3 tools/build_variant.sh exp -DHEXL_AMD_EXPERIMENTS
-    HEXL_AMD_LIB=tools/libhexl_amd_exp.so python -m pytest experiments/test_experiments.py -m experiments
+plan), lifted out of tests/test_gpu_parity.py in round 4 for the record.  They need a library
+built from the archived sources (experiments/README.md: the tree at commit 55a090c with
+-DHEXL_AMD_EXPERIMENTS) and are not part of `pytest tests/` -- the product has no such plan to
+select.  Marker: experiments.
 """
 import os
 import sys

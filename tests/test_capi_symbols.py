@@ -158,6 +158,23 @@ def test_no_product_file_touches_the_oracle():
                     assert "hexl_oracle" not in text and "oracle/" not in text, os.path.join(d, f)
 
 
+def test_bench_uses_the_oracle_in_its_cpu_baseline_legs_only():
+    """bench.py may import / call the oracle only as the reported CPU baseline (`cpu_baseline`,
+    and its per-call leg for `host_path`): never inside what is measured as the product."""
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    allowed = {"cpu_baseline", "cpu_per_call_baseline"}
+    for node in tree.body:
+        uses = [n for n in ast.walk(node)
+                if (isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle"))
+                or (isinstance(n, ast.Import) and any(a.name.startswith("oracle") for a in n.names))]
+        if uses:
+            assert isinstance(node, ast.FunctionDef) and node.name in allowed, getattr(node, "name", node)
+    # and tests/cpp/multi_device.cpp, the C++ caller bench.py --launcher threads runs, is C-ABI only
+    text = open(os.path.join(ROOT, "tests", "cpp", "multi_device.cpp")).read()
+    assert "hip/" not in text and "oracle" not in text and '#include "hexl_amd.h"' in text
+
+
 def test_c_abi_header_is_plain_c(tmp_path):
     """include/hexl_amd.h is a C header: C99, pedantic, no C++ or HIP types, and links against
     the library from a C translation unit."""

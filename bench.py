@@ -617,6 +617,13 @@ def main():
     from hexl_amd.sharding import job_partition, rendezvous
     if os.environ.get("BENCH_ONE_DEVICE") == "1":
         local_rank = 0
+    # fewer visible devices than ranks (a launcher that masks devices per rank, or a box with
+    # fewer GPUs than --gpus): the ranks share what is there and the line says so -- a shared
+    # device is a dry run of the code path, not a scaling measurement
+    visible = torch.cuda.device_count()
+    oversubscribed = visible > 0 and world > visible
+    if visible > 0 and local_rank >= visible:
+        local_rank %= visible
     torch.cuda.set_device(local_rank)
     # The ranks meet for a barrier and two scalar reductions only (no data-path collective):
     # gloo is always there, RCCL is used when -- and only when -- every rank brought it up
@@ -787,6 +794,8 @@ def main():
             # collective): "nccl" (= RCCL), "gloo" (RCCL unavailable / failed its probe: why is in
             # rendezvous_note), "none" (one process)
             "launcher": "processes", "rendezvous": rv.backend or "none", "rendezvous_note": rv.note,
+            "visible_devices": visible,
+            "devices_shared_between_ranks": bool(oversubscribed or os.environ.get("BENCH_ONE_DEVICE") == "1"),
             "config": {
                 "workload": (("BASELINE configs[3]: in-place ForwardNTT(1,1) + InverseNTT(1,1), N=65536, "
                               f"8 RNS primes (55-bit) x {batch} polynomials = {total_polys} transforms per "

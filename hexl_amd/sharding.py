@@ -39,8 +39,11 @@ class Rendezvous:
     the barrier / reductions use; `device` where their scalar tensors live; `note` why RCCL
     is not in use when it was asked for."""
 
-    def __init__(self, dist=None, backend=None, group=None, device=None, note=None):
+    def __init__(self, dist=None, backend=None, group=None, device=None, note=None, pending=False):
         self.dist, self.backend, self.group, self.device, self.note = dist, backend, group, device, note
+        # an RCCL probe that timed out may have left a collective in flight: tearing the
+        # process group down could then block (see close)
+        self.pending = pending
 
     def barrier(self):
         if self.dist is None:
@@ -57,11 +60,22 @@ class Rendezvous:
         return gather_over_ranks(value, self.dist, device=self.device, group=self.group)
 
     def close(self):
-        if self.dist is not None and self.dist.is_initialized():
-            self.dist.destroy_process_group()
+        """Leaves the group.  Returns False when the caller should end the process with
+        os._exit after flushing its output: an RCCL probe timed out on some rank and a
+        collective may still be in flight, so destroying the NCCL communicator could block."""
+        if self.dist is None or not self.dist.is_initialized():
+            return True
+        if self.pending:
+            try:
+                self.dist.barrier()  # the default (gloo) group: every rank has printed
+            except Exception:  # noqa: BLE001
+                pass
+            return False
+        self.dist.destroy_process_group()
+        return True
 
 
-def rendezvous(rank, world, local_rank=0, prefer="nccl", probe_seconds=60.0):
+def rendezvous(rank, world, local_rank=0, prefer="nccl", probe_seconds=120.0):
     """Process group of a one-process-per-GPU run that cannot lose the run to RCCL.
 
     The job has no data-path collective, so the ranks only need a barrier and
@@ -86,7 +100,7 @@ def rendezvous(rank, world, local_rank=0, prefer="nccl", probe_seconds=60.0):
                             timeout=datetime.timedelta(seconds=600))
     if prefer != "nccl":
         return Rendezvous(dist, "gloo", None, "cpu", f"{prefer} requested")
-    group, note, ok = None, None, 0
+    group, note, ok, started = None, None, 0, False
     try:
         if not torch.cuda.is_available():
             raise RuntimeError("no GPU visible to this rank")
@@ -97,6 +111,7 @@ def rendezvous(rank, world, local_rank=0, prefer="nccl", probe_seconds=60.0):
         dev = torch.device("cuda", local_rank)
         probe = torch.ones(1, dtype=torch.float64, device=dev)
         work = dist.all_reduce(probe, group=group, async_op=True)
+        started = True  # enqueued: if it never completes it stays in flight
         done = torch.cuda.Event()
         deadline = time.monotonic() + probe_seconds
         # (poll instead of a blocking wait: a communicator that never comes up must not hang
@@ -118,9 +133,12 @@ def rendezvous(rank, world, local_rank=0, prefer="nccl", probe_seconds=60.0):
     dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
     if int(agreed.item()) == 1:
         return Rendezvous(dist, "nccl", group, torch.device("cuda", local_rank), None)
+    # did any rank get as far as issuing the probe?  Then its collective may never complete.
+    began = torch.tensor([1 if started else 0], dtype=torch.int64)
+    dist.all_reduce(began, op=dist.ReduceOp.MAX)
     if note is None:
         note = "another rank could not bring RCCL up"
-    return Rendezvous(dist, "gloo", None, "cpu", note)
+    return Rendezvous(dist, "gloo", None, "cpu", note, pending=bool(int(began.item())))
 
 
 def max_over_ranks(seconds, dist=None, device=None, group=None):

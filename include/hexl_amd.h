@@ -65,7 +65,13 @@ int hexl_amd_pointer_is_device(const void* p);
  * and a multi-pass transform reads its operand there.
  *   hexl_amd_host_alloc / _free        such memory from the runtime (hipHostMalloc, mapped)
  *   hexl_amd_host_register / _unregister  an existing allocation made such (hipHostRegister,
- *                                      mapped): one call over a caller's memory pool
+ *                                      mapped): one call over a caller's memory pool.  Register
+ *                                      what you keep: a page-aligned range that stays allocated
+ *                                      (a pool), not short-lived heap arrays -- with ROCm 7.0,
+ *                                      registering, unregistering and freeing a buffer whose
+ *                                      address range a later allocation reuses made an unrelated
+ *                                      large pageable copy abort inside the runtime about once in
+ *                                      a dozen test-suite runs (EXPERIMENTS.md section 9)
  *   hexl_amd_pointer_kind              0 ordinary host, 1 device / managed, 2 mapped host
  * include/hexl/util/device-mapped-allocator.hpp wraps the first pair as an
  * intel::hexl::AllocatorBase (allocator.hpp:12-51) for AlignedVector64 data buffers. */

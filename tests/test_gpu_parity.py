@@ -379,6 +379,9 @@ def test_ntt_indexed_without_period(hx, ho):
         hx.ComputeForwardMap(plans, [0, 5], 1, out, d, 1, 1)
 
 
+_REGISTERED_REGIONS = []
+
+
 def test_pointer_kinds_and_zero_copy_host_path(hx, ho):
     """hexl_amd_pointer_kind: 0 ordinary host memory, 1 device memory, 2 pinned device-mapped host
     memory (from hexl_amd_host_alloc, or an existing buffer after hexl_amd_host_register); the
@@ -409,8 +412,17 @@ def test_pointer_kinds_and_zero_copy_host_path(hx, ho):
         assert lib.hexl_amd_eltwise_host(4, out, pm, pm, 0, n, q, 1, 1) == 0
         assert np.array_equal(m[n:], ho.eltwise_mult_mod(x, x, q, 1))
         assert lib.hexl_amd_host_free(pm) == 0
-        # an existing allocation, registered
-        buf = np.zeros(2 * n, dtype=np.uint64)
+        # an existing allocation, registered: like the memory pool a caller registers once -- its own
+        # page-aligned mapping that stays allocated for the life of the process.  (Registering a
+        # short-lived heap array and freeing it right after was how this test was written in round
+        # 3; the suite then aborted inside the HIP runtime in about one run in twelve, always in the
+        # first >= 1 MiB pageable host-to-device copy that followed -- a later allocation reusing
+        # the unregistered address range: EXPERIMENTS.md section 9.)
+        import mmap
+        region = mmap.mmap(-1, 2 * n * 8)
+        _REGISTERED_REGIONS.append(region)  # never unmapped
+        buf = np.frombuffer(region, dtype=np.uint64)
+        buf[:] = 0
         buf[:n] = x
         pb = buf.ctypes.data_as(C.c_void_p)
         assert lib.hexl_amd_host_register(pb, buf.nbytes) == 0

@@ -213,3 +213,40 @@ def test_bench_counter_profile_is_tied_to_the_kernel_sources(tmp_path, monkeypat
         {"kernel_source_sha16": bench.kernel_source_hash(),
          "by_bench_kernel_family": {"k": {"valu_busy": 1.0}}}))
     assert bench.counter_profile()[0] == {"k": {"valu_busy": 1.0}}
+
+
+def test_bench_threads_launcher_line_shape(monkeypatch, capsys):
+    """`bench.py --launcher threads` prints the same JSON shape as the one-process-per-GPU launcher
+    (VERDICT r3 item 1); checked here without a GPU by feeding it a result of tests/cpp/multi_device."""
+    import argparse
+    import json
+
+    import bench
+    fake = {"launcher": "threads", "ok": True, "error": "", "n_gpus": 2, "devices": [0, 1],
+            "visible_devices": 2, "scaling": "strong", "N": 65536, "batch": 4096, "primes": 8,
+            "polynomials_total": 32768, "steps": 3, "warmup": 1, "value": 4.9e6, "unit": "NTT/s",
+            "ms_per_step": 13.4, "per_rank_NTT_per_s": [2.45e6, 2.46e6], "per_rank_polynomials": [16384, 16384],
+            "probe_polynomials_compared": 8, "probe_mismatches": 0, "ref_device": 0}
+    seen = {}
+
+    def fake_run(devices, scaling, steps, warmup, batch=4096, n=65536, timeout=900):
+        seen.update(devices=list(devices), scaling=scaling, steps=steps, batch=batch)
+        return fake
+    monkeypatch.setattr(bench, "run_multi_device", fake_run)
+    monkeypatch.delenv("BENCH_ONE_DEVICE", raising=False)
+    bench.threads_main(argparse.Namespace(gpus=2, scaling="strong", steps=3, warmup=1, batch=4096))
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert seen == {"devices": [0, 1], "scaling": "strong", "steps": 3, "batch": 4096}
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "per_rank_NTT_per_s", "launcher",
+                "rendezvous", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["launcher"] == "threads" and line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["per_rank_NTT_per_s"] == fake["per_rank_NTT_per_s"] and line["value"] == fake["value"]
+    assert line["metric"].startswith("Fwd+Inv NTTs/sec") and line["dtype"] == "u64"
+    assert line["verified"]["probe_mismatches"] == 0
+    # a one-GPU box: the ranks share device 0
+    monkeypatch.setenv("BENCH_ONE_DEVICE", "1")
+    bench.threads_main(argparse.Namespace(gpus=3, scaling="weak", steps=2, warmup=1, batch=128))
+    capsys.readouterr()
+    assert seen["devices"] == [0, 0, 0] and seen["scaling"] == "weak" and seen["batch"] == 128

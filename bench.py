@@ -511,6 +511,15 @@ def launcher_command(gpus, argv, port=None):
             "--master-port", str(port or free_port()), os.path.abspath(__file__)] + list(argv)
 
 
+def guarded(name, fn):
+    """fn(), or {"error": ...} in its place: for the blocks reported beside the headline."""
+    try:
+        return fn()
+    except (Exception, SystemExit) as e:  # noqa: BLE001
+        sys.stderr.write(f"bench.py: {name} failed: {type(e).__name__}: {e}\n")
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 MULTI_DEVICE_BIN = os.path.join(ROOT, "tests", "cpp", "multi_device")
 
 
@@ -757,27 +766,31 @@ def main():
     if rank == 0 and world == 1 and batch == BATCH and not args.no_secondary and not strong:
         del data
         torch.cuda.empty_cache()
-        secondary = secondary_configs(hx, torch)
-        extras["host_path"] = host_path(hx)
-        if not args.no_cpu_baseline:
-            for key, cpu in cpu_per_call_baseline(hx).items():
-                extras["host_path"][key]["cpu_baseline_one_thread"] = cpu
-        extras["composites"] = composites(hx)
+        # Everything below is reported BESIDE the headline, which is measured and complete at
+        # this point: a failure in one of these blocks is recorded in its place, never allowed to
+        # cost the line.
+        secondary = guarded("secondary", lambda: secondary_configs(hx, torch))
+
+        def host_path_block():
+            hp = host_path(hx)
+            if not args.no_cpu_baseline:
+                for key, cpu in cpu_per_call_baseline(hx).items():
+                    hp[key]["cpu_baseline_one_thread"] = cpu
+            return hp
+        extras["host_path"] = guarded("host_path", host_path_block)
+        extras["composites"] = guarded("composites", lambda: composites(hx))
         # the headline shape with the primes SEAL defaults to (60-bit)
-        extras["headline_60bit"] = dict(
+        extras["headline_60bit"] = guarded("headline_60bit", lambda: dict(
             secondary["headline_shape_other_moduli"]["60-bit prime (Harvey60 policy)"],
             workload="in-place ForwardNTT(1,1) + InverseNTT(1,1), N=65536, batch=4096, "
-                     "60-bit prime (GeneratePrimes(1, 59, false, 65536))")
+                     "60-bit prime (GeneratePrimes(1, 59, false, 65536))"))
         # the C-ABI's own multi-device launcher on whatever this box shows (one std::thread +
         # stream + plans per visible GPU, one prime x 4096 polynomials each; verified against a
         # single-device run): tests/cpp/multi_device.cpp
         if os.path.exists(MULTI_DEVICE_BIN):
             torch.cuda.empty_cache()
-            try:
-                extras["multi_device_threads"] = run_multi_device(
-                    range(torch.cuda.device_count()), "weak", 5, 6)
-            except SystemExit as e:
-                extras["multi_device_threads"] = {"error": str(e)[:300]}
+            extras["multi_device_threads"] = guarded("multi_device_threads", lambda: run_multi_device(
+                range(torch.cuda.device_count()), "weak", 5, 6, timeout=300))
     if rank == 0:
         out = {
             "metric": "Fwd+Inv NTTs/sec, N=65536 q~55b batch=4096",
@@ -852,7 +865,7 @@ def main():
             out["secondary"] = secondary
         out.update(extras)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = guarded("cpu_baseline", cpu_baseline)
         elif world > 1:
             out["cpu_baseline"] = None
         os.write(json_fd, (json.dumps(out) + "\n").encode())

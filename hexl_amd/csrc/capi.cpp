@@ -232,19 +232,26 @@ static int pointer_kind(const void* p, void** dev_alias, int* owner = nullptr) {
 // the alias of the first plus the same offset (a buffer that starts inside a registered pool
 // and runs past its end, or straddles two registrations, is ordinary host memory to the
 // zero-copy paths: they stage it instead of faulting on the device); 1 likewise for device
-// memory; otherwise 0.
-static int range_kind(const void* p, size_t bytes, void** dev_alias) {
-  void *first = nullptr, *last = nullptr;
-  int k = pointer_kind(p, &first);
-  if (k != 0 && bytes > 1) {
+// memory; otherwise 0.  `first` is the kind of the first byte alone (0 = the host can
+// dereference it: what the bounce path asks).  One runtime query for ordinary host memory, two
+// for device / mapped memory.
+struct RangeKind {
+  int kind = 0;
+  int first = 0;
+  void* alias = nullptr;
+};
+static RangeKind classify_range(const void* p, size_t bytes) {
+  RangeKind r;
+  void* last = nullptr;
+  r.first = r.kind = pointer_kind(p, &r.alias);
+  if (r.kind != 0 && bytes > 1) {
     const int kl = pointer_kind((const char*)p + bytes - 1, &last);
-    if (kl != k || (char*)last - (char*)first != (ptrdiff_t)(bytes - 1)) {
-      k = 0;
-      first = nullptr;
+    if (kl != r.kind || (char*)last - (char*)r.alias != (ptrdiff_t)(bytes - 1)) {
+      r.kind = 0;
+      r.alias = nullptr;
     }
   }
-  if (dev_alias) *dev_alias = first;
-  return k;
+  return r;
 }
 
 int hexl_amd_pointer_is_device(const void* p) { return pointer_kind(p, nullptr) == 1 ? 1 : 0; }
@@ -861,9 +868,12 @@ static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t*
   // reads the operand and writes the result straight over the link -- no staging copies, one
   // launch, one synchronisation; a multi-pass transform reads the operand in its first pass
   // (no H2D copy) and copies the result back.
-  void *op_dev = nullptr, *res_dev = nullptr;
-  const int op_kind = range_kind(operand, bytes, &op_dev),
-            res_kind = range_kind(result, bytes, &res_dev);
+  // (one classification per distinct buffer: in place is the common call)
+  const RangeKind op_range = classify_range(operand, bytes);
+  const RangeKind res_range =
+      (const void*)result == (const void*)operand ? op_range : classify_range(result, bytes);
+  void *op_dev = op_range.alias, *res_dev = res_range.alias;
+  const int op_kind = op_range.kind, res_kind = res_range.kind;
   if (op_kind == 2 && (bytes < host_pipeline_min_bytes() || batch < 4)) {
     if (int rc = g_staging.ensure(p->device, 8)) return rc;  // (the stream)
     hipStream_t st = g_staging.stream;
@@ -886,7 +896,7 @@ static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t*
     return HEXL_AMD_OK;
   }
   if (op_kind == 0 && res_kind == 0 && bytes <= host_bounce_max_bytes() &&
-      pointer_kind(operand, nullptr) != 1 && pointer_kind(result, nullptr) != 1) {
+      op_range.first != 1 && res_range.first != 1) {
     // ordinary host memory, small call: the kernels (one or two passes) run in place on the
     // mapped bounce buffer
     if (int rc = g_staging.ensure(p->device, 8)) return rc;  // (the stream)
@@ -1097,9 +1107,16 @@ static int eltwise_host_run(EltOp op, EltArgs g, uint64_t* result, const uint64_
   HX_HIP(hipGetDevice(&device));
   const size_t bytes = (size_t)n * sizeof(u64);
   const bool has_b = operand2 != nullptr;
-  void *r = nullptr, *a = nullptr, *b = nullptr;
-  const int kr = range_kind(result, bytes, &r), ka = range_kind(operand1, bytes, &a),
-            kb = has_b ? range_kind(operand2, bytes, &b) : 0;
+  // (one classification per distinct buffer)
+  const RangeKind ra = classify_range(operand1, bytes);
+  const RangeKind rb = !has_b                                        ? RangeKind{}
+                       : (const void*)operand2 == (const void*)operand1 ? ra
+                                                                     : classify_range(operand2, bytes);
+  const RangeKind rr = (const void*)result == (const void*)operand1              ? ra
+                       : has_b && (const void*)result == (const void*)operand2 ? rb
+                                                                                : classify_range(result, bytes);
+  void *r = rr.alias, *a = ra.alias, *b = rb.alias;
+  const int kr = rr.kind, ka = ra.kind, kb = rb.kind;
   // mapped caller memory: the streaming kernel runs straight on it (see ntt_run_host)
   if (kr == 2 && ka == 2 && (!has_b || kb == 2)) {
     if (int rc = g_staging.ensure(device, 8)) return rc;
@@ -1114,9 +1131,8 @@ static int eltwise_host_run(EltOp op, EltArgs g, uint64_t* result, const uint64_
   // small call, every buffer ordinary host memory: the mapped bounce buffer (ntt_run_host).
   // (The shim sends mixed argument sets here too -- a device operand with a host result: those
   // are not host-dereferenceable and take the staged copies below, whose direction is detected.)
-  if (bytes <= host_bounce_max_bytes() && kr == 0 && ka == 0 && kb == 0 &&
-      pointer_kind(result, nullptr) == 0 && pointer_kind(operand1, nullptr) == 0 &&
-      (!has_b || pointer_kind(operand2, nullptr) == 0)) {
+  if (bytes <= host_bounce_max_bytes() && kr == 0 && ka == 0 && kb == 0 && rr.first == 0 &&
+      ra.first == 0 && rb.first == 0) {
     if (int rc = g_staging.ensure(device, 8)) return rc;
     if (int rc = g_staging.ensure_bounce(bytes * (has_b ? 2 : 1))) return rc;
     u64* ha = (u64*)g_staging.bounce;
@@ -1598,6 +1614,9 @@ int hexl_amd_profile_get(int i, const char** name, float* ms) {
 }
 
 int hexl_amd_release_stream_workspaces(void* stream) {
+  // (scratch is keyed by (device, stream): look on the device that owns the stream, like every
+  // other stream-taking entry point)
+  HX_ON_STREAM_DEVICE(stream);
   release_stream_workspaces((hipStream_t)stream);
   return HEXL_AMD_OK;
 }

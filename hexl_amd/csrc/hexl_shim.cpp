@@ -482,5 +482,27 @@ void EltwiseCmpSubMod(uint64_t* result, const uint64_t* operand1, uint64_t n, ui
                                     diff));
 }
 
+// The reference's public DyadicMultiply / KeySwitch are one-line forwards to these
+// (hexl/experimental/seal/dyadic-multiply.cpp, key-switch.cpp); callers that name the internal
+// entry points (hexl.hpp includes their headers) get the same GPU path.
+namespace internal {
+
+void DyadicMultiply(uint64_t* result, const uint64_t* operand1, const uint64_t* operand2,
+                    uint64_t n, const uint64_t* moduli, uint64_t num_moduli) {
+  ::intel::hexl::DyadicMultiply(result, operand1, operand2, n, moduli, num_moduli);
+}
+
+void KeySwitch(uint64_t* result, const uint64_t* t_target_iter_ptr, uint64_t n,
+               uint64_t decomp_modulus_size, uint64_t key_modulus_size,
+               uint64_t rns_modulus_size, uint64_t key_component_count, const uint64_t* moduli,
+               const uint64_t** k_switch_keys, const uint64_t* modswitch_factors,
+               const uint64_t* root_of_unity_powers_ptr) {
+  ::intel::hexl::KeySwitch(result, t_target_iter_ptr, n, decomp_modulus_size, key_modulus_size,
+                           rns_modulus_size, key_component_count, moduli, k_switch_keys,
+                           modswitch_factors, root_of_unity_powers_ptr);
+}
+
+}  // namespace internal
+
 }  // namespace hexl
 }  // namespace intel

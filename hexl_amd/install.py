@@ -119,7 +119,7 @@ Name: Intel HEXL (hexl_amd, MI355X-native hot path)
 Version: %(version)s
 Description: Drop-in for the NTT and element-wise modular arithmetic of Intel HEXL on AMD MI355X.
 
-Libs: -L${libdir} -lhexl %(pc_libs)s
+Libs: %(pc_hexl)s %(pc_libs)s
 Libs.private: -L%(rocm_lib)s -lamdhip64 -lpthread -ldl
 Cflags: -I${includedir}
 """
@@ -132,6 +132,9 @@ def install(prefix, static=False):
     subst = dict(version=VERSION, major=major, minor=minor, patch=patch, prefix=prefix,
                  rocm_lib=rocm_lib, flavour="static" if static else "shared",
                  shared_lib="OFF" if static else "ON",
+                 # static: name the archive by path -- libhexl.so is installed next to it and
+                 # GNU ld prefers the shared object for -lhexl
+                 pc_hexl="${libdir}/libhexl.a" if static else "-L${libdir} -lhexl",
                  pc_libs=f"-L{rocm_lib} -lamdhip64 -lpthread -ldl" if static else "-lhexl_amd")
     inc = os.path.join(prefix, "include")
     lib = os.path.join(prefix, "lib")

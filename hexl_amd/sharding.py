@@ -101,11 +101,21 @@ def rendezvous(rank, world, local_rank=0, prefer="nccl", probe_seconds=120.0):
     if prefer != "nccl":
         return Rendezvous(dist, "gloo", None, "cpu", f"{prefer} requested")
     group, note, ok, started = None, None, 0, False
+    # new_group below is a collective over the default group: every rank calls it or none does.
+    # A rank without a GPU or without the backend says so over gloo FIRST, so that the others
+    # do not wait inside new_group for a rank that will never enter it.
+    can_try = 1
+    if not torch.cuda.is_available():
+        can_try, note = 0, "RuntimeError: no GPU visible to this rank"
+    elif not dist.is_nccl_available():
+        can_try, note = 0, "RuntimeError: this torch build has no NCCL/RCCL backend"
+    everyone = torch.tensor([can_try], dtype=torch.int64)
+    dist.all_reduce(everyone, op=dist.ReduceOp.MIN)
+    if int(everyone.item()) == 0:
+        if note is None:
+            note = "another rank has no GPU or no NCCL/RCCL backend"
+        return Rendezvous(dist, "gloo", None, "cpu", note)
     try:
-        if not torch.cuda.is_available():
-            raise RuntimeError("no GPU visible to this rank")
-        if not dist.is_nccl_available():
-            raise RuntimeError("this torch build has no NCCL/RCCL backend")
         group = dist.new_group(backend="nccl",
                                timeout=datetime.timedelta(seconds=max(probe_seconds, 10.0)))
         dev = torch.device("cuda", local_rank)

@@ -1,6 +1,8 @@
 // hexl/hexl.hpp -- umbrella header of the MI355X-native HEXL hot path
-// (reference: hexl/include/hexl/hexl.hpp:6-26).  The experimental SEAL / FFT-like
-// / logging headers of the reference are outside this build's scope.
+// (reference: hexl/include/hexl/hexl.hpp:6-26): everything the reference's umbrella exposes except
+// its FFT-like and LR mat-vec experiments (outside this build's scope).
+// hexl/experimental/seal/ntt-cache.hpp (GetNTT) and locks.hpp are installed too; like the
+// reference's umbrella this header does not pull them in.
 #pragma once
 
 #include "hexl/eltwise/eltwise-add-mod.hpp"
@@ -10,8 +12,11 @@
 #include "hexl/eltwise/eltwise-mult-mod.hpp"
 #include "hexl/eltwise/eltwise-reduce-mod.hpp"
 #include "hexl/eltwise/eltwise-sub-mod.hpp"
+#include "hexl/experimental/seal/dyadic-multiply-internal.hpp"
 #include "hexl/experimental/seal/dyadic-multiply.hpp"
+#include "hexl/experimental/seal/key-switch-internal.hpp"
 #include "hexl/experimental/seal/key-switch.hpp"
+#include "hexl/logging/logging.hpp"
 #include "hexl/ntt/ntt.hpp"
 #include "hexl/number-theory/number-theory.hpp"
 #include "hexl/util/aligned-allocator.hpp"

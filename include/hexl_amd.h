@@ -475,11 +475,13 @@ int hexl_amd_set_tuning(const char* key, uint64_t value);
 
 /* Device scratch of the composite entry points (KeySwitch, the experimental one-launch
  * transform) is cached per (device, stream) and grows on demand.  _release_stream_workspaces
- * frees what is keyed by `stream` on the current device (call it before destroying a stream
- * that ran such calls; waits for the device); _release_workspaces frees all of it, buffer by
- * buffer under its stream's sequence lock -- a buffer another thread is enqueueing against at
- * that moment is left alone and the call returns HEXL_AMD_ERR_INVALID_ARG (call again later).  The per-thread streams of the host-pointer entry
- * points release theirs when the thread ends. */
+ * frees what is keyed by `stream` on the device that OWNS the stream (NULL: the calling
+ * thread's current device), whatever the caller's current device is -- hexl_amd_stream_destroy
+ * does it for streams it created; call it before destroying a stream of your own that ran such
+ * calls; waits for the device.  _release_workspaces frees all of it, buffer by buffer under its
+ * stream's sequence lock -- a buffer another thread is enqueueing against at that moment is left
+ * alone and the call returns HEXL_AMD_ERR_INVALID_ARG (call again later).  The per-thread
+ * streams of the host-pointer entry points release theirs when the thread ends. */
 int hexl_amd_release_stream_workspaces(void* stream);
 int hexl_amd_release_workspaces(void);
 

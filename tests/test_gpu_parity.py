@@ -446,6 +446,45 @@ def test_pointer_kinds_and_zero_copy_host_path(hx, ho):
     assert bad.value == 0
 
 
+def test_short_lived_registration_then_large_pageable_copies(hx, ho):
+    """The lifetime pattern behind round 4's one-in-eleven abort of this suite, restored as a
+    regression test: a short-lived heap array is registered (hexl_amd_host_register), transformed
+    in place over the link, unregistered and freed; the next allocations reuse its address range
+    and go through >= 1 MiB pageable host-to-device copies (a plan's table upload, a staged *_host
+    call, the caller's own copy).  tests/cpp/register_abort_repro.cpp is the standalone form."""
+    import ctypes as C
+    lib = hx.lib
+    for n, bits in ((4096, 49), (8192, 54), (65536, 54), (65536, 54)):
+        q = ho.generate_primes(1, bits, True, n)[0]
+        ntt, ont = hx.NTT(n, q), ho.NTT(n, q)
+        x = ho.fill_splitmix(n, 5 + n, q)
+        want = ont.forward(x, 1, 1)
+        buf = np.zeros(2 * n, dtype=np.uint64)  # short-lived; 1 MiB at n = 65536
+        buf[:n] = x
+        pb = buf.ctypes.data_as(C.c_void_p)
+        assert lib.hexl_amd_host_register(pb, buf.nbytes) == 0
+        try:
+            assert lib.hexl_amd_pointer_kind(pb) == 2
+            po = C.c_void_p(pb.value + n * 8)
+            assert lib.hexl_amd_ntt_forward_host(ntt._h, po, pb, 1, 1, 1) == 0
+            assert np.array_equal(buf[n:], want)
+        finally:
+            assert lib.hexl_amd_host_unregister(pb) == 0
+        assert lib.hexl_amd_pointer_kind(pb) == 0
+        del buf, pb, po
+    # what followed in the runs that died: large pageable copies from fresh allocations
+    n2 = 131072
+    q2 = ho.generate_primes(1, 54, True, n2)[0]
+    big = hx.NTT(n2, q2)  # 2 x 2 MiB table upload
+    y = ho.fill_splitmix(n2, 77, q2)
+    src, dst = y.copy(), np.zeros_like(y)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    assert lib.hexl_amd_ntt_forward_host(big._h, p(dst), p(src), 1, 1, 1) == 0  # staged, 1 MiB
+    assert np.array_equal(dst, ho.NTT(n2, q2).forward(y, 1, 1))
+    z = np.arange(3 << 16, dtype=np.uint64)  # 1.5 MiB through the caller's own copy
+    assert np.array_equal(host(hx, dev(hx, z)), z)
+
+
 @pytest.mark.parametrize("n,batch,bits", [(4096, 1, 49), (4096, 8, 54), (16384, 2, 54), (16384, 3, 54),
                                           (32768, 1, 54), (65536, 1, 54), (1024, 1, 35), (64, 3, 40)])
 def test_host_pointer_paths_on_ordinary_memory(hx, ho, n, batch, bits):

@@ -567,7 +567,7 @@ def profile_stop():
 
 
 def set_tuning(key, value):
-    """Tuning knobs (include/hexl_amd.h documents them): "fp64", "lazy_family", "h60" (read when a
+    """Tuning knobs (include/hexl_amd.h documents them): "fp64", "fp64_long", "lazy_family", "h60" (read when a
     plan is created), "tile13", "bigtile", "host_bounce_kb", "host_pipeline_min_mb", "host_chunk_mb".
     The library reads no environment variable; results never depend on the knobs."""
     _check(lib.hexl_amd_set_tuning(key.encode(), int(value)))

@@ -448,18 +448,19 @@ int hexl_amd_ntt_create(hexl_amd_ntt** out, uint64_t degree, uint64_t modulus,
   const bool doubled = policy == kPolicyLazy || policy == kPolicyLazy32 || policy == kPolicyLazy16 ||
                        policy == kPolicyHarvey60;
   const u64 shoup_bits = policy == kPolicySmall ? 32 : doubled ? 63 : 64;
+  const bool fp_tables = policy == kPolicyFp64 || policy == kPolicyFp64L;  // one double per twiddle
   auto balanced = [q](u64 w) { return w > q / 2 ? -(double)(q - w) : (double)w; };
   auto bits_of = [](double d) {
     u64 b;
     memcpy(&b, &d, sizeof b);
     return b;
   };
-  const size_t entry = policy == kPolicyFp64 ? sizeof(double) : sizeof(ulonglong2);
+  const size_t entry = fp_tables ? sizeof(double) : sizeof(ulonglong2);
   std::vector<u64> hf, hi;  // raw table words
   hf.reserve(n * entry / 8);
   hi.reserve(n * entry / 8);
   for (u64 i = 0; i < n; ++i) {
-    if (policy == kPolicyFp64) {
+    if (fp_tables) {
       hf.push_back(bits_of(balanced(R[i])));
       hi.push_back(bits_of(balanced(Rinv[i])));
     } else {
@@ -476,7 +477,7 @@ int hexl_amd_ntt_create(hexl_amd_ntt** out, uint64_t degree, uint64_t modulus,
   il.mont_mask = (u32)((doubled ? 2 * n : n) - 1);
   il.n1 = nt::inverse_mod(n, q);
   il.n1w = nt::multiply_mod(il.n1, Rinv[1], q);
-  if (policy == kPolicyFp64) {
+  if (fp_tables) {
     il.n1 = bits_of(balanced(il.n1));
     il.n1w = bits_of(balanced(il.n1w));
     il.n1p = il.n1wp = 0;

@@ -24,6 +24,9 @@ constexpr u64 kSmallModulusBound = 1ull << 30;
 // Moduli in [kSmallModulusBound, kFp64ModulusBound) use the Fp64 policy (exact integers in
 // doubles, one-word balanced twiddles).
 constexpr u64 kFp64ModulusBound = 1ull << 50;
+// Below this bound the Fp64 arithmetic has 2^53 / q >= 64 of headroom and runs of stages between
+// full reductions can be twice as long (modarith.h: Fp64L).
+constexpr u64 kFp64LongModulusBound = 1ull << 47;
 
 // Moduli in [kLazy16ModulusBound, kHarvey60ModulusBound) -- from kLazyModulusBound with the
 // bounded Lazy members switched off -- use the Harvey60 policy (Harvey ranges on doubled values;
@@ -41,7 +44,8 @@ enum ArithPolicy : int {
   kPolicyHarvey60 = 4,
   kPolicyLazy32 = 5,
   kPolicyLazy16 = 6,
-  kNumPolicies = 7
+  kPolicyFp64L = 7,
+  kNumPolicies = 8
 };
 int choose_policy(u64 q);  // ntt_kernels.hip
 

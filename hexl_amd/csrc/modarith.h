@@ -266,6 +266,7 @@ struct Strict {  // any q < 2^62; tables hold floor(W * 2^64 / q); plain values
   static constexpr bool kH60 = false;
   static constexpr int kLimit = 0;
   static constexpr bool kExact = false;
+  static constexpr int kFwdRun = 0, kInvRun = 0;
 };
 // The Lazy family: doubled values, 63-bit Shoup factors, no conditional subtraction per
 // butterfly.  kLimit = what floor(2^63 / q) is at least for the moduli the member serves: every
@@ -285,6 +286,7 @@ struct LazyT {
   static constexpr bool kH60 = false;
   static constexpr int kLimit = LIMIT;
   static constexpr bool kExact = EXACT;
+  static constexpr int kFwdRun = 0, kInvRun = 0;
 };
 typedef LazyT<128, false> Lazy;
 typedef LazyT<32, false> Lazy32;
@@ -305,6 +307,7 @@ struct Harvey60 {
   static constexpr bool kH60 = true;
   static constexpr int kLimit = 0;
   static constexpr bool kExact = false;
+  static constexpr int kFwdRun = 0, kInvRun = 0;
 };
 // q < 2^30 (the reference's 32-bit path, hexl/ntt/ntt-internal.cpp:218-226,
 // :279-287): every value of the Strict invariants is below 4q < 2^32, so the
@@ -318,6 +321,7 @@ struct Small {
   static constexpr bool kH60 = false;
   static constexpr int kLimit = 0;
   static constexpr bool kExact = false;
+  static constexpr int kFwdRun = 0, kInvRun = 0;
 };
 
 // 2^30 <= q < 2^50 (the moduli the reference sends to its IFMA-52 / FP64-assisted
@@ -342,14 +346,25 @@ struct Small {
 // A full reduction v - rint(v / q) q leaves |v| <= (0.5 + 2^-48) q in three
 // instructions.  tests/cpp/host_arith_check.cpp replays whole networks through these
 // functions on the CPU and checks every intermediate bound.
-struct Fp64 {
+// kFwdRun / kInvRun: the longest run of stages between two full reductions.  For q < 2^47 the
+// same analysis has 2^53 / q >= 64 to work with and a per-unit error of 1.5 q 2^-53 < 0.0235:
+// a forward pass of up to 14 stages grows a fully reduced value to < 9q (no reduction between
+// the first load and the last store of a pass), an inverse run of 6 stages doubles it to
+// 32q (differences of two such values stay below 2^53): Fp64L.  SEAL's default moduli up to
+// N = 8192 (36- to 44-bit primes) are of this kind.
+template <int FWD_RUN, int INV_RUN>
+struct Fp64T {
   static constexpr bool kLazy = false;
   static constexpr bool kSmall = false;
   static constexpr bool kFp = true;
   static constexpr bool kH60 = false;
   static constexpr int kLimit = 0;
   static constexpr bool kExact = false;
+  static constexpr int kFwdRun = FWD_RUN;
+  static constexpr int kInvRun = INV_RUN;
 };
+typedef Fp64T<7, 3> Fp64;    // 2^47 <= q < 2^50
+typedef Fp64T<24, 6> Fp64L;  // 2^30 <= q < 2^47
 constexpr int kFpFwdRun = 7;
 constexpr int kFpInvRun = 3;
 

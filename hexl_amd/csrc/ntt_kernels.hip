@@ -157,12 +157,12 @@ __device__ __forceinline__ void store_global(u64* uniform_base, u32 byte_off, u6
 
 // A twiddle as it sits in the device table: (W, Shoup factor) for the integer
 // policies, ONE double (balanced W) for Fp64.
-template <class A>
+template <class A, bool FP = A::kFp>
 struct TwOf {
   typedef ulonglong2 T;
 };
-template <>
-struct TwOf<Fp64> {
+template <class A>
+struct TwOf<A, true> {
   typedef double T;
 };
 template <class A>
@@ -270,7 +270,7 @@ __device__ __forceinline__ void fwd_bound_level(u64* x, const ModConst& m, u32 s
 // fwd_bound_level (bit v = stage v of this subtree).
 template <int R, class A>
 __device__ __forceinline__ void fwd_subtree(u64* x, const TwT<A>* wv, const ModConst& m, u32 smask = 0) {
-  static_assert(R <= kFpFwdRun, "Fp64 forward run too long");
+  static_assert(!A::kFp || R <= A::kFwdRun, "Fp64 forward run too long");
 #pragma unroll
   for (int v = 0; v < R; ++v) {
     const int half = 1 << (R - 1 - v);
@@ -306,7 +306,9 @@ __device__ __forceinline__ void fwd_subtree(u64* x, const TwT<A>* wv, const ModC
 // MONT (with LAST): the transform has at least 64 coefficients, the N^-1 scaling of the sum branch
 // is scale_by_inverse_degree (modarith.h).
 // (B = T = 0: what a pass hands over under the policy's limit)
-template <int R, class A, bool LAST, int B = 0, int T = 0, bool MONT = true>
+// FP_EXIT (Fp64 family): all elements are fully reduced at exit (the caller knows whether the
+// run of stages since the last reduction may go on: Rounds::fp_inv_reduce_after).
+template <int R, class A, bool LAST, int B = 0, int T = 0, bool MONT = true, bool FP_EXIT = !LAST>
 __device__ __forceinline__ void inv_subtree(u64* x, const TwT<A>* wv, const ModConst& m,
                                             const InvLast& il) {
   static_assert(R <= 5, "register subtrees are at most 5 stages deep");
@@ -334,9 +336,11 @@ __device__ __forceinline__ void inv_subtree(u64* x, const TwT<A>* wv, const ModC
         // stage (it would keep all their temporaries live at once and spill).
         if (R >= 4) __builtin_amdgcn_sched_barrier(0);
       }
-      if (A::kFp && (t + 1) % kFpInvRun == 0 && v > 0) fp_bound_all<A, (1 << R)>(x, m);
+      if constexpr (A::kFp) {
+        if ((t + 1) % A::kInvRun == 0 && v > 0) fp_bound_all<A, (1 << R)>(x, m);
+      }
     }
-    if (!LAST) fp_bound_all<A, (1 << R)>(x, m);
+    if (FP_EXIT) fp_bound_all<A, (1 << R)>(x, m);
   }
 }
 
@@ -442,7 +446,7 @@ __device__ __forceinline__ void inv_subtree5_streamed(u64* x, const TwT<A>* __re
   load_twiddle_run<1, CTW>(&w0, tw, node);
   inv_level<5, 3, 0, 8, A, false, SC>(x, w3, m, il);
   inv_level<5, 2, 0, 4, A, false, SC>(x, w2, m, il);
-  fp_bound_all<A, 32>(x, m);
+  if constexpr (A::kFp && A::kInvRun < 5) fp_bound_all<A, 32>(x, m);  // (three stages done)
   inv_level<5, 1, 0, 2, A, false, SC>(x, w1, m, il);
   inv_level<5, 0, 0, 1, A, LAST, SC>(x, &w0, m, il);
   if constexpr (A::kLazy) inv_exit_lazy<SC, 5>(x, m);
@@ -636,7 +640,7 @@ __device__ __forceinline__ const u64* multi_source(const MultiCtx& mc, u32 poly,
 template <class A>
 constexpr int policy_id() {
   return A::kSmall ? kPolicySmall
-         : A::kFp  ? kPolicyFp64
+         : A::kFp  ? (A::kInvRun > 3 ? kPolicyFp64L : kPolicyFp64)
          : (A::kLazy && A::kLimit == 32) ? kPolicyLazy32
          : (A::kLazy && A::kLimit == 16) ? kPolicyLazy16
          : A::kLazy ? kPolicyLazy
@@ -740,10 +744,14 @@ __device__ __forceinline__ void round_compute(u64* x, const TwT<A>* wv, const Mo
     else  // (Lazy: entry bound and exit threshold of round j of this pass's chain)
       inv_subtree<r, A, LAST,
                   lazy_chain_entry(j, Rounds<S, CB>::NR, Rounds<S, CB>::R0, kRE, A::kLazy ? A::kLimit : kLazyLimit),
-                  lazy_chain_thresh(j, Rounds<S, CB>::R0, kRE, A::kLazy ? A::kLimit : kLazyLimit), (S >= 6)>(
+                  lazy_chain_thresh(j, Rounds<S, CB>::R0, kRE, A::kLazy ? A::kLimit : kLazyLimit), (S >= 6),
+                  // (Fp64 family: reduce at the round's exit only where the run may not go on)
+                  (A::kFp ? Rounds<S, CB>::fp_inv_reduce_after(j, A::kInvRun > 0 ? A::kInvRun : 1, LAST) : !LAST)>(
           x + (s << r), wv + (s << r), m, il);
   }
-  if (FWD && Rounds<S, CB>::fp_reduce_after(j)) fp_bound_all<A, kE>(x, m);
+  if constexpr (FWD && A::kFp) {
+    if (Rounds<S, CB>::fp_reduce_after(j, A::kFwdRun)) fp_bound_all<A, kE>(x, m);
+  }
 }
 
 // LDS byte address of a slot.  lds_slot is linear over XOR and the fields of a
@@ -1255,7 +1263,7 @@ struct Plan {
 // library reads no environment variable: every knob has a compiled-in default and changes only
 // through that call.  Results never depend on it.
 struct Tuning {
-  std::atomic<u32> fp64{1}, h60{1}, tile13{2}, bigtile{1}, lazy_family{1};
+  std::atomic<u32> fp64{1}, h60{1}, tile13{2}, bigtile{1}, lazy_family{1}, fp64_long{1};
 };
 Tuning& tuning();  // one per process: defined by the dispatch unit
 #if HX_TU_DISPATCH
@@ -1270,6 +1278,7 @@ int set_tuning(const char* key, u64 value) {
   else if (strcmp(key, "h60") == 0 && value <= 1) t.h60 = (u32)value;
   else if (strcmp(key, "bigtile") == 0 && value <= 1) t.bigtile = (u32)value;
   else if (strcmp(key, "lazy_family") == 0 && value <= 1) t.lazy_family = (u32)value;
+  else if (strcmp(key, "fp64_long") == 0 && value <= 1) t.fp64_long = (u32)value;
   else return -1;
   return 0;
 }
@@ -1432,6 +1441,7 @@ HX_POLICY_ENTRY_DECL(strict)
 HX_POLICY_ENTRY_DECL(harvey60)
 HX_POLICY_ENTRY_DECL(lazy32)
 HX_POLICY_ENTRY_DECL(lazy16)
+HX_POLICY_ENTRY_DECL(fp64l)
 #undef HX_POLICY_ENTRY_DECL
 
 #define HX_POLICY_ENTRY_DEF(NAME, A)                                                            \
@@ -1465,9 +1475,12 @@ HX_POLICY_ENTRY_DEF(lazy32, Lazy32)
 #if HX_TU_POLICY(6)
 HX_POLICY_ENTRY_DEF(lazy16, Lazy16)
 #endif
+#if HX_TU_POLICY(7)
+HX_POLICY_ENTRY_DEF(fp64l, Fp64L)
+#endif
 #undef HX_POLICY_ENTRY_DEF
 static_assert(kPolicySmall == 0 && kPolicyFp64 == 1 && kPolicyLazy == 2 && kPolicyStrict == 3 &&
-                  kPolicyHarvey60 == 4 && kPolicyLazy32 == 5 && kPolicyLazy16 == 6,
+                  kPolicyHarvey60 == 4 && kPolicyLazy32 == 5 && kPolicyLazy16 == 6 && kPolicyFp64L == 7,
               "the HX_TU_POLICY numbers above are the ArithPolicy values");
 
 #if HX_TU_DISPATCH
@@ -1482,6 +1495,7 @@ static hipError_t transform_dispatch(bool forward, const NttTables& t, u64* resu
       return transform_entry_harvey60(forward, t, result, operand, batch, out_mf, st);
     case kPolicyLazy32: return transform_entry_lazy32(forward, t, result, operand, batch, out_mf, st);
     case kPolicyLazy16: return transform_entry_lazy16(forward, t, result, operand, batch, out_mf, st);
+    case kPolicyFp64L: return transform_entry_fp64l(forward, t, result, operand, batch, out_mf, st);
     default: return transform_entry_strict(forward, t, result, operand, batch, out_mf, st);
   }
 }
@@ -1561,6 +1575,8 @@ hipError_t ntt_multi_launch(bool forward, const NttTables* const* tabs, u32 num_
     e = multi_entry_lazy32(forward, t0, mc, polys, result, operand, out_mf, st);
   if (have[kPolicyLazy16] && e == hipSuccess)
     e = multi_entry_lazy16(forward, t0, mc, polys, result, operand, out_mf, st);
+  if (have[kPolicyFp64L] && e == hipSuccess)
+    e = multi_entry_fp64l(forward, t0, mc, polys, result, operand, out_mf, st);
   if (have[kPolicyStrict] && e == hipSuccess)
     e = multi_entry_strict(forward, t0, mc, polys, result, operand, out_mf, st);
   // past the check above a refusal can only come after launches were made: a hard error,
@@ -1575,6 +1591,8 @@ int choose_policy(u64 q) {
   const bool fp = tuning().fp64.load() != 0;
   // HEXL_AMD_FP64=2: Fp64 also below 2^30 (A/B against the 32-bit Small policy)
   if (q < kSmallModulusBound && !(fp && tuning().fp64.load() == 2)) return kPolicySmall;
+  // (below 2^47 the long-run member of the Fp64 family; "fp64_long" = 0: Fp64 for all of them)
+  if (q < kFp64LongModulusBound && fp && tuning().fp64_long.load() != 0) return kPolicyFp64L;
   if (q < kFp64ModulusBound && fp) return kPolicyFp64;
   // (the Lazy policy's quotient estimates shift the HIGH word of a value: q >= 2^32; with the
   // Fp64 policy switched off the moduli between 2^30 and 2^32 take the Harvey60 policy)

@@ -52,20 +52,36 @@ struct Rounds {
   // Forward executes rounds 0..NR-1, inverse NR-1..0.
   static constexpr bool pre_fwd(int j) { return j >= 1 && j < NR && !vec(j); }
   static constexpr bool pre_inv(int j) { return j >= 0 && j <= NR - 2 && !vec(j); }
-  // Fp64 forward: a pass starts from fully reduced values; all elements are reduced
-  // again after round j when running round j + 1 too would make the run longer than
-  // kFpFwdRun stages (modarith.h).  fwd_run(j) = stages since the last reduction at
-  // the end of round j.
-  static constexpr int fwd_run(int j) {
+  // Fp64 family, forward: a pass starts from fully reduced values; all elements are reduced
+  // again after round j when running round j + 1 too would make the run longer than `run`
+  // stages (modarith.h: kFwdRun of the policy).  fwd_run(j) = stages since the last reduction
+  // at the end of round j.
+  static constexpr int fwd_run(int j, int run = kFpFwdRun) {
     int c = 0;
     for (int i = 0; i <= j; ++i) {
       c += r(i);
-      if (i < j && c + r(i + 1) > kFpFwdRun) c = 0;
+      if (i < j && c + r(i + 1) > run) c = 0;
     }
     return c;
   }
-  static constexpr bool fp_reduce_after(int j) {
-    return j + 1 < NR && fwd_run(j) + r(j + 1) > kFpFwdRun;
+  static constexpr bool fp_reduce_after(int j, int run = kFpFwdRun) {
+    return j + 1 < NR && fwd_run(j, run) + r(j + 1) > run;
+  }
+  // The same for the inverse, whose rounds execute NR-1 .. 0 (kInvRun of the policy): all
+  // elements are reduced after round j when round j - 1 would make the run too long; after
+  // round 0 unless the pass ends the transform (the hand-over between passes is reduced, the
+  // finish reduces by itself).  inv_run(j) = stages since the last reduction at the end of
+  // round j.
+  static constexpr int inv_run(int j, int run) {
+    int c = 0;
+    for (int i = NR - 1; i >= j; --i) {
+      c += r(i);
+      if (i > j && c + r(i - 1) > run) c = 0;
+    }
+    return c;
+  }
+  static constexpr bool fp_inv_reduce_after(int j, int run, bool last) {
+    return j == 0 ? !last : inv_run(j, run) + r(j - 1) > run;
   }
 };
 

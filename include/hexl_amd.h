@@ -450,6 +450,9 @@ int hexl_amd_profile_get(int i, const char** name, float* ms);
  *   "fp64"             1 (default) = plans for 2^30 <= q < 2^50 use the Fp64 arithmetic policy
  *                      (exact integers in doubles), 0 = the integer Lazy policy, 2 = Fp64 also
  *                      below 2^30; read when a plan is created
+ *   "fp64_long"        1 (default) = plans for 2^30 <= q < 2^47 use the long-run member of the Fp64
+ *                      family (no reduction inside a forward pass, inverse runs of 6 stages), 0 =
+ *                      the Fp64 policy of 2^47 <= q < 2^50 for them too; read when a plan is created
  *   "lazy_family"      1 (default) = plans for 2^56 <= q < 2^58 / 2^58 <= q < 2^59 use the bounded
  *                      members of the Lazy arithmetic family (doubled values kept below 32q / 16q:
  *                      a sign-tested subtraction on the stages the host marks instead of one per

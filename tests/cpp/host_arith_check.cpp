@@ -386,7 +386,8 @@ static std::vector<LazyPass> library_passes(int L, bool one_kernel_14 = true) {
 // promises, and the outputs against the oracle bit for bit.
 #include <cmath>
 static void check_fp(u64 n, u64 q, const std::vector<int>& fwd_runs,
-                     const std::vector<int>& inv_runs, u64 in_mf_f, u64 in_mf_i) {
+                     const std::vector<int>& inv_runs, u64 in_mf_f, u64 in_mf_i,
+                     int max_fwd_run = kFpFwdRun, int max_inv_run = kFpInvRun) {
   int L = 0;
   while ((1ull << L) < n) ++L;
   std::vector<u64> R(n), Rp(n), Ri_stage(n), Rip_stage(n);
@@ -401,6 +402,9 @@ static void check_fp(u64 n, u64 q, const std::vector<int>& fwd_runs,
   const ModConst m = make_mod_const(q);
   ++g_cases;
   const double two53 = 9007199254740992.0, qd = (double)q;
+  // per unit of |y| / q the quotient estimate is off by at most 1.5 q 2^-53 (modarith.h):
+  // 0.1875 for q < 2^50, 0.0235 for q < 2^47
+  const double unit_err = 1.5 * qd / two53;
   std::vector<u64> in(n), ref(n), x(n);
   // ---------------- forward
   for (auto& v : in) v = rnd() % (in_mf_f * q);
@@ -416,8 +420,9 @@ static void check_fp(u64 n, u64 q, const std::vector<int>& fwd_runs,
   for (size_t ri = 0; ri < fwd_runs.size() && s < L; ++ri) {
     double bound = 0.5000001;  // in units of q
     for (int tt = 0; tt < fwd_runs[ri] && s < L; ++tt, ++s) {
-      EXPECT(tt < kFpFwdRun, "forward run longer than kFpFwdRun");
-      bound = 1.1875 * bound + 0.5;
+      EXPECT(tt < max_fwd_run, "forward run longer than the policy's kFwdRun");
+      bound = (1.0 + unit_err) * bound + 0.5;
+      EXPECT(bound * qd < two53, "fp fwd: the bound itself passes 2^53 (stage %d)", s);
       const u64 mgroups = 1ull << s, t = n >> (s + 1);
       for (u64 i = 0; i < mgroups; ++i)
         for (u64 j = 0; j < t; ++j) {
@@ -451,8 +456,13 @@ static void check_fp(u64 n, u64 q, const std::vector<int>& fwd_runs,
   const double n1d = balanced(n1), n1wd = balanced(ho_multiply_mod(n1, ho_inverse_mod(R[1], q), q));
   int stage = L - 1;
   for (size_t ri = 0; ri < inv_runs.size() && stage >= 0; ++ri) {
+    double bound = 0.5000001;  // every element at the start of a run
     for (int tt = 0; tt < inv_runs[ri] && stage >= 0; ++tt, --stage) {
-      EXPECT(tt < kFpInvRun, "inverse run longer than kFpInvRun");
+      EXPECT(tt < max_inv_run, "inverse run longer than the policy's kInvRun");
+      // sums double; a product of a difference below 2 B q comes out below (0.5 + unit_err 2 B) q
+      const double diff = 2.0 * bound;
+      EXPECT(diff * qd < two53, "fp inv: differences pass 2^53 (stage %d)", stage);
+      bound = std::max(2.0 * bound, 0.5 + unit_err * diff);
       const u64 mgroups = 1ull << stage, t = n >> (stage + 1);
       for (u64 i = 0; i < mgroups; ++i)
         for (u64 j = 0; j < t; ++j) {
@@ -463,7 +473,8 @@ static void check_fp(u64 n, u64 q, const std::vector<int>& fwd_runs,
             inv_butterfly_fp(x[ia], x[ib], V[mgroups + i], m);
           const double av = std::fabs(fp_bits_to_double(x[ia])),
                        bv = std::fabs(fp_bits_to_double(x[ib]));
-          EXPECT(av <= 4.0001 * qd && bv <= 4.0001 * qd, "fp inv bound: stage %d", stage);
+          EXPECT(av < two53 && bv < two53, "fp inv 2^53: stage %d", stage);
+          EXPECT(av <= bound * 1.0001 * qd && bv <= bound * 1.0001 * qd, "fp inv bound: stage %d", stage);
         }
     }
     if (stage >= 0)
@@ -701,6 +712,43 @@ int main() {
     }
     check_fp_product(562949954093057ull);
     check_fp(4096, 562949954093057ull, {3, 3, 6}, {3, 3, 3, 3}, 1, 1);
+    // Fp64L (q < 2^47: forward passes without a reduction between first load and last store,
+    // inverse runs of up to 6 stages), the run layouts of the kernels: one tile pass of the whole
+    // network (N <= 2^14: rounds NR-1 .. 0, reduced where two more rounds would not fit), strided
+    // + tile passes above
+    const Case fpl_cases[] = {{16, 30}, {1024, 35}, {4096, 36}, {4096, 43}, {8192, 43}, {8192, 46},
+                              {16384, 46}, {65536, 44}, {131072, 46}};
+    for (const Case& c : fpl_cases) {
+      int L = 0;
+      while ((1ull << L) < c.n) ++L;
+      size_t got = ho_generate_primes(primes, 1, c.bits, 1, c.n);
+      got += ho_generate_primes(primes + got, 1, c.bits, 0, c.n);  // just below 2^(bits+1)
+      for (size_t pi = 0; pi < got; ++pi) {
+        if (primes[pi] >= (1ull << 47)) continue;
+        check_fp_product(primes[pi]);
+        std::vector<int> fwd, inv;
+        if (L <= 14) {
+          fwd = {L};
+          // rounds of the tile pass in inverse order, merged into runs of <= 6 stages
+          const int re = re_of(L), rounds = (L + re - 1) / re, r0 = L - (rounds - 1) * re;
+          int c_run = 0;
+          for (int j = rounds - 1; j >= 0; --j) {
+            const int r = j == 0 ? r0 : re, rn = j >= 1 ? (j - 1 == 0 ? r0 : re) : 0;
+            c_run += r;
+            if (j == 0 || c_run + rn > 6) {
+              inv.push_back(c_run);
+              c_run = 0;
+            }
+          }
+        } else {
+          const int bottom = L <= 16 ? 11 : 12;
+          fwd = {L - bottom, bottom};
+          inv = bottom == 11 ? std::vector<int>{6, 5, L - bottom} : std::vector<int>{6, 6, L - bottom};
+        }
+        check_fp(c.n, primes[pi], fwd, inv, 4, 2, Fp64L::kFwdRun, Fp64L::kInvRun);
+        check_fp(c.n, primes[pi], fwd, inv, 1, 1, Fp64L::kFwdRun, Fp64L::kInvRun);
+      }
+    }
   }
   if (g_fail) {
     fprintf(stderr, "host_arith_check: %d failures\n", g_fail);

@@ -319,6 +319,7 @@ def _mixed_primes(ho, n, bits_list):
     (65536, [54] * 8, list(range(8)), 1, 16),              # configs[3]'s 8 primes, interleaved
     (16384, [28, 54, 45, 60, 61, 54, 45, 59], list(range(8)), 1, 24),  # five policies
     (65536, [56, 54, 58, 57, 59], list(range(5)), 1, 10),              # the Lazy family + Harvey60
+    (8192, [43, 49, 36, 54], list(range(4)), 1, 12),                   # Fp64L + Fp64 + Lazy in one call
     (4096, [54, 49, 60], [0, 1, 2, 1], 2, 19),             # inner 2, a plan used twice, ragged end
     (32768, [54, 54, 54], [2, 0, 1], 3, 10),               # permuted table, last slot cut short
     (2048, [54, 45], [0, 1], 1, 6),                        # below the multi-plan degrees: run by run
@@ -685,6 +686,58 @@ def test_ntt_fp64_policy_matches_integer_policy(hx, n, batch):
         assert torch.equal(a, b)
         fp.ComputeInverse(x, x, in_mf, 2)  # in place, lazy output range
         assert int(x.min()) >= 0 and int(x.max()) < 2 * q and torch.equal(x % q, a)
+
+
+@pytest.mark.parametrize("n,batch,bits,small_end", [
+    (64, 9, 30, True), (1024, 33, 35, True), (4096, 256, 36, True), (4096, 64, 46, False),
+    (8192, 40, 43, True), (8192, 7, 46, False), (16384, 200, 44, True), (16384, 5, 46, False),
+    (32768, 12, 40, True), (65536, 64, 46, False), (65536, 20, 33, True), (1 << 17, 3, 46, False),
+    (1 << 18, 2, 45, True), (1 << 19, 2, 46, False), (1 << 20, 1, 46, False)])
+def test_ntt_fp64_long_run_policy(hx, n, batch, bits, small_end):
+    """2^30 <= q < 2^47 (SEAL's default moduli up to N = 8192): the long-run member of the Fp64
+    family (modarith.h Fp64L: no reduction inside a forward pass, inverse runs of 6 stages instead
+    of 3) against the integer policy AND against the short-run Fp64 on the same inputs, bit for
+    bit -- primes at both ends of the range, adversarial inputs, every plan shape."""
+    import torch
+    q = hx.GeneratePrimes(1, bits, small_end, n)[0]
+    assert (1 << 30) <= q < (1 << 47)
+    try:
+        hx.set_tuning("fp64", 0)
+        integer = hx.NTT(n, q)
+        hx.set_tuning("fp64", 1)
+        hx.set_tuning("fp64_long", 0)
+        short = hx.NTT(n, q)
+        hx.set_tuning("fp64_long", 1)
+        long_run = hx.NTT(n, q)
+    finally:
+        hx.set_tuning("fp64", 1)
+        hx.set_tuning("fp64_long", 1)
+    x = torch.empty((batch, n), dtype=torch.int64, device="cuda")
+    a, b, c = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    for in_mf in (1, 2, 4):
+        for fill in ("random", "top"):
+            if fill == "random":
+                hx.fill_splitmix(x, n, batch, 171, in_mf * q)
+            else:
+                x.fill_(in_mf * q - 1)
+            integer.ComputeForward(a, x, in_mf, 1)
+            short.ComputeForward(b, x, in_mf, 1)
+            long_run.ComputeForward(c, x, in_mf, 1)
+            assert torch.equal(a, b) and torch.equal(a, c)
+            long_run.ComputeForward(c, x, in_mf, 4)
+            assert int(c.min()) >= 0 and int(c.max()) < 4 * q and torch.equal(c % q, a)
+    for in_mf in (1, 2):
+        for fill in ("random", "top"):
+            if fill == "random":
+                hx.fill_splitmix(x, n, batch, 172, in_mf * q)
+            else:
+                x.fill_(in_mf * q - 1)
+            integer.ComputeInverse(a, x, in_mf, 1)
+            short.ComputeInverse(b, x, in_mf, 1)
+            long_run.ComputeInverse(c, x, in_mf, 1)
+            assert torch.equal(a, b) and torch.equal(a, c)
+            long_run.ComputeInverse(c, x, in_mf, 2)
+            assert int(c.min()) >= 0 and int(c.max()) < 2 * q and torch.equal(c % q, a)
 
 
 @pytest.mark.parametrize("n,bits,small_end", [(4096, 30, True), (65536, 31, False), (16384, 31, True),

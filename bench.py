@@ -9,16 +9,22 @@ prime (BASELINE.json configs[2]).  Inputs are generated on the device
 (splitmix64) and are resident in HBM before the timed region starts.
 
 Multi-GPU (--gpus G > 1, one process per GPU, no data-path collective):
-  --scaling weak (default)  rank g transforms the 4096 polynomials of RNS prime g: per-GPU
-                            work fixed, the job grows with G (at G = 1 this is the headline
-                            configuration, which keeps the 1-GPU line comparable);
+  --scaling auto (default)  G = 1: the headline configuration.  G > 1: `value` is the STRONG job
+                            below -- the one BASELINE.json names for the 1/2/4/8 curve -- and the
+                            line's "weak" block carries the weak figure measured in the same run
+                            (the headline configuration on every GPU: comparable point to point
+                            with the one-GPU line; the one-GPU line's secondary.config4 is the
+                            strong job's G = 1 point);
   --scaling strong          the job is ALWAYS BASELINE configs[3] -- 8 RNS primes x 4096
                             polynomials = 32,768 transforms per direction -- cut into G
                             contiguous shards of the flat (prime, polynomial) index (SURVEY.md
                             8e; hexl/experimental/seal/key-switch-internal.cpp:51-55 is the
                             per-modulus loop being sharded): one prime per GPU at G = 8, four
                             at G = 2, all eight (16 GiB) at G = 1, each rank running its
-                            primes through hexl_amd_ntt_forward_rns / _inverse_rns.
+                            primes through hexl_amd_ntt_forward_rns / _inverse_rns;
+  --scaling weak            rank g transforms the 4096 polynomials of RNS prime g: per-GPU
+                            work fixed, the job grows with G.
+  (with G > 1 the mode that is not `value` is timed the same way and reported beside it)
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement):
 value = Fwd+Inv NTTs per second over the whole job; `roofline` = algorithmic
@@ -396,7 +402,17 @@ def host_path(hx):
     import torch
 
     out = {"unit": "us per call, one forward transform of one polynomial",
-           "entry_point": "hexl_amd_ntt_forward_host (what intel::hexl::NTT::ComputeForward binds)"}
+           "entry_point": "hexl_amd_ntt_forward_host (what intel::hexl::NTT::ComputeForward binds)",
+           "measured_through": "Python ctypes around the C-ABI (adds about a microsecond of "
+                               "call overhead per call); cpp_budget is the same call made from C++"}
+    # the same call from C++ (intel::hexl::NTT::ComputeForward on a std::vector, clock_gettime
+    # around it) with its phases timed one by one: tests/cpp/host_call_budget.cpp
+    if os.path.exists(HOST_CALL_BUDGET_BIN):
+        import subprocess
+        r = subprocess.run([HOST_CALL_BUDGET_BIN, "1000"], capture_output=True, text=True, timeout=300)
+        rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+        out["cpp_budget"] = ({f"N={row['n']}": row for row in rows} if r.returncode == 0 and rows
+                             else {"error": (r.stderr or r.stdout)[-300:]})
     for n, bits in HOST_PATH_SHAPES:
         q = hx.GeneratePrimes(1, bits, True, n)[0]
         ntt = hx.NTT(n, q)
@@ -483,17 +499,82 @@ def composites(hx):
                              for _ in range(C) for i in range(D)])
     ks = {"shape": f"n={n}, {D} decomposition moduli (55-bit) + special prime, {C} key components"}
     d_t, d_r = hx.from_numpy(target), hx.from_numpy(result)
+    # one target per call, as the reference's caller makes it (key-switch-internal.cpp:25-201):
+    # on the default stream (always launch by launch) and on a stream of the caller's own, where a
+    # sequence that comes back with the same buffers is replayed from a captured graph
+    # (include/hexl_amd.h: "ks_graph"); the counters say which path the timed calls took
     t = gpu_time(lambda: hx.KeySwitch(d_r, d_t, n, D, K, D + 1, C, moduli, keys, msf), 30)
-    ks["one_target_per_call_us"] = t * 1e6
+    ks["one_target_per_call_default_stream_us"] = t * 1e6
+    side = torch.cuda.Stream()
+
+    def on_side():
+        with torch.cuda.stream(side):
+            hx.KeySwitch(d_r, d_t, n, D, K, D + 1, C, moduli, keys, msf)
+
+    def side_time(reps):
+        for _ in range(4):
+            on_side()
+        side.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        w0 = time.perf_counter()
+        with torch.cuda.stream(side):
+            e0.record()
+        for _ in range(reps):
+            on_side()
+        with torch.cuda.stream(side):
+            e1.record()
+        enqueue = time.perf_counter() - w0
+        side.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3, enqueue / reps
+    hx.set_tuning("ks_graph", 0)
+    t_eager, host_eager = side_time(30)
+    hx.set_tuning("ks_graph", 1)
+    r0 = hx.get_counter("ks_graph_replays")
+    t_replay, host_replay = side_time(30)
+    replays = hx.get_counter("ks_graph_replays") - r0
+    ks["one_target_per_call_eager_us"] = t_eager * 1e6
+    ks["one_target_per_call_us"] = t_replay * 1e6
+    ks["one_target_per_call_path"] = (f"graph replay ({replays} of 34 calls)" if replays >= 30
+                                      else f"launch by launch ({replays} replays)")
+    ks["host_enqueue_us_per_call"] = {"eager": host_eager * 1e6, "replay": host_replay * 1e6}
+    hx.lib.hexl_amd_release_stream_workspaces(side.cuda_stream)
+    # Floors for one target: (a) its transforms alone at the batched per-transform rate of this
+    # degree -- D inverse (targets to coefficient form) + D^2 forward (operands) + C inverse (last
+    # components) + C D forward (corrections); (b) its algorithmic HBM bytes at 8 TB/s -- target
+    # D n, key blocks (D + 1) D C n, result read + written C D n each, 8 bytes a word.
+    ref_q = moduli[0]
+    plan = hx.NTT(n, ref_q)
+    polys = 4096
+    buf = torch.empty((polys, n), dtype=torch.int64, device="cuda")
+    hx.fill_splitmix(buf, n, polys, 7, ref_q)
+    t_fwd = gpu_time(lambda: plan.ComputeForward(buf, buf, 1, 1), 10) / polys
+    t_inv = gpu_time(lambda: plan.ComputeInverse(buf, buf, 1, 1), 10) / polys
+    del buf
+    n_fwd, n_inv = D * D + C * D, D + C
+    ntt_floor = n_fwd * t_fwd + n_inv * t_inv
+    hbm_bytes = 8.0 * n * (D + (D + 1) * D * C + 2 * C * D)
+    ks["transforms_per_target"] = {"forward": n_fwd, "inverse": n_inv,
+                                   "ns_per_transform_batched": {"forward": t_fwd * 1e9, "inverse": t_inv * 1e9}}
+    ks["ntt_floor_us"] = ntt_floor * 1e6
+    ks["hbm_floor_us"] = hbm_bytes / (HBM_PEAK_GBPS * 1e9) * 1e6
+    ks["algorithmic_bytes_per_target"] = hbm_bytes
     for T in (256,):
         d_tt, d_rr = hx.from_numpy(np.tile(target, T)), hx.from_numpy(np.tile(result, T))
         t = gpu_time(lambda: hx.KeySwitchBatch(d_rr, d_tt, T, n, D, K, D + 1, C, moduli, keys, msf), 5)
         ks[f"{T}_targets_per_call_us_per_target"] = t * 1e6 / T
         ks[f"{T}_targets_per_call_ms"] = t * 1e3
+        ks[f"{T}_targets_frac_of_ntt_floor"] = ntt_floor / (t / T)
+        ks[f"{T}_targets_GBps_algorithmic"] = hbm_bytes * T / t / 1e9
+        ks[f"{T}_targets_frac_of_hbm_peak"] = hbm_bytes * T / t / 1e9 / HBM_PEAK_GBPS
         del d_tt, d_rr
+    ks["one_target_frac_of_ntt_floor"] = ntt_floor / t_replay
+    ks["one_target_frac_of_ntt_floor_eager"] = ntt_floor / t_eager
     out["key_switch"] = ks
     torch.cuda.empty_cache()
     return out
+
+
+HOST_CALL_BUDGET_BIN = os.path.join(ROOT, "tests", "cpp", "host_call_budget")
 
 
 def free_port():
@@ -547,6 +628,8 @@ def threads_main(args):
     """--launcher threads: the same job as the one-process-per-GPU launcher, driven from ONE
     process through the C-ABI (tests/cpp/multi_device.cpp), same JSON shape."""
     devices = [0] * args.gpus if os.environ.get("BENCH_ONE_DEVICE") == "1" else list(range(args.gpus))
+    if args.scaling == "auto":
+        args.scaling = "strong" if args.gpus > 1 else "weak"
     md = run_multi_device(devices, args.scaling, args.steps, args.warmup + PREWARM // 2, batch=args.batch)
     strong = args.scaling == "strong"
     total = md["polynomials_total"]
@@ -580,10 +663,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scaling", choices=("weak", "strong"),
-                    default=os.environ.get("BENCH_SCALING", "weak"),
-                    help="multi-GPU job: weak = one prime x 4096 polynomials per GPU (default); "
-                         "strong = always 8 primes x 4096 polynomials, sharded over the GPUs")
+    ap.add_argument("--scaling", choices=("auto", "weak", "strong"),
+                    default=os.environ.get("BENCH_SCALING", "auto"),
+                    help="multi-GPU job: strong = always BASELINE configs[3], 8 primes x 4096 "
+                         "polynomials sharded over the GPUs; weak = one prime x 4096 polynomials per "
+                         "GPU; auto (default) = the headline configuration on one GPU, strong on "
+                         "several with the weak figure in the line's \"weak\" block")
     ap.add_argument("--launcher", choices=("processes", "threads"),
                     default=os.environ.get("BENCH_LAUNCHER", "processes"),
                     help="processes (default): one process per GPU under torch.distributed.run; "
@@ -647,35 +732,72 @@ def main():
     # The job: weak = `world` primes x `batch` polynomials (rank g owns prime g); strong =
     # the 8 primes x `batch` polynomials of configs[3] whatever `world` is.  Either way the flat
     # (prime, polynomial) index is cut into contiguous per-rank shards, no collective on the
-    # data path.
+    # data path.  "auto" (the default, what the driver's launcher gets): one GPU = the headline
+    # configuration (configs[2]); several GPUs = configs[3] sharded, the job BASELINE.json names
+    # for the 1/2/4/8 curve, with the weak figure (one prime x `batch` per GPU: the headline
+    # configuration on every GPU, comparable point to point with the one-GPU line) measured
+    # in the same run and reported in the line's "weak" block.
     batch = args.batch
+    if args.scaling == "auto":
+        args.scaling = "strong" if world > 1 else "weak"
     strong = args.scaling == "strong"
-    num_primes = len(PRIMES) if strong else world
-    segments = job_partition(num_primes, batch, world, args.scaling)[rank]
-    my_polys = sum(c for _, _, c in segments)
-    plans = [hx.NTT(N, PRIMES[p % len(PRIMES)]) for p, _, _ in segments]
-    data = torch.empty((my_polys, N), dtype=torch.int64, device="cuda")
-    views, off = [], 0
-    for (p, first, count), plan in zip(segments, plans):
-        v = data[off:off + count]
-        hx.fill_splitmix(v, N, count, 1 + p * batch + first, PRIMES[p % len(PRIMES)])
-        views.append(v)
-        off += count
-    check = data[:2].clone()
-    whole = len(segments) > 1 and all(c == segments[0][2] for _, _, c in segments)
 
-    def step():
-        if len(segments) == 1:
-            plans[0].ComputeForward(data, data, 1, 1)
-            plans[0].ComputeInverse(data, data, 1, 1)
-        elif whole:  # several whole primes: the RNS entry point (prime-major blocks)
-            hx.ComputeForwardRNS(plans, data, data, 1, 1)
-            hx.ComputeInverseRNS(plans, data, data, 1, 1)
-        else:  # a shard that cuts through primes: segment by segment
-            for plan, v in zip(plans, views):
-                plan.ComputeForward(v, v, 1, 1)
-            for plan, v in zip(plans, views):
-                plan.ComputeInverse(v, v, 1, 1)
+    def build_job(scaling):
+        """This rank's shard of the job: (segments, plans, data, check, step, polynomials)."""
+        primes = len(PRIMES) if scaling == "strong" else world
+        segs = job_partition(primes, batch, world, scaling)[rank]
+        polys = sum(c for _, _, c in segs)
+        plans_ = [hx.NTT(N, PRIMES[p % len(PRIMES)]) for p, _, _ in segs]
+        data_ = torch.empty((polys, N), dtype=torch.int64, device="cuda")
+        views_, off = [], 0
+        for (p, first, count), plan in zip(segs, plans_):
+            v = data_[off:off + count]
+            hx.fill_splitmix(v, N, count, 1 + p * batch + first, PRIMES[p % len(PRIMES)])
+            views_.append(v)
+            off += count
+        whole_ = len(segs) > 1 and all(c == segs[0][2] for _, _, c in segs)
+
+        def step_():
+            if len(segs) == 1:
+                plans_[0].ComputeForward(data_, data_, 1, 1)
+                plans_[0].ComputeInverse(data_, data_, 1, 1)
+            elif whole_:  # several whole primes: the RNS entry point (prime-major blocks)
+                hx.ComputeForwardRNS(plans_, data_, data_, 1, 1)
+                hx.ComputeInverseRNS(plans_, data_, data_, 1, 1)
+            else:  # a shard that cuts through primes: segment by segment
+                for plan, v in zip(plans_, views_):
+                    plan.ComputeForward(v, v, 1, 1)
+                for plan, v in zip(plans_, views_):
+                    plan.ComputeInverse(v, v, 1, 1)
+        return segs, plans_, data_, data_[:2].clone(), step_, polys, primes
+
+    def side_job(scaling):
+        """The other scaling mode of a multi-GPU run, timed like the headline (K steps between
+        barriers, max over ranks, round trip asserted), reported beside it."""
+        segs, plans_, data_, check_, step_, polys, primes = build_job(scaling)
+        for _ in range(PREWARM + args.warmup):
+            step_()
+        barrier()
+        t_ = time.perf_counter()
+        for _ in range(args.steps):
+            step_()
+        barrier()
+        dt = time.perf_counter() - t_
+        assert torch.equal(check_, data_[:2]), "round trip mismatch in the side job"
+        rate = rv.gather(2 * polys * args.steps / dt)
+        dt = rv.max(dt)
+        total = primes * batch
+        del data_
+        torch.cuda.empty_cache()
+        return {"scaling": scaling, "value": 2 * total * args.steps / dt, "unit": "NTT/s",
+                "ms_per_step": dt / args.steps * 1e3, "steps": args.steps,
+                "polynomials_total": total, "polynomials_this_rank": polys,
+                "per_rank_NTT_per_s": rate,
+                "workload": (f"configs[3]: 8 primes x {batch} polynomials sharded over {world} GPU(s)"
+                             if scaling == "strong" else
+                             f"the headline configuration on every GPU: one prime x {batch} polynomials each")}
+
+    segments, plans, data, check, step, my_polys, num_primes = build_job(args.scaling)
 
     # The first ~10 passes over a freshly allocated 2 GiB buffer run 8 % slower (clock ramp,
     # first-touch page mapping), whatever W is; PREWARM untimed passes precede the W warm-up
@@ -701,6 +823,11 @@ def main():
     sustained = sustained_run(torch, step, my_polys, float(os.environ.get("BENCH_SUSTAINED_S", "3")))
     my_rate = 2 * my_polys * args.steps / elapsed
     per_rank = rv.gather(my_rate)
+    # several GPUs: the other scaling mode in the same run (every rank takes part)
+    other_mode = None
+    if world > 1 and not args.no_secondary:
+        other = "weak" if strong else "strong"
+        other_mode = (other, side_job(other))
     median_ms = rv.max(median(step_ms))
     elapsed = rv.max(elapsed)
 
@@ -859,6 +986,8 @@ def main():
                          "kernel below it; valu_busy = SQ_ACTIVE_INST_VALU (quad-cycles) * 4 / (SIMDs * "
                          "GRBM_GUI_ACTIVE per XCD) from rocprofv3 --pmc (DESIGN.md 5)")},
         }
+        if other_mode is not None:
+            out[other_mode[0]] = other_mode[1]
         if mult is not None:
             out["eltwise_mult_mod"] = mult
         if secondary is not None:

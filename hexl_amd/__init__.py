@@ -110,6 +110,7 @@ def _load():
     sig("hexl_amd_profile_stop", ci, C.POINTER(ci))
     sig("hexl_amd_profile_get", ci, ci, C.POINTER(C.c_char_p), C.POINTER(C.c_float))
     sig("hexl_amd_set_tuning", ci, C.c_char_p, u64)
+    sig("hexl_amd_get_counter", ci, C.c_char_p, C.POINTER(u64))
     sig("hexl_amd_ntt_forward_map", ci, C.POINTER(vp), u64, C.POINTER(C.c_uint8), u64, u64, p64, p64,
         u64, u64, u64, vp)
     sig("hexl_amd_ntt_inverse_map", ci, C.POINTER(vp), u64, C.POINTER(C.c_uint8), u64, u64, p64, p64,
@@ -158,7 +159,7 @@ C_ABI_SYMBOLS = [
     "hexl_amd_minimal_primitive_root", "hexl_amd_reverse_bits", "hexl_amd_is_prime",
     "hexl_amd_generate_primes", "hexl_amd_ntt_check_arguments", "hexl_amd_fill_splitmix",
     "hexl_amd_profile_start", "hexl_amd_profile_stop", "hexl_amd_profile_get",
-    "hexl_amd_set_tuning",
+    "hexl_amd_set_tuning", "hexl_amd_get_counter",
     "hexl_amd_ntt_forward_map", "hexl_amd_ntt_inverse_map", "hexl_amd_ntt_forward_indexed",
     "hexl_amd_ntt_inverse_indexed", "hexl_amd_release_stream_workspaces",
     "hexl_amd_release_workspaces", "hexl_amd_host_alloc", "hexl_amd_host_free",
@@ -566,9 +567,16 @@ def profile_stop():
     return out
 
 
+def get_counter(key):
+    """Process-wide event counters: "ks_graph_captures", "ks_graph_replays", "ks_eager"."""
+    v = C.c_uint64(0)
+    _check(lib.hexl_amd_get_counter(key.encode(), C.byref(v)))
+    return int(v.value)
+
+
 def set_tuning(key, value):
     """Tuning knobs (include/hexl_amd.h documents them): "fp64", "fp64_long", "lazy_family", "h60" (read when a
-    plan is created), "tile13", "bigtile", "host_bounce_kb", "host_pipeline_min_mb", "host_chunk_mb".
+    plan is created), "tile13", "bigtile", "host_bounce_kb".
     The library reads no environment variable; results never depend on the knobs."""
     _check(lib.hexl_amd_set_tuning(key.encode(), int(value)))
 

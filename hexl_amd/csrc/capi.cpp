@@ -95,7 +95,6 @@ struct Staging {
   void* buf = nullptr;
   size_t cap = 0;
   hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;  // second lane of the pipelined host path
   // Small calls on ordinary host memory: a pinned, device-mapped bounce buffer.  The caller's
   // words are copied into it on the host (a 32 KiB memcpy is ~1 us), the one-kernel transform
   // or element-wise kernel runs straight on it over the link, the result is copied out:
@@ -111,20 +110,17 @@ struct Staging {
   // errors are ignored all the same.
   ~Staging() {
     if (stream) (void)hipStreamSynchronize(stream);
-    if (stream2) (void)hipStreamSynchronize(stream2);
     // the composites' scratch keyed by these streams (KeySwitch through host pointers)
-    if (device >= 0 && (stream || stream2)) {
+    if (device >= 0 && stream) {
       int cur = -1;
       if (hipGetDevice(&cur) == hipSuccess && (cur == device || hipSetDevice(device) == hipSuccess)) {
         if (stream) release_stream_workspaces(stream);
-        if (stream2) release_stream_workspaces(stream2);
         if (cur != device && cur >= 0) (void)hipSetDevice(cur);
       }
     }
     if (buf) (void)hipFree(buf);
     if (bounce) (void)hipHostFree(bounce);
     if (stream) (void)hipStreamDestroy(stream);
-    if (stream2) (void)hipStreamDestroy(stream2);
   }
   // pinned + mapped host memory of at least `bytes` (any device may address it: portable)
   int ensure_bounce(size_t bytes) {
@@ -144,23 +140,18 @@ struct Staging {
       if (device >= 0 && (buf || stream)) {  // release what belongs to the previous device
         if (hipSetDevice(device) == hipSuccess) {
           if (stream) (void)hipStreamSynchronize(stream);
-          if (stream2) (void)hipStreamSynchronize(stream2);
-          if (stream) release_stream_workspaces(stream);
-          if (stream2) release_stream_workspaces(stream2);
-          if (buf) (void)hipFree(buf);
+                if (stream) release_stream_workspaces(stream);
+            if (buf) (void)hipFree(buf);
           if (stream) (void)hipStreamDestroy(stream);
-          if (stream2) (void)hipStreamDestroy(stream2);
-        }
+              }
         HX_HIP(hipSetDevice(dev));
       }
       buf = nullptr;
       cap = 0;
       stream = nullptr;
-      stream2 = nullptr;
       device = dev;
     }
     if (!stream) HX_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    if (!stream2) HX_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
     if (cap < bytes) {
       if (buf) HX_HIP(hipFree(buf));
       buf = nullptr;
@@ -276,6 +267,15 @@ int hexl_amd_host_register(void* p, uint64_t bytes) {
 }
 int hexl_amd_host_unregister(void* p) {
   if (!p) return HEXL_AMD_OK;
+  // Nothing may still be reading or writing the range when its device mapping goes away: the
+  // *_host entry points return only after their own work is done, but the caller may have handed
+  // the mapped alias to kernels or copies of its own on any stream of any device.
+  int ndev = 0, cur = -1;
+  if (hipGetDeviceCount(&ndev) == hipSuccess && hipGetDevice(&cur) == hipSuccess) {
+    for (int d = 0; d < ndev; ++d)
+      if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
+    (void)hipSetDevice(cur);
+  }
   HX_HIP(hipHostUnregister(p));
   return HEXL_AMD_OK;
 }
@@ -376,6 +376,31 @@ int hexl_amd_check_bounds(const uint64_t* data, uint64_t n, uint64_t bound,
   *violations = bad;
   return HEXL_AMD_OK;
 }
+
+}  // extern "C"
+
+// Plan tables go to the device through the calling thread's pinned bounce buffer, 1 MiB at a
+// time: the library never hands its own pageable memory to a large host-to-device copy (from
+// 1 MiB the runtime pins the source pages for the duration of the copy instead of staging them;
+// the round-4 suite aborts all sat in such copies, EXPERIMENTS.md sections 9 and 10).  One-off
+// cost per plan: a memcpy of the tables.
+static hipError_t upload_table(void* dst, const void* src, size_t bytes, int device) {
+  constexpr size_t kChunk = (size_t)1 << 20;
+  if (g_staging.ensure(device, 8) != HEXL_AMD_OK) return hipErrorOutOfMemory;
+  if (g_staging.ensure_bounce(bytes < kChunk ? bytes : kChunk) != HEXL_AMD_OK) return hipErrorOutOfMemory;
+  const size_t chunk = g_staging.bounce_cap < kChunk ? g_staging.bounce_cap : kChunk;
+  for (size_t off = 0; off < bytes; off += chunk) {
+    const size_t nb = bytes - off < chunk ? bytes - off : chunk;
+    memcpy(g_staging.bounce, (const char*)src + off, nb);
+    hipError_t e = hipMemcpyAsync((char*)dst + off, g_staging.bounce, nb, hipMemcpyHostToDevice,
+                                  g_staging.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_staging.stream);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+extern "C" {
 
 int hexl_amd_ntt_check_arguments(uint64_t degree, uint64_t modulus) {
   return nt::ntt_check_arguments(degree, modulus) ? 1 : 0;
@@ -490,8 +515,8 @@ int hexl_amd_ntt_create(hexl_amd_ntt** out, uint64_t degree, uint64_t modulus,
   hipError_t e = scope.err;
   if (e == hipSuccess) e = hipMalloc((void**)&p->d_fwd, n * entry);
   if (e == hipSuccess) e = hipMalloc((void**)&p->d_inv, n * entry);
-  if (e == hipSuccess) e = hipMemcpy(p->d_fwd, hf.data(), n * entry, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(p->d_inv, hi.data(), n * entry, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = upload_table(p->d_fwd, hf.data(), n * entry, device);
+  if (e == hipSuccess) e = upload_table(p->d_inv, hi.data(), n * entry, device);
   if (e != hipSuccess) {
     if (p->d_fwd) (void)hipFree(p->d_fwd);
     if (p->d_inv) (void)hipFree(p->d_inv);
@@ -820,36 +845,35 @@ int hexl_amd_ntt_inverse_rns(const hexl_amd_ntt* const* plans, uint64_t num_plan
 }
 
 // Host buffers (what an unmodified intel::hexl caller hands over): stage to the device,
-// transform, copy back.  Optionally (set_tuning "host_pipeline_min_mb") large calls are
-// cut into chunks that alternate between two streams, each with its own device staging
-// buffer, the caller's pages pinned for the duration of the call (hipHostRegister), so
-// that the H2D copy of chunk k+1 runs under the kernels and the D2H copy of chunk k.
-// Off by default: on the MI355X boxes of this pool the link moves 53 GB/s in one direction
+// transform, copy back.  On the MI355X boxes of this pool the link moves 53 GB/s in one direction
 // and 53 GB/s in both directions together, from pageable memory as fast as from pinned
-// (tools/pcie_probe.py), so the plain sequence below already runs at the link rate
-// (54-55 GB/s in+out, tools/host_path_rate.py) and pipelining gains nothing.
-// Knobs of the host path (hexl_amd_set_tuning; no environment variable is read).
-static std::atomic<size_t> g_host_pipeline_min_bytes{~(size_t)0};  // "host_pipeline_min_mb": off
-static std::atomic<size_t> g_host_chunk_bytes{(size_t)16 << 20};   // "host_chunk_mb"
-// Largest call (bytes of operand) that goes through the mapped bounce buffer: beyond it the
+// (tools/pcie_probe.py), so the plain sequence H2D, kernels, D2H runs at the link rate (54-55 GB/s
+// in + out); a two-stream chunked pipeline over caller pages pinned for the call was built in
+// round 2, measured equal and -- never on by default, never exercised -- removed in round 5.
+// Knob of the host path (hexl_amd_set_tuning; no environment variable is read):
+// largest call (bytes of operand) that goes through the mapped bounce buffer: beyond it the
 // host-side copies cost as much as the DMA they replace (measured: N = 65536, 512 KiB: 82 us
 // against 88 staged; N = 131072: 185 against 144; reading only the operand through the buffer:
 // 80 / 142).  "host_bounce_kb"; 0 switches the bounce path off.
 static std::atomic<size_t> g_host_bounce_max_bytes{(size_t)256 << 10};
-static size_t host_pipeline_min_bytes() { return g_host_pipeline_min_bytes.load(); }
-static size_t host_chunk_bytes() { return g_host_chunk_bytes.load(); }
 static size_t host_bounce_max_bytes() { return g_host_bounce_max_bytes.load(); }
+// "ks_graph": 1 (default) = a KeySwitch of at most kKsGraphMaxTargets targets whose buffers, keys
+// and moduli were seen before on the same stream is replayed from a captured HIP graph; 0 = the
+// launches are always enqueued one by one.
+static std::atomic<u32> g_ks_graph{1};
+constexpr int kKsGraphMaxTargets = 4;
+// hexl_amd_get_counter
+static std::atomic<u64> g_ks_graph_captures{0}, g_ks_graph_replays{0}, g_ks_eager{0};
 static bool set_host_tuning(const char* key, uint64_t value) {
   if (strcmp(key, "host_bounce_kb") == 0 && value <= (1u << 20)) {
     g_host_bounce_max_bytes = (size_t)value << 10;
-  } else if (strcmp(key, "host_pipeline_min_mb") == 0 && value <= (1u << 20)) {
-    g_host_pipeline_min_bytes = value ? (size_t)value << 20 : ~(size_t)0;
-  } else if (strcmp(key, "host_chunk_mb") == 0 && value >= 1 && value <= (1u << 14)) {
-    g_host_chunk_bytes = (size_t)value << 20;
-  } else {
-    return false;
+    return true;
   }
-  return true;
+  if (strcmp(key, "ks_graph") == 0 && value <= 1) {
+    g_ks_graph = (u32)value;
+    return true;
+  }
+  return false;
 }
 
 static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t* operand,
@@ -875,7 +899,7 @@ static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t*
       (const void*)result == (const void*)operand ? op_range : classify_range(result, bytes);
   void *op_dev = op_range.alias, *res_dev = res_range.alias;
   const int op_kind = op_range.kind, res_kind = res_range.kind;
-  if (op_kind == 2 && (bytes < host_pipeline_min_bytes() || batch < 4)) {
+  if (op_kind == 2) {
     if (int rc = g_staging.ensure(p->device, 8)) return rc;  // (the stream)
     hipStream_t st = g_staging.stream;
     auto launch = [&](u64* dst) {
@@ -910,49 +934,16 @@ static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t*
     memcpy(result, g_staging.bounce, bytes);
     return HEXL_AMD_OK;
   }
-  if (bytes < host_pipeline_min_bytes() || batch < 4) {
-    if (int rc = g_staging.ensure(p->device, bytes)) return rc;
-    u64* d = (u64*)g_staging.buf;
-    hipStream_t st = g_staging.stream;
-    // (hipMemcpyDefault: a mixed argument set -- device operand, host result -- lands here too)
-    HX_HIP(hipMemcpyAsync(d, operand, bytes, hipMemcpyDefault, st));
-    hipError_t e = run(d, batch, st);
-    if (e != hipSuccess) return hip_fail(e, "NTT launch");
-    HX_HIP(hipMemcpyAsync(result, d, bytes, hipMemcpyDefault, st));
-    HX_HIP(hipStreamSynchronize(st));
-    return HEXL_AMD_OK;
-  }
-  u64 chunk_polys = host_chunk_bytes() / poly_bytes;
-  if (chunk_polys == 0) chunk_polys = 1;
-  if (chunk_polys > (batch + 1) / 2) chunk_polys = (batch + 1) / 2;  // at least two chunks
-  const size_t chunk_bytes = (size_t)chunk_polys * poly_bytes;
-  if (int rc = g_staging.ensure(p->device, 2 * chunk_bytes)) return rc;
-  u64* dbuf[2] = {(u64*)g_staging.buf, (u64*)g_staging.buf + chunk_polys * p->n};
-  hipStream_t st[2] = {g_staging.stream, g_staging.stream2};
-  // pin the caller's pages so that the copies are asynchronous DMA
-  const bool pin_in = hipHostRegister((void*)operand, bytes, hipHostRegisterDefault) == hipSuccess;
-  const bool pin_out = (const void*)result == (const void*)operand
-                           ? false
-                           : hipHostRegister((void*)result, bytes, hipHostRegisterDefault) == hipSuccess;
-  if (!pin_in || (!pin_out && (const void*)result != (const void*)operand)) (void)hipGetLastError();
-  int rc = HEXL_AMD_OK;
-  for (u64 first = 0, k = 0; first < batch && rc == HEXL_AMD_OK; first += chunk_polys, ++k) {
-    const u64 polys = batch - first < chunk_polys ? batch - first : chunk_polys;
-    const size_t cb = (size_t)polys * poly_bytes;
-    const int lane = (int)(k & 1);
-    hipError_t e = hipMemcpyAsync(dbuf[lane], operand + first * p->n, cb, hipMemcpyHostToDevice,
-                                  st[lane]);
-    if (e == hipSuccess) e = run(dbuf[lane], polys, st[lane]);
-    if (e == hipSuccess)
-      e = hipMemcpyAsync(result + first * p->n, dbuf[lane], cb, hipMemcpyDeviceToHost, st[lane]);
-    if (e != hipSuccess) rc = hip_fail(e, "pipelined host NTT");
-  }
-  hipError_t e0 = hipStreamSynchronize(st[0]), e1 = hipStreamSynchronize(st[1]);
-  if (pin_in) (void)hipHostUnregister((void*)operand);
-  if (pin_out) (void)hipHostUnregister((void*)result);
-  if (rc == HEXL_AMD_OK && e0 != hipSuccess) rc = hip_fail(e0, "hipStreamSynchronize");
-  if (rc == HEXL_AMD_OK && e1 != hipSuccess) rc = hip_fail(e1, "hipStreamSynchronize");
-  return rc;
+  if (int rc = g_staging.ensure(p->device, bytes)) return rc;
+  u64* d = (u64*)g_staging.buf;
+  hipStream_t st = g_staging.stream;
+  // (hipMemcpyDefault: a mixed argument set -- device operand, host result -- lands here too)
+  HX_HIP(hipMemcpyAsync(d, operand, bytes, hipMemcpyDefault, st));
+  hipError_t e = run(d, batch, st);
+  if (e != hipSuccess) return hip_fail(e, "NTT launch");
+  HX_HIP(hipMemcpyAsync(result, d, bytes, hipMemcpyDefault, st));
+  HX_HIP(hipStreamSynchronize(st));
+  return HEXL_AMD_OK;
 }
 
 int hexl_amd_ntt_forward_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t* operand,
@@ -1357,101 +1348,169 @@ static int key_switch_device(u64* result, const u64* t_target_iter, u64 T, u64 n
   u64* prod = ntt_buf + T * D * D * n;
   u64* tbuf = prod + R * T * C * n;
   const KsDims dims{n, (u32)D, (u32)T, (u32)C, (u32)K};
-  hipError_t e;
+  // the launch sequence (no allocation, no synchronisation: capturable)
+  auto enqueue = [&]() -> int {
+    hipError_t e;
 
-  // key-switch-internal.cpp:38-56: coefficient form of the targets per decomposition modulus
-  {
-    MultiMap map{};
-    map.inner = 1;
-    map.period = (u32)D;
-    for (u64 j = 0; j < D; ++j) map.plan_tab[j] = (uint8_t)j;
-    if (int rc = ntt_mapped(false, plan, map, T * D, t_target, t_target_iter, n, 1, st)) return rc;
-  }
-
-  // :61-131 per RNS index i: operands to the key modulus, lazy forward NTT, MAC, reduce
-  KsGatherAll g{};
-  KsMacAll m{};
-  for (u64 j = 0; j < D; ++j) m.keys[j] = keys[j];
-  for (u64 i = 0; i < R; ++i) {
-    const u64 key_index = (i == D) ? K - 1 : i;
-    const u64 q = moduli[key_index];
-    g.q[i] = m.q[i] = q;
-    g.barrett[i] = m.barrett[i] = floor_2_64_over(q);
-    for (u64 j = 0; j < D; ++j)
-      if (j != i && moduli[j] > q) g.reduce_mask[i] |= 1u << j;
-    m.key_index[i] = (u32)key_index;
-    m.two64_mod_q[i] = (u64)((((unsigned __int128)1) << 64) % q);
-    const u32 ceil_log = 64 - __builtin_clzll(q);
-    m.shift[i] = ceil_log - 2;
-    m.mu[i] = (u64)((((unsigned __int128)(1ull << (ceil_log + 62 - 64))) << 64) / q);
-  }
-  {
-    // The D^2 product operands of a target, ordered by RNS index i: target polynomial j
-    // (coefficient form) reduced to q_i where moduli[j] is larger, for every j != i (i < D)
-    // or every j (i == D).  The first pass of their forward transform reads them straight
-    // from t_target through the source map (MultiMap); only where the multi-plan launch
-    // does not apply (small degrees) are they gathered into ntt_buf first.
-    MultiMap map{};
-    map.inner = 1;
-    map.period = (u32)(D * D);
-    map.src_stride = (u32)D;
-    for (u64 s = 0; s < D * D; ++s) {
-      const u64 i = s < D * (D - 1) ? s / (D - 1) : D;
-      const u64 r = s - i * (D - 1);
-      const u64 j = i < D ? (r < i ? r : r + 1) : s - D * (D - 1);
-      map.plan_tab[s] = (uint8_t)i;
-      map.src_tab[s] = (uint8_t)(j | (((g.reduce_mask[i] >> j) & 1) ? 0x80 : 0));
+    // key-switch-internal.cpp:38-56: coefficient form of the targets per decomposition modulus
+    {
+      MultiMap map{};
+      map.inner = 1;
+      map.period = (u32)D;
+      for (u64 j = 0; j < D; ++j) map.plan_tab[j] = (uint8_t)j;
+      if (int rc = ntt_mapped(false, plan, map, T * D, t_target, t_target_iter, n, 1, st)) return rc;
     }
-    std::vector<const NttTables*> tabs(plan.size());
-    for (size_t k = 0; k < plan.size(); ++k) tabs[k] = &plan[k]->t;
-    e = ntt_multi_launch(true, tabs.data(), (u32)tabs.size(), map, T * D * D, ntt_buf, t_target,
-                         4, st);
-    if (e == hipErrorNotSupported) {
-      e = ks_gather_launch(ntt_buf, t_target, dims, g, st);
-      if (e != hipSuccess) return hip_fail(e, "KeySwitch gather");
-      map.src_stride = 0;
-      if (int rc = ntt_mapped(true, plan, map, T * D * D, ntt_buf, ntt_buf, n, 4, st)) return rc;
-    } else if (e != hipSuccess) {
-      return hip_fail(e, "KeySwitch multi-plan NTT");
-    }
-  }
-  e = ks_mac_launch(prod, t_target_iter, ntt_buf, dims, m, st);
-  if (e != hipSuccess) return hip_fail(e, "KeySwitch multiply-accumulate");
 
-  // :134-197 modulus switching from the special prime, all (target, key component) at once
-  const u64 qk = moduli[K - 1];
-  KsRound rd{};
-  KsFinish fin{};
-  rd.qk = qk;
-  rd.barrett_k = floor_2_64_over(qk);
-  rd.qk_half = qk >> 1;
-  for (u64 i = 0; i < D; ++i) {
-    const u64 qi = moduli[i];
-    const u64 bf = floor_2_64_over(qi);
-    u64 h = rd.qk_half - (u64)(((unsigned __int128)rd.qk_half * bf) >> 64) * qi;  // BarrettReduce64
-    if (h >= qi) h -= qi;
-    rd.mod[i] = KsRoundMod{qi, bf, qi - h, qk > qi ? 1u : 0u};
-    u64 s = msf[i];  // FMAMod reduces its scalar from [0, 8q) (eltwise-fma-mod.cpp:60-64)
-    if (s >= 4 * qi) s -= 4 * qi;
-    if (s >= 2 * qi) s -= 2 * qi;
-    if (s >= qi) s -= qi;
-    fin.mod[i] = KsFinishMod{qi, s, (u64)((((unsigned __int128)s) << 64) / qi)};
+    // :61-131 per RNS index i: operands to the key modulus, lazy forward NTT, MAC, reduce
+    KsGatherAll g{};
+    KsMacAll m{};
+    for (u64 j = 0; j < D; ++j) m.keys[j] = keys[j];
+    for (u64 i = 0; i < R; ++i) {
+      const u64 key_index = (i == D) ? K - 1 : i;
+      const u64 q = moduli[key_index];
+      g.q[i] = m.q[i] = q;
+      g.barrett[i] = m.barrett[i] = floor_2_64_over(q);
+      for (u64 j = 0; j < D; ++j)
+        if (j != i && moduli[j] > q) g.reduce_mask[i] |= 1u << j;
+      m.key_index[i] = (u32)key_index;
+      m.two64_mod_q[i] = (u64)((((unsigned __int128)1) << 64) % q);
+      const u32 ceil_log = 64 - __builtin_clzll(q);
+      m.shift[i] = ceil_log - 2;
+      m.mu[i] = (u64)((((unsigned __int128)(1ull << (ceil_log + 62 - 64))) << 64) / q);
+    }
+    {
+      // The D^2 product operands of a target, ordered by RNS index i: target polynomial j
+      // (coefficient form) reduced to q_i where moduli[j] is larger, for every j != i (i < D)
+      // or every j (i == D).  The first pass of their forward transform reads them straight
+      // from t_target through the source map (MultiMap); only where the multi-plan launch
+      // does not apply (small degrees) are they gathered into ntt_buf first.
+      MultiMap map{};
+      map.inner = 1;
+      map.period = (u32)(D * D);
+      map.src_stride = (u32)D;
+      for (u64 s = 0; s < D * D; ++s) {
+        const u64 i = s < D * (D - 1) ? s / (D - 1) : D;
+        const u64 r = s - i * (D - 1);
+        const u64 j = i < D ? (r < i ? r : r + 1) : s - D * (D - 1);
+        map.plan_tab[s] = (uint8_t)i;
+        map.src_tab[s] = (uint8_t)(j | (((g.reduce_mask[i] >> j) & 1) ? 0x80 : 0));
+      }
+      std::vector<const NttTables*> tabs(plan.size());
+      for (size_t k = 0; k < plan.size(); ++k) tabs[k] = &plan[k]->t;
+      e = ntt_multi_launch(true, tabs.data(), (u32)tabs.size(), map, T * D * D, ntt_buf, t_target,
+                           4, st);
+      if (e == hipErrorNotSupported) {
+        e = ks_gather_launch(ntt_buf, t_target, dims, g, st);
+        if (e != hipSuccess) return hip_fail(e, "KeySwitch gather");
+        map.src_stride = 0;
+        if (int rc = ntt_mapped(true, plan, map, T * D * D, ntt_buf, ntt_buf, n, 4, st)) return rc;
+      } else if (e != hipSuccess) {
+        return hip_fail(e, "KeySwitch multi-plan NTT");
+      }
+    }
+    e = ks_mac_launch(prod, t_target_iter, ntt_buf, dims, m, st);
+    if (e != hipSuccess) return hip_fail(e, "KeySwitch multiply-accumulate");
+
+    // :134-197 modulus switching from the special prime, all (target, key component) at once
+    const u64 qk = moduli[K - 1];
+    KsRound rd{};
+    KsFinish fin{};
+    rd.qk = qk;
+    rd.barrett_k = floor_2_64_over(qk);
+    rd.qk_half = qk >> 1;
+    for (u64 i = 0; i < D; ++i) {
+      const u64 qi = moduli[i];
+      const u64 bf = floor_2_64_over(qi);
+      u64 h = rd.qk_half - (u64)(((unsigned __int128)rd.qk_half * bf) >> 64) * qi;  // BarrettReduce64
+      if (h >= qi) h -= qi;
+      rd.mod[i] = KsRoundMod{qi, bf, qi - h, qk > qi ? 1u : 0u};
+      u64 s = msf[i];  // FMAMod reduces its scalar from [0, 8q) (eltwise-fma-mod.cpp:60-64)
+      if (s >= 4 * qi) s -= 4 * qi;
+      if (s >= 2 * qi) s -= 2 * qi;
+      if (s >= qi) s -= qi;
+      fin.mod[i] = KsFinishMod{qi, s, (u64)((((unsigned __int128)s) << 64) / qi)};
+    }
+    u64* t_last = prod + D * T * C * n;  // prod[D][.][.]: T C contiguous polynomials
+    e = ntt_inverse_launch(plan[D]->t, t_last, t_last, T * C, 2, st);
+    if (e != hipSuccess) return hip_fail(e, "KeySwitch inverse NTT (last)");
+    e = ks_round_launch(tbuf, prod, dims, rd, st);
+    if (e != hipSuccess) return hip_fail(e, "KeySwitch rounding");
+    {
+      MultiMap map{};
+      map.inner = 1;
+      map.period = (u32)D;
+      for (u64 i = 0; i < D; ++i) map.plan_tab[i] = (uint8_t)i;
+      if (int rc = ntt_mapped(true, plan, map, T * C * D, tbuf, tbuf, n, 4, st)) return rc;
+    }
+    e = ks_finish_launch(result, prod, tbuf, dims, fin, st);
+    if (e != hipSuccess) return hip_fail(e, "KeySwitch finish");
+    return HEXL_AMD_OK;
+  };
+
+  // One ciphertext per call -- what a caller of the reference's KeySwitch does
+  // (key-switch-internal.cpp:25-201 is one target) -- is launch-bound: ~6 us of transform work
+  // behind eleven dependent launches.  A sequence that comes back with the very same buffers,
+  // keys and moduli on the same stream is captured once into a HIP graph and replayed from then
+  // on (workspace.h; hexl_amd_key_switch_host always qualifies: it stages into the thread's own
+  // buffers).  First sight of a buffer set runs eagerly, so a caller that walks over different
+  // ciphertexts never pays a capture.
+  bool replayable = T <= (u64)kKsGraphMaxTargets && g_ks_graph.load() != 0 && g_profile == nullptr &&
+                    st != nullptr && st != hipStreamLegacy && st != hipStreamPerThread;
+  if (replayable) {
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &capturing) != hipSuccess) (void)hipGetLastError();
+    replayable = capturing == hipStreamCaptureStatusNone;  // (inside a caller's own capture: eager)
   }
-  u64* t_last = prod + D * T * C * n;  // prod[D][.][.]: T C contiguous polynomials
-  e = ntt_inverse_launch(plan[D]->t, t_last, t_last, T * C, 2, st);
-  if (e != hipSuccess) return hip_fail(e, "KeySwitch inverse NTT (last)");
-  e = ks_round_launch(tbuf, prod, dims, rd, st);
-  if (e != hipSuccess) return hip_fail(e, "KeySwitch rounding");
-  {
-    MultiMap map{};
-    map.inner = 1;
-    map.period = (u32)D;
-    for (u64 i = 0; i < D; ++i) map.plan_tab[i] = (uint8_t)i;
-    if (int rc = ntt_mapped(true, plan, map, T * C * D, tbuf, tbuf, n, 4, st)) return rc;
+  if (!replayable) {
+    g_ks_eager.fetch_add(1, std::memory_order_relaxed);
+    return enqueue();
   }
-  e = ks_finish_launch(result, prod, tbuf, dims, fin, st);
-  if (e != hipSuccess) return hip_fail(e, "KeySwitch finish");
-  return HEXL_AMD_OK;
+  std::vector<uint64_t> key;
+  key.reserve(10 + K + 2 * D);
+  for (u64 v : {(u64)(uintptr_t)result, (u64)(uintptr_t)t_target_iter, (u64)(uintptr_t)ws, T, n, D, K, R, C})
+    key.push_back(v);
+  for (u64 i = 0; i < K; ++i) key.push_back(moduli[i]);
+  for (u64 i = 0; i < D; ++i) key.push_back(msf[i]);
+  for (u64 j = 0; j < D; ++j) key.push_back((u64)(uintptr_t)keys[j]);
+  hipGraphExec_t exec = nullptr;
+  switch (lookup_sequence_graph(st, key, &exec)) {
+    case kGraphReplay:
+      if (hipGraphLaunch(exec, st) == hipSuccess) {
+        g_ks_graph_replays.fetch_add(1, std::memory_order_relaxed);
+        return HEXL_AMD_OK;
+      }
+      (void)hipGetLastError();
+      poison_sequence_graph(st, key);
+      return enqueue();
+    case kGraphCapture: {
+      if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        poison_sequence_graph(st, key);
+        return enqueue();
+      }
+      const int rc = enqueue();
+      hipGraph_t graph = nullptr;
+      hipError_t ec = hipStreamEndCapture(st, &graph);
+      if (rc == HEXL_AMD_OK && ec == hipSuccess && graph)
+        ec = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      else if (ec == hipSuccess)
+        ec = hipErrorUnknown;
+      if (graph) (void)hipGraphDestroy(graph);
+      if (ec == hipSuccess) ec = hipGraphLaunch(exec, st);
+      if (ec != hipSuccess) {  // nothing was enqueued: run the sequence as it is (and report its error)
+        (void)hipGetLastError();
+        if (exec) (void)hipGraphExecDestroy(exec);
+        poison_sequence_graph(st, key);
+        return enqueue();
+      }
+      store_sequence_graph(st, key, exec);
+      g_ks_graph_captures.fetch_add(1, std::memory_order_relaxed);
+      return HEXL_AMD_OK;
+    }
+    default:
+      g_ks_eager.fetch_add(1, std::memory_order_relaxed);
+      return enqueue();
+  }
 }
 
 int hexl_amd_key_switch(uint64_t* result, const uint64_t* t_target_iter_ptr, uint64_t n,
@@ -1627,6 +1686,19 @@ int hexl_amd_release_workspaces(void) {
     return fail(HEXL_AMD_ERR_INVALID_ARG,
                 "%d scratch buffer(s) not released: a composite call was enqueueing on their "
                 "stream", busy);
+  return HEXL_AMD_OK;
+}
+
+int hexl_amd_get_counter(const char* key, uint64_t* value) {
+  if (!key || !value) return fail(HEXL_AMD_ERR_INVALID_ARG, "key == nullptr or value == nullptr");
+  if (strcmp(key, "ks_graph_captures") == 0)
+    *value = g_ks_graph_captures.load();
+  else if (strcmp(key, "ks_graph_replays") == 0)
+    *value = g_ks_graph_replays.load();
+  else if (strcmp(key, "ks_eager") == 0)
+    *value = g_ks_eager.load();
+  else
+    return fail(HEXL_AMD_ERR_INVALID_ARG, "unknown counter: %s", key);
   return HEXL_AMD_OK;
 }
 

@@ -30,6 +30,44 @@ std::map<std::pair<int, hipStream_t>, std::shared_ptr<SeqMutex>>& sequence_table
   static auto* t = new std::map<std::pair<int, hipStream_t>, std::shared_ptr<SeqMutex>>;
   return *t;
 }
+// Replay cache (workspace.h).  Entries of one (device, stream) are only touched under that
+// stream's sequence lock; g_mu covers the outer map.
+struct GraphEntry {
+  std::vector<uint64_t> key;
+  hipGraphExec_t exec = nullptr;
+  bool poisoned = false;
+  uint64_t last_use = 0;
+};
+struct GraphSet {
+  std::vector<GraphEntry> entries;
+  uint64_t clock = 0;
+};
+std::map<std::pair<int, hipStream_t>, GraphSet>& graph_table() {
+  static auto* t = new std::map<std::pair<int, hipStream_t>, GraphSet>;
+  return *t;
+}
+GraphSet* graph_set(int device, hipStream_t stream, bool create) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto& tab = graph_table();
+  auto it = tab.find(std::make_pair(device, stream));
+  if (it != tab.end()) return &it->second;  // node addresses are stable
+  if (!create) return nullptr;
+  return &tab[std::make_pair(device, stream)];
+}
+// Under the stream's sequence lock.  The graphs may still be executing: wait for the stream.
+void drop_graphs(int device, hipStream_t stream) {
+  GraphSet* gs = graph_set(device, stream, false);
+  if (!gs) return;
+  bool waited = false;
+  for (auto& en : gs->entries)
+    if (en.exec) {
+      if (!waited) (void)hipStreamSynchronize(stream);
+      waited = true;
+      (void)hipGraphExecDestroy(en.exec);
+    }
+  gs->entries.clear();
+}
+
 std::shared_ptr<SeqMutex> sequence_mutex(int device, hipStream_t stream) {
   std::lock_guard<std::mutex> lock(g_mu);
   auto& slot = sequence_table()[std::make_pair(device, stream)];
@@ -70,6 +108,8 @@ hipError_t stream_workspace(WorkspacePurpose purpose, hipStream_t stream, size_t
   if (en->cap < bytes) {
     // (hipFree / hipMalloc are illegal under stream capture: the first call of a size class
     // must happen outside a capture, as tools/graph_replay.py does with its warm-up call)
+    // captured sequences hold the old buffer's address
+    drop_graphs(device, stream);
     if (en->ptr) {
       // hipFree waits for the device, so no kernel still reads the old buffer
       e = hipFree(en->ptr);
@@ -89,13 +129,77 @@ hipError_t stream_workspace(WorkspacePurpose purpose, hipStream_t stream, size_t
   return hipSuccess;
 }
 
+SequenceGraphAction lookup_sequence_graph(hipStream_t stream, const std::vector<uint64_t>& key,
+                                          hipGraphExec_t* exec) {
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return kGraphEager;
+  GraphSet* gs = graph_set(device, stream, true);
+  ++gs->clock;
+  for (auto& en : gs->entries)
+    if (en.key == key) {
+      en.last_use = gs->clock;
+      if (en.poisoned) return kGraphEager;
+      if (en.exec) {
+        *exec = en.exec;
+        return kGraphReplay;
+      }
+      return kGraphCapture;  // second sight
+    }
+  // first sight: remember the key, evicting the least recently used one
+  if ((int)gs->entries.size() >= kMaxSequenceGraphs) {
+    size_t victim = 0;
+    for (size_t i = 1; i < gs->entries.size(); ++i)
+      if (gs->entries[i].last_use < gs->entries[victim].last_use) victim = i;
+    if (gs->entries[victim].exec) {
+      (void)hipStreamSynchronize(stream);  // it may still be executing
+      (void)hipGraphExecDestroy(gs->entries[victim].exec);
+    }
+    gs->entries.erase(gs->entries.begin() + (long)victim);
+  }
+  GraphEntry en;
+  en.key = key;
+  en.last_use = gs->clock;
+  gs->entries.push_back(std::move(en));
+  return kGraphEager;
+}
+
+void store_sequence_graph(hipStream_t stream, const std::vector<uint64_t>& key, hipGraphExec_t exec) {
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return;
+  GraphSet* gs = graph_set(device, stream, true);
+  for (auto& en : gs->entries)
+    if (en.key == key) {
+      if (en.exec && en.exec != exec) (void)hipGraphExecDestroy(en.exec);
+      en.exec = exec;
+      return;
+    }
+  (void)hipGraphExecDestroy(exec);  // the key was evicted meanwhile
+}
+
+void poison_sequence_graph(hipStream_t stream, const std::vector<uint64_t>& key) {
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return;
+  GraphSet* gs = graph_set(device, stream, true);
+  for (auto& en : gs->entries)
+    if (en.key == key) {
+      if (en.exec) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipGraphExecDestroy(en.exec);
+      }
+      en.exec = nullptr;
+      en.poisoned = true;
+    }
+}
+
 void release_stream_workspaces(hipStream_t stream) {
   int device = 0;
   if (hipGetDevice(&device) != hipSuccess) return;
   std::vector<void*> victims;
   {
     StreamSequenceLock sequence(stream);  // nobody is enqueueing against the buffers
+    drop_graphs(device, stream);
     std::lock_guard<std::mutex> lock(g_mu);
+    graph_table().erase(std::make_pair(device, stream));
     for (auto it = table().begin(); it != table().end();) {
       if (std::get<0>(it->first) == device && std::get<1>(it->first) == stream) {
         if (it->second.ptr) victims.push_back(it->second.ptr);
@@ -132,7 +236,15 @@ int release_workspaces() {
       continue;
     }
     {
+      int cur = 0;
+      (void)hipGetDevice(&cur);
+      if (cur != std::get<0>(key)) (void)hipSetDevice(std::get<0>(key));
+      drop_graphs(std::get<0>(key), std::get<1>(key));
+      if (cur != std::get<0>(key)) (void)hipSetDevice(cur);
+    }
+    {
       std::lock_guard<std::mutex> lock(g_mu);
+      graph_table().erase(std::make_pair(std::get<0>(key), std::get<1>(key)));
       auto it = table().find(key);
       if (it != table().end()) {
         if (it->second.ptr) victims.emplace_back(std::get<0>(key), it->second.ptr);

@@ -8,6 +8,9 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <stddef.h>
+#include <stdint.h>
+
+#include <vector>
 
 namespace hexl_amd {
 
@@ -40,6 +43,28 @@ class StreamSequenceLock {
   struct Held;
   Held* held_;
 };
+
+// Replay cache for launch sequences enqueued against a stream's scratch (KeySwitch, one
+// ciphertext per call: at most eleven dependent launches of a few microseconds each, where the
+// host-side launch overhead is most of the call).  A sequence is identified by EVERYTHING its
+// launches depend on -- every pointer, size and per-modulus constant, the scratch address --
+// as a vector of words compared exactly (no digest, no collisions).  Protocol, under the
+// stream's StreamSequenceLock:
+//   lookup_sequence_graph(...)  -> kGraphReplay: *exec is an instantiated graph of the sequence
+//                                  (hipGraphLaunch it);
+//                               -> kGraphCapture: the key was seen before: capture the sequence
+//                                  now and hand the instantiated graph to store_sequence_graph;
+//                               -> kGraphEager: first sight of the key (a caller that walks over
+//                                  different buffers never pays a capture): enqueue eagerly.
+// At most kMaxSequenceGraphs keys per (device, stream), least recently used evicted; all graphs of
+// a stream go when its scratch is regrown or released.
+enum SequenceGraphAction : int { kGraphEager = 0, kGraphCapture = 1, kGraphReplay = 2 };
+constexpr int kMaxSequenceGraphs = 8;
+SequenceGraphAction lookup_sequence_graph(hipStream_t stream, const std::vector<uint64_t>& key,
+                                          hipGraphExec_t* exec);
+void store_sequence_graph(hipStream_t stream, const std::vector<uint64_t>& key, hipGraphExec_t exec);
+// the key could not be captured (or replay failed): stays eager for the life of the entry
+void poison_sequence_graph(hipStream_t stream, const std::vector<uint64_t>& key);
 
 // Frees every cached buffer of the current process (all devices), each under its stream's
 // sequence lock.  Returns the number of buffers left alone because another thread was

@@ -366,7 +366,13 @@ int hexl_amd_dyadic_multiply_host(uint64_t* result, const uint64_t* operand1,
  * Scratch: the intermediates live in a device buffer keyed by (device, stream).
  * Calls on one stream reuse it in stream order -- from several host threads too: a
  * call's launches are enqueued under a per-stream lock; calls on different streams
- * get different buffers and may overlap on the device. */
+ * get different buffers and may overlap on the device.
+ * Replay: a call on a stream of its own (not NULL) that comes back with the same result,
+ * target and key buffers, sizes, moduli and factors as an earlier one is captured into a HIP
+ * graph at its second sight and replayed from the third (tuning key "ks_graph"; up to eight
+ * buffer sets per stream, least recently used evicted) -- the DATA in the buffers is read at
+ * execution time, only the addresses are fixed.  Callers that walk over different buffers run
+ * launch by launch, as do calls made while the caller itself is capturing the stream. */
 int hexl_amd_key_switch(uint64_t* result, const uint64_t* t_target_iter_ptr,
                         uint64_t n, uint64_t decomp_modulus_size,
                         uint64_t key_modulus_size, uint64_t rns_modulus_size,
@@ -470,11 +476,18 @@ int hexl_amd_profile_get(int i, const char** name, float* ms);
  *   "host_bounce_kb"   largest host-pointer call (KiB of operand) that runs on the per-thread
  *                      pinned, device-mapped bounce buffer instead of staged copies (default 256;
  *                      0 = never)
- *   "host_pipeline_min_mb"  host-pointer calls of at least this size are cut into chunks that
- *                      alternate between two streams (default 0 = off: on this pool the link
- *                      moves as much in one direction as in both)
- *   "host_chunk_mb"    chunk size of that pipeline (default 16) */
+ *   "ks_graph"         1 (default) = hexl_amd_key_switch / _host / _batch calls of at most four
+ *                      targets whose buffers, keys and moduli were seen before on the same stream
+ *                      are replayed from a HIP graph captured at their second sight (one graph
+ *                      launch instead of up to eleven kernel launches); 0 = always launch by launch
+ *   (the round-2 keys "host_pipeline_min_mb" / "host_chunk_mb" went with the chunked two-stream
+ *   host pipeline they switched on: measured equal to the plain sequence, removed in round 5) */
 int hexl_amd_set_tuning(const char* key, uint64_t value);
+/* Process-wide event counters (monotonic; for tests and the bench line, which must be able to
+ * tell a replayed KeySwitch from a launch-by-launch one): "ks_graph_captures" (sequences
+ * captured and instantiated), "ks_graph_replays" (calls served by a graph launch), "ks_eager"
+ * (calls enqueued launch by launch).  Unknown keys return HEXL_AMD_ERR_INVALID_ARG. */
+int hexl_amd_get_counter(const char* key, uint64_t* value);
 
 /* Device scratch of the composite entry points (KeySwitch, the experimental one-launch
  * transform) is cached per (device, stream) and grows on demand.  _release_stream_workspaces

@@ -78,6 +78,9 @@ def fake_torch():
         def wait_stream(self, other):
             pass
 
+        def synchronize(self):
+            pass
+
     class CUDAGraph:
         def replay(self):
             pass
@@ -133,10 +136,17 @@ def fake_hexl_amd(real, fail_composites=False):
     for name in ("DyadicMultiply", "DyadicMultiplyBatch", "KeySwitch", "KeySwitchBatch"):
         setattr(hx, name, composites_op)
     hx.GeneratePrimes = real.GeneratePrimes
+    counters = {"ks_graph_replays": 0}
+
+    def get_counter(key):
+        counters[key] = counters.get(key, 0) + 17  # (every look: 17 more)
+        return counters[key]
+    hx.get_counter = get_counter
+    hx.set_tuning = lambda key, value: None
     hx.from_numpy = lambda a, device="cuda": FakeTensor(a.shape)
     hx.lib = types.SimpleNamespace(
         hexl_amd_ntt_forward_host=lambda *a: 0, hexl_amd_host_alloc=lambda *a: 1,  # (no mapped memory here)
-        hexl_amd_host_free=lambda *a: 0)
+        hexl_amd_host_free=lambda *a: 0, hexl_amd_release_stream_workspaces=lambda *a: 0)
     return hx
 
 
@@ -154,6 +164,7 @@ def run_main(monkeypatch, capfd, argv, fail_composites=False):
     monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
     monkeypatch.setattr(bench, "PREWARM", 1)
     monkeypatch.setattr(bench, "MULTI_DEVICE_BIN", "/nonexistent")  # (needs a GPU)
+    monkeypatch.setattr(bench, "HOST_CALL_BUDGET_BIN", "/nonexistent")  # (needs a GPU)
     monkeypatch.setenv("BENCH_SUSTAINED_S", "0.05")
     # the CPU legs are real but bounded: a fraction of a second each
     monkeypatch.setattr(bench, "cpu_baseline", lambda: bench.__dict__["_cpu_baseline_real"](0.2, 0.2))
@@ -202,6 +213,14 @@ def test_default_line_has_the_contract_and_the_round_4_blocks(monkeypatch, capfd
     assert line["sustained"]["steps"] >= 64 and line["sustained"]["ms_per_step_median"] == 3.3
     assert set(k for k in line["host_path"] if k.startswith("N=")) == {"N=4096", "N=16384", "N=65536"}
     assert line["host_path"]["N=4096"]["cpu_baseline_one_thread"]["us_per_call"] > 0
+    assert "ctypes" in line["host_path"]["measured_through"]
+    ks = line["composites"]["key_switch"]
+    for key in ("one_target_per_call_us", "one_target_per_call_eager_us", "one_target_per_call_path",
+                "ntt_floor_us", "hbm_floor_us", "one_target_frac_of_ntt_floor",
+                "256_targets_frac_of_ntt_floor", "256_targets_frac_of_hbm_peak", "transforms_per_target"):
+        assert key in ks, key
+    # n = 16384, D = 7, C = 2: 7 + 2 inverse and 49 + 14 forward transforms per target
+    assert ks["transforms_per_target"]["forward"] == 63 and ks["transforms_per_target"]["inverse"] == 9
     assert "graph_of_32" in line["secondary"]["config2"]
     assert set(line["secondary"]["headline_shape_other_moduli"]) >= {
         "57-bit prime (Lazy32 policy)", "59-bit prime (Lazy16 policy)", "60-bit prime (Harvey60 policy)"}

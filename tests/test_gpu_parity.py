@@ -1326,6 +1326,159 @@ def test_key_switch_batch_vs_oracle(hx, ho, n, D, K, C, T, bits):
     assert np.array_equal(host(hx, d_res), want)
 
 
+def _ks_case(ho, rng, n, D, K, C, bits):
+    moduli = [int(q) for q in ho.generate_primes(K, bits, True, n)]
+    keys = [np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                            for _ in range(C) for i in range(K)]) for _ in range(D)]
+    msf = [int(rng.integers(1, moduli[i], dtype=np.uint64)) for i in range(D)]
+    return moduli, keys, msf
+
+
+def _ks_data(rng, moduli, n, D, C):
+    target = np.concatenate([rng.integers(0, moduli[j], n, dtype=np.uint64) for j in range(D)])
+    result = np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                             for _ in range(C) for i in range(D)])
+    return target, result
+
+
+@pytest.mark.parametrize("n,D,K,C,bits", [(4096, 3, 4, 2, 50), (16384, 7, 8, 2, 54), (1024, 1, 2, 2, 40)])
+def test_key_switch_replayed_from_a_graph(hx, ho, n, D, K, C, bits):
+    """One ciphertext per call on a stream of the caller's, the same buffers coming back with new
+    DATA each time: eager at first sight, captured at the second, replayed from the third
+    (hexl_amd_get_counter says so) -- every call bit-exact against the oracle; two buffer sets
+    interleaved; with "ks_graph" 0 the same calls run launch by launch."""
+    import torch
+    rng = np.random.default_rng(n + 31 * D)
+    moduli, keys, msf = _ks_case(ho, rng, n, D, K, C, bits)
+    d_keys = [dev(hx, k) for k in keys]
+    stream = torch.cuda.Stream()
+    sets = []
+    for _ in range(2):
+        t, r = _ks_data(rng, moduli, n, D, C)
+        sets.append((dev(hx, t), dev(hx, r)))
+    torch.cuda.synchronize()
+    c0 = {k: hx.get_counter(k) for k in ("ks_graph_captures", "ks_graph_replays", "ks_eager")}
+    for rep in range(5):
+        for d_t, d_r in sets:
+            t, r = _ks_data(rng, moduli, n, D, C)
+            want = ho.key_switch(r, t, n, D, K, D + 1, C, moduli, keys, msf)
+            d_t.copy_(dev(hx, t))
+            d_r.copy_(dev(hx, r))
+            torch.cuda.synchronize()
+            with torch.cuda.stream(stream):
+                hx.KeySwitch(d_r, d_t, n, D, K, D + 1, C, moduli, d_keys, msf)
+            stream.synchronize()
+            assert np.array_equal(host(hx, d_r), want), rep
+    c1 = {k: hx.get_counter(k) for k in c0}
+    assert c1["ks_eager"] - c0["ks_eager"] == 2          # first sight of each buffer set
+    assert c1["ks_graph_captures"] - c0["ks_graph_captures"] == 2
+    assert c1["ks_graph_replays"] - c0["ks_graph_replays"] == 6
+    hx.set_tuning("ks_graph", 0)
+    try:
+        d_t, d_r = sets[0]
+        t, r = _ks_data(rng, moduli, n, D, C)
+        d_t.copy_(dev(hx, t))
+        d_r.copy_(dev(hx, r))
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            hx.KeySwitch(d_r, d_t, n, D, K, D + 1, C, moduli, d_keys, msf)
+        stream.synchronize()
+        assert np.array_equal(host(hx, d_r), ho.key_switch(r, t, n, D, K, D + 1, C, moduli, keys, msf))
+        assert hx.get_counter("ks_graph_replays") == c1["ks_graph_replays"]
+    finally:
+        hx.set_tuning("ks_graph", 1)
+    # the graphs hold the scratch address: releasing the scratch drops them, the next calls start over
+    assert hx.lib.hexl_amd_release_stream_workspaces(stream.cuda_stream) == 0
+    for rep in range(3):
+        d_t, d_r = sets[1]
+        t, r = _ks_data(rng, moduli, n, D, C)
+        d_t.copy_(dev(hx, t))
+        d_r.copy_(dev(hx, r))
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            hx.KeySwitch(d_r, d_t, n, D, K, D + 1, C, moduli, d_keys, msf)
+        stream.synchronize()
+        assert np.array_equal(host(hx, d_r), ho.key_switch(r, t, n, D, K, D + 1, C, moduli, keys, msf))
+    assert hx.get_counter("ks_graph_captures") == c1["ks_graph_captures"] + 1
+    assert hx.lib.hexl_amd_release_stream_workspaces(stream.cuda_stream) == 0
+
+
+def test_key_switch_replay_cache_evicts_and_tells_parameter_sets_apart(hx, ho):
+    """More buffer sets than the cache holds (eight per stream), each seen three times in a
+    round-robin -- least recently used entries go, nothing is ever replayed for the wrong buffers;
+    then the same buffers with another modulus-switch factor (a different sequence: the factor is
+    a kernel argument) -- and a caller that is itself capturing the stream gets plain launches."""
+    import torch
+    n, D, K, C = 2048, 2, 3, 2
+    rng = np.random.default_rng(99)
+    moduli, keys, msf = _ks_case(ho, rng, n, D, K, C, 45)
+    d_keys = [dev(hx, k) for k in keys]
+    stream = torch.cuda.Stream()
+    sets = []
+    for _ in range(10):
+        t, r = _ks_data(rng, moduli, n, D, C)
+        sets.append((t, r, dev(hx, t), dev(hx, r)))
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for t, r, d_t, d_r in sets:
+            d_r.copy_(dev(hx, r))
+            torch.cuda.synchronize()
+            with torch.cuda.stream(stream):
+                hx.KeySwitch(d_r, d_t, n, D, K, D + 1, C, moduli, d_keys, msf)
+            stream.synchronize()
+            assert np.array_equal(host(hx, d_r), ho.key_switch(r, t, n, D, K, D + 1, C, moduli, keys, msf))
+    t, r, d_t, d_r = sets[-1]
+    for other in ([msf[0] + 1] + msf[1:], msf, [msf[0] + 1] + msf[1:], [msf[0] + 1] + msf[1:]):
+        d_r.copy_(dev(hx, r))
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            hx.KeySwitch(d_r, d_t, n, D, K, D + 1, C, moduli, d_keys, other)
+        stream.synchronize()
+        assert np.array_equal(host(hx, d_r), ho.key_switch(r, t, n, D, K, D + 1, C, moduli, keys, other))
+    # inside the caller's own capture the calls are plain launches (a graph launch cannot be captured
+    # into another capture as a replay of ours); the caller's graph then replays them
+    d_r.copy_(dev(hx, r))
+    torch.cuda.synchronize()
+    before = hx.get_counter("ks_eager")
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=stream):
+        hx.KeySwitch(d_r, d_t, n, D, K, D + 1, C, moduli, d_keys, msf)
+    assert hx.get_counter("ks_eager") == before + 1
+    d_r.copy_(dev(hx, r))
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(host(hx, d_r), ho.key_switch(r, t, n, D, K, D + 1, C, moduli, keys, msf))
+    del g
+    assert hx.lib.hexl_amd_release_stream_workspaces(stream.cuda_stream) == 0
+
+
+def test_key_switch_host_calls_replay(hx, ho):
+    """hexl_amd_key_switch_host stages into the calling thread's own buffers, so an unmodified
+    per-ciphertext loop over host memory replays from its third call; every call against the
+    oracle, host keys and device-resident keys."""
+    import ctypes as C_
+    n, D, K, C = 4096, 3, 4, 2
+    rng = np.random.default_rng(5)
+    moduli, keys, msf = _ks_case(ho, rng, n, D, K, C, 50)
+    mod = (C_.c_uint64 * K)(*moduli)
+    fac = (C_.c_uint64 * D)(*msf)
+    d_keys = [dev(hx, k) for k in keys]
+    for key_ptrs in ([k.ctypes.data for k in keys], [k.data_ptr() for k in d_keys]):
+        kp = (C_.c_void_p * D)(*key_ptrs)
+        r0 = hx.get_counter("ks_graph_replays")
+        for rep in range(5):
+            t, r = _ks_data(rng, moduli, n, D, C)
+            want = ho.key_switch(r, t, n, D, K, D + 1, C, moduli, keys, msf)
+            got = r.copy()
+            rc = hx.lib.hexl_amd_key_switch_host(got.ctypes.data_as(C_.c_void_p),
+                                                 t.ctypes.data_as(C_.c_void_p), n, D, K, D + 1, C, mod,
+                                                 C_.cast(kp, C_.POINTER(C_.c_void_p)), fac)
+            assert rc == 0, hx.lib.hexl_amd_last_error()
+            assert np.array_equal(got, want), rep
+        assert hx.get_counter("ks_graph_replays") >= r0 + 3
+
+
 def test_workspaces_can_be_released(hx, ho):
     """Scratch of the composites is cached per (device, stream); the release entry points give
     it back, and a later call simply allocates again."""

@@ -298,6 +298,11 @@ struct DyadicModuli {
 // blockIdx.y = modulus within this launch; every thread reads its four inputs
 // before it writes its three outputs, so the result may alias either operand
 // (the in-place forms of the reference's tests).
+// VEC2: two adjacent coefficients per thread, 16 bytes per lane per access like the other
+// streaming kernels (seven streams of 8-byte accesses ran at 0.63 of the HBM peak where
+// MultMod's 16-byte ones run at 0.78); needs 16-byte aligned buffers and an even n (every
+// polynomial then starts on a 16-byte boundary).
+template <bool VEC2>
 __global__ void __launch_bounds__(256)
 dyadic_multiply_kernel(u64* res, const u64* x, const u64* y, u64 n, u64 n_proc, u64 poly_size,
                        u64 first_modulus, DyadicModuli mods) {
@@ -308,16 +313,37 @@ dyadic_multiply_kernel(u64* res, const u64* x, const u64* y, u64 n, u64 n_proc, 
   const MultOp op = mods.mult[blockIdx.y];
   const u64 base = (first_modulus + blockIdx.y) * n;
   const u64 stride = (u64)gridDim.x * 256;
-  for (u64 e = (u64)blockIdx.x * 256 + threadIdx.x; e < n_proc; e += stride) {
-    const u64 p0 = base + e, p1 = p0 + poly_size, p2 = p1 + poly_size;
-    const u64 x0 = x[p0], x1 = x[p1], y0 = y[p0], y1 = y[p1];
-    const u64 r2 = op(x1, y1);
-    const u64 t = op(x1, y0);
-    const u64 r1 = csub(op(x0, y1) + t, op.q);
-    const u64 r0 = op(x0, y0);
-    res[p2] = r2;
-    res[p1] = r1;
-    res[p0] = r0;
+  if constexpr (VEC2) {
+    const u64 pairs = n_proc >> 1;  // (n_proc is even with n)
+    for (u64 e = (u64)blockIdx.x * 256 + threadIdx.x; e < pairs; e += stride) {
+      const u64 p0 = base + 2 * e, p1 = p0 + poly_size, p2 = p1 + poly_size;
+      const ulonglong2 x0 = *reinterpret_cast<const ulonglong2*>(x + p0);
+      const ulonglong2 x1 = *reinterpret_cast<const ulonglong2*>(x + p1);
+      const ulonglong2 y0 = *reinterpret_cast<const ulonglong2*>(y + p0);
+      const ulonglong2 y1 = *reinterpret_cast<const ulonglong2*>(y + p1);
+      ulonglong2 r0, r1, r2;
+      r2.x = op(x1.x, y1.x);
+      r2.y = op(x1.y, y1.y);
+      r1.x = csub(op(x0.x, y1.x) + op(x1.x, y0.x), op.q);
+      r1.y = csub(op(x0.y, y1.y) + op(x1.y, y0.y), op.q);
+      r0.x = op(x0.x, y0.x);
+      r0.y = op(x0.y, y0.y);
+      *reinterpret_cast<ulonglong2*>(res + p2) = r2;
+      *reinterpret_cast<ulonglong2*>(res + p1) = r1;
+      *reinterpret_cast<ulonglong2*>(res + p0) = r0;
+    }
+  } else {
+    for (u64 e = (u64)blockIdx.x * 256 + threadIdx.x; e < n_proc; e += stride) {
+      const u64 p0 = base + e, p1 = p0 + poly_size, p2 = p1 + poly_size;
+      const u64 x0 = x[p0], x1 = x[p1], y0 = y[p0], y1 = y[p1];
+      const u64 r2 = op(x1, y1);
+      const u64 t = op(x1, y0);
+      const u64 r1 = csub(op(x0, y1) + t, op.q);
+      const u64 r0 = op(x0, y0);
+      res[p2] = r2;
+      res[p1] = r1;
+      res[p0] = r0;
+    }
   }
 }
 
@@ -342,10 +368,16 @@ hipError_t dyadic_multiply_launch(u64* result, const u64* op1, const u64* op2, u
     DyadicModuli mods;
     for (u64 i = 0; i < count; ++i) mods.mult[i] = make_mult_op(moduli[first + i], 1);
     for (u64 i = count; i < kDyadicModuliPerLaunch; ++i) mods.mult[i] = mods.mult[0];
-    unsigned gx = grid_for(n_proc);
+    const bool vec2 = (n & 1) == 0 && (n_proc & 1) == 0 &&
+                      (((uintptr_t)result | (uintptr_t)op1 | (uintptr_t)op2) & 15) == 0;
+    unsigned gx = grid_for(vec2 ? n_proc >> 1 : n_proc);
     if (gx > 65535u * 16) gx = 65535u * 16;
-    hipLaunchKernelGGL(dyadic_multiply_kernel, dim3(gx, (unsigned)count, (unsigned)pairs),
-                       dim3(256), 0, st, result, op1, op2, n, n_proc, poly_size, first, mods);
+    if (vec2)
+      hipLaunchKernelGGL(dyadic_multiply_kernel<true>, dim3(gx, (unsigned)count, (unsigned)pairs),
+                         dim3(256), 0, st, result, op1, op2, n, n_proc, poly_size, first, mods);
+    else
+      hipLaunchKernelGGL(dyadic_multiply_kernel<false>, dim3(gx, (unsigned)count, (unsigned)pairs),
+                         dim3(256), 0, st, result, op1, op2, n, n_proc, poly_size, first, mods);
   }
   return hipGetLastError();
 }

@@ -35,6 +35,10 @@ constexpr u64 kFp64LongModulusBound = 1ull << 47;
 // 2^60, which takes in the smallest primes above 2^60 -- what GeneratePrimes(., 60, true, .)
 // returns, the reference's "61-bit" test and benchmark moduli (BASELINE configs[4]).
 constexpr u64 kHarvey60ModulusBound = (1ull << 60) + (1ull << 28);
+// Moduli in [kHarvey60ModulusBound, kStrict8ModulusBound) use the Strict8 policy (Strict's
+// arithmetic, forward subtraction on host-marked stages only: 8q < 2^64); the rest, up to 2^62,
+// Strict.
+constexpr u64 kStrict8ModulusBound = 1ull << 61;
 
 enum ArithPolicy : int {
   kPolicySmall = 0,
@@ -45,7 +49,8 @@ enum ArithPolicy : int {
   kPolicyLazy32 = 5,
   kPolicyLazy16 = 6,
   kPolicyFp64L = 7,
-  kNumPolicies = 8
+  kPolicyStrict8 = 8,
+  kNumPolicies = 9
 };
 int choose_policy(u64 q);  // ntt_kernels.hip
 

@@ -467,6 +467,10 @@ int hexl_amd_profile_get(int i, const char** name, float* ms);
  *                      2^60 + 2^28 use the Harvey60 arithmetic policy (Harvey ranges on doubled
  *                      values, 19/20-instruction butterflies), 0 = the Strict policy; read when a
  *                      plan is created
+ *   "strict8"          1 (default) = plans for 2^60 + 2^28 <= q < 2^61 use the Strict8 policy (the
+ *                      forward network's conditional subtraction only on the stages the host
+ *                      marks: values below 8q < 2^64), 0 = the Strict policy; read when a plan is
+ *                      created
  *   "tile13"           which degrees above 4096 run as ONE kernel on an LDS tile holding the
  *                      whole polynomial (one HBM round trip instead of two): 2 (default) =
  *                      N = 8192 (64 KiB tile) and N = 16384 (128 KiB tile, batches >= 192),

@@ -22,9 +22,15 @@
 #include <unistd.h>
 
 static struct sigaction g_prev[65];
+/* Where the report goes: the file named by ABORT_TRACE_LOG, opened when the library loads (pytest
+ * points file descriptor 2 at its capture file while a test runs, so a report written there is
+ * lost with the process -- which is what happened to the first crash this was built for), and
+ * file descriptor 2 as well. */
+static int g_log_fd = -1;
 
 static void put(const char* s) {
   ssize_t r = write(2, s, strlen(s));
+  if (g_log_fd >= 0) r = write(g_log_fd, s, strlen(s));
   (void)r;
 }
 
@@ -32,11 +38,14 @@ static void put_num(long v) {
   char b[32];
   int i = 31;
   b[i] = 0;
+  const int neg = v < 0;
+  if (neg) v = -v;
   if (v == 0) b[--i] = '0';
-  while (v > 0 && i > 0) {
+  while (v > 0 && i > 1) {
     b[--i] = (char)('0' + v % 10);
     v /= 10;
   }
+  if (neg) b[--i] = '-';
   put(b + i);
 }
 
@@ -68,9 +77,15 @@ static void on_signal(int sig, siginfo_t* info, void* ctx) {
   put(" (pid ");
   put_num((long)getpid());
   put(") -- native backtrace ===\n");
+  put("si_code ");
+  put_num(info ? (long)info->si_code : -1);
+  put(" si_pid ");
+  put_num(info ? (long)info->si_pid : -1);
+  put("\n");
   void* frames[128];
   int n = backtrace(frames, 128);
   backtrace_symbols_fd(frames, n, 2);
+  if (g_log_fd >= 0) backtrace_symbols_fd(frames, n, g_log_fd);
   put("=== abort_trace: end ===\n");
   copy_maps();
   /* hand over */
@@ -91,6 +106,8 @@ static void on_signal(int sig, siginfo_t* info, void* ctx) {
 __attribute__((constructor)) static void install(void) {
   void* warm[4];
   (void)backtrace(warm, 4); /* loads libgcc_s now, not inside the handler */
+  const char* log = getenv("ABORT_TRACE_LOG");
+  if (log) g_log_fd = open(log, O_WRONLY | O_CREAT | O_APPEND | O_CLOEXEC, 0644);
   const int sigs[] = {SIGABRT, SIGSEGV, SIGBUS};
   for (unsigned i = 0; i < sizeof sigs / sizeof sigs[0]; ++i) {
     struct sigaction sa;

@@ -575,7 +575,7 @@ def get_counter(key):
 
 
 def set_tuning(key, value):
-    """Tuning knobs (include/hexl_amd.h documents them): "fp64", "fp64_long", "lazy_family", "h60", "strict8" (read when a
+    """Tuning knobs (include/hexl_amd.h documents them): "fp64", "fp64_long", "lazy_family", "h60" (read when a
     plan is created), "tile13", "bigtile", "host_bounce_kb", "ks_graph".
     The library reads no environment variable; results never depend on the knobs."""
     _check(lib.hexl_amd_set_tuning(key.encode(), int(value)))

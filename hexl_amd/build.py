@@ -18,11 +18,11 @@ OBJ = os.path.join(HERE, "lib", "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-# ntt_kernels.hip is compiled once per arithmetic policy (-DHEXL_AMD_TU=0..8: the kernels of
+# ntt_kernels.hip is compiled once per arithmetic policy (-DHEXL_AMD_TU=0..7: the kernels of
 # that policy) plus once for the dispatch and the process-wide state (-DHEXL_AMD_TU=-1): the
 # template instantiations are disjoint between policies and compile in parallel.
 NTT_UNITS = [("ntt_kernels.hip", f"-DHEXL_AMD_TU={tu}", f"ntt_kernels.tu{tu if tu >= 0 else 'd'}")
-             for tu in (2, 5, 6, 3, 8, 4, 1, 7, 0, -1)]  # the slowest units first
+             for tu in (2, 5, 6, 3, 4, 1, 7, 0, -1)]  # the slowest units first
 CORE_SOURCES = NTT_UNITS + ["eltwise_kernels.hip", "keyswitch_kernels.hip", "capi.cpp",
                             "number_theory.cpp", "workspace.cpp"]
 SHIM_SOURCES = ["hexl_shim.cpp"]

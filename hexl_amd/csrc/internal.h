@@ -35,10 +35,6 @@ constexpr u64 kFp64LongModulusBound = 1ull << 47;
 // 2^60, which takes in the smallest primes above 2^60 -- what GeneratePrimes(., 60, true, .)
 // returns, the reference's "61-bit" test and benchmark moduli (BASELINE configs[4]).
 constexpr u64 kHarvey60ModulusBound = (1ull << 60) + (1ull << 28);
-// Moduli in [kHarvey60ModulusBound, kStrict8ModulusBound) use the Strict8 policy (Strict's
-// arithmetic, forward subtraction on host-marked stages only: 8q < 2^64); the rest, up to 2^62,
-// Strict.
-constexpr u64 kStrict8ModulusBound = 1ull << 61;
 
 enum ArithPolicy : int {
   kPolicySmall = 0,
@@ -49,8 +45,7 @@ enum ArithPolicy : int {
   kPolicyLazy32 = 5,
   kPolicyLazy16 = 6,
   kPolicyFp64L = 7,
-  kPolicyStrict8 = 8,
-  kNumPolicies = 9
+  kNumPolicies = 8
 };
 int choose_policy(u64 q);  // ntt_kernels.hip
 
@@ -142,7 +137,7 @@ hipError_t ntt_inverse_launch(const NttTables& t, u64* result, const u64* operan
                               u64 out_mf, hipStream_t st);
 
 // Whether a transform of `batch` polynomials under plan `t` is ONE kernel launch (degrees up
-// to 2^12, 2^13, and 2^14 from 192 polynomials): what the zero-copy host path can run straight
+// to 2^12, 2^13, and 2^14 from 96 polynomials): what the zero-copy host path can run straight
 // on caller memory.
 bool ntt_is_single_kernel(const NttTables& t, u64 batch);
 

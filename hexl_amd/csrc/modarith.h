@@ -113,7 +113,7 @@ inline ModConst make_mod_const(u64 q) {  // host only
   m.neg_q = 0 - q;
   m.neg_two_q = 0 - (q << 1);
   m.barrett = (u64)((((unsigned __int128)1) << 64) / q);
-  m.four_q = q << 2;  // only meaningful (and only read) for q < 2^61 (Harvey60, Lazy16, Strict8)
+  m.four_q = q << 2;  // only meaningful (and only read) for q < 2^60 + 2^28 (Harvey60, Lazy16)
   m.neg_four_q = 0 - (q << 2);
   m.six_q = 6 * q;  // only meaningful (and only read) for q < 2^58 (Lazy, Lazy32: 6q < 2^61)
   u32 b = 0;
@@ -268,28 +268,6 @@ struct Strict {  // any q < 2^62; tables hold floor(W * 2^64 / q); plain values
   static constexpr bool kExact = false;
   static constexpr int kFwdRun = 0, kInvRun = 0;
 };
-// 2^60 + 2^28 <= q < 2^61 (Strict8): the same arithmetic with the forward network's conditional
-// subtraction moved out of the butterfly.  floor(2^64 / q) >= 8, the exact Shoup product accepts
-// ANY 64-bit y, and both outputs of a butterfly derive from its x operand (x' = x + T,
-// y' = x + 2q - T, T < 2q): values may grow by 2q per stage up to 8q, and ONE sign-free
-// subtraction of 4q on the x operands (csub_wrap: x >= 4q ? x - 4q : x) buys two stages --
-// 4 -> 6 -> 8 | -4q | 6 -> 8 | ... : the stages the host marks (forward_seq walks the bound
-// through all passes of the plan, as for Lazy32 / Lazy16) subtract, every other one, 21
-// instructions per butterfly on average where Strict has 23; the finish brings < 8q to < 4q
-// first.  The inverse network is Strict's.
-struct Strict8 {
-  static constexpr bool kLazy = false;
-  static constexpr bool kSmall = false;
-  static constexpr bool kFp = false;
-  static constexpr bool kH60 = false;
-  static constexpr int kLimit = 8;
-  static constexpr bool kExact = false;
-  static constexpr int kFwdRun = 0, kInvRun = 0;
-};
-template <class A>
-constexpr bool is_strict8() {
-  return !A::kLazy && !A::kSmall && !A::kFp && !A::kH60 && A::kLimit == 8;
-}
 // The Lazy family: doubled values, 63-bit Shoup factors, no conditional subtraction per
 // butterfly.  kLimit = what floor(2^63 / q) is at least for the moduli the member serves: every
 // (doubled) value stays below kLimit * q.  kExact: the forward product keeps the lowest partial
@@ -490,8 +468,7 @@ HX_HD void fwd_butterfly(u64& x, u64& y, u64 W, u64 Wp, const ModConst& m) {
     x = tx + T;
     y = tx + (u32)m.two_q - T;
   } else {
-    // (Strict8: x < 6q as the host's stage marks left it -- fwd_bound_level)
-    const u64 tx = is_strict8<A>() ? x : csub_wrap(x, m.neg_two_q);
+    const u64 tx = csub_wrap(x, m.neg_two_q);
     const u64 xs = mul_add_strict(tx, y, W, Wp, m.neg_q);
     y = (tx << 1) + m.two_q - xs;  // = tx + 2q - T (mod 2^64; the true value is < 4q)
     x = xs;
@@ -534,7 +511,6 @@ HX_HD u64 fwd_finish(u64 x, const ModConst& m, bool canonical) {
     return x >> 1;
   }
   if (A::kSmall) return canonical ? csub32(csub32((u32)x, (u32)m.two_q), (u32)m.q) : x;
-  if (is_strict8<A>()) x = csub_wrap(x, m.neg_four_q);  // < 8q -> < 4q
   return canonical ? csub(csub(x, m.two_q), m.q) : x;
 }
 

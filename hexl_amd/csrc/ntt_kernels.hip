@@ -43,8 +43,8 @@
 //     Bound by VALU issue (integer multiplies), not by HBM: see DESIGN.md.
 //
 // Values stay lazy as in the reference's Harvey butterflies
-// (hexl/ntt/ntt-default.hpp:28-42, :112-125); see modarith.h for the nine
-// arithmetic policies (Small, Fp64 / Fp64L, Lazy / Lazy32 / Lazy16, Harvey60, Strict8 / Strict;
+// (hexl/ntt/ntt-default.hpp:28-42, :112-125); see modarith.h for the eight
+// arithmetic policies (Small, Fp64 / Fp64L, Lazy / Lazy32 / Lazy16, Harvey60, Strict;
 // choose_policy below picks one per modulus).  Below the kernels: the multi-plan variants
 // (polynomials of several moduli in one launch: RNS limbs, KeySwitch), and the
 // host-side planning.  Canonical outputs (output_mod_factor == 1) are bit-identical to the
@@ -239,37 +239,26 @@ __device__ __forceinline__ void load_twiddles(T* wv, const T* __restrict__ tw, u
     }
 }
 
-// Bounded members of the Lazy family (and Strict8, the same idea on plain values): the x operands
-// of a stage whose bit is set in `smask` are brought below kLimit/2 * q first (a uniform branch:
-// the mask is a kernel argument).
+// Bounded members of the Lazy family: the x operands of a stage whose bit is set in `smask` are
+// brought below kLimit/2 * q first (a uniform branch: the mask is a kernel argument).
 template <class A>
 constexpr bool bounded_lazy() { return A::kLazy && A::kLimit < kLazyLimit; }
-template <class A>
-constexpr bool bounded_fwd() { return bounded_lazy<A>() || is_strict8<A>(); }
 template <class A>
 constexpr int bounded_lazy_shift() {  // kLimit/2 * q = 2q << shift
   int s = 0;
   while ((4 << s) < A::kLimit) ++s;
   return s;
 }
-// x >= kLimit/2 * q ? x - kLimit/2 * q : x
-template <class A>
-__device__ __forceinline__ u64 fwd_bound_csub(u64 x, const ModConst& m) {
-  if constexpr (is_strict8<A>())
-    return csub_wrap(x, m.neg_four_q);
-  else
-    return lazy_csub(x, m, bounded_lazy_shift<A>());
-}
 template <int R, int V, int G0, int G1, class A>
 __device__ __forceinline__ void fwd_bound_level(u64* x, const ModConst& m, u32 smask) {
-  if constexpr (bounded_fwd<A>()) {
+  if constexpr (bounded_lazy<A>()) {
     if (smask & (1u << V)) {
       constexpr int half = 1 << (R - 1 - V);
 #pragma unroll
       for (int g = G0; g < G1; ++g)
 #pragma unroll
         for (int j = 0; j < half; ++j) {
-          x[g * 2 * half + j] = fwd_bound_csub<A>(x[g * 2 * half + j], m);
+          x[g * 2 * half + j] = lazy_csub(x[g * 2 * half + j], m, bounded_lazy_shift<A>());
           // (32 elements per thread: keep the scheduler from issuing all the additions before
           // the first selection -- their sums would all be live at once and spill)
           if (R >= 5 && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -286,13 +275,13 @@ __device__ __forceinline__ void fwd_subtree(u64* x, const TwT<A>* wv, const ModC
 #pragma unroll
   for (int v = 0; v < R; ++v) {
     const int half = 1 << (R - 1 - v);
-    if constexpr (bounded_fwd<A>()) {
+    if constexpr (bounded_lazy<A>()) {
       if (smask & (1u << v)) {
 #pragma unroll
         for (int g = 0; g < (1 << v); ++g)
 #pragma unroll
           for (int j = 0; j < half; ++j)
-            x[g * 2 * half + j] = fwd_bound_csub<A>(x[g * 2 * half + j], m);
+            x[g * 2 * half + j] = lazy_csub(x[g * 2 * half + j], m, bounded_lazy_shift<A>());
       }
     }
 #pragma unroll
@@ -657,7 +646,6 @@ constexpr int policy_id() {
          : (A::kLazy && A::kLimit == 16) ? kPolicyLazy16
          : A::kLazy ? kPolicyLazy
          : A::kH60  ? kPolicyHarvey60
-         : is_strict8<A>() ? kPolicyStrict8
                     : kPolicyStrict;
 }
 
@@ -677,7 +665,7 @@ strided_pass_multi(u64* out, const u64* in, MultiCtx mc, u32 log_n, u32 a0, u32 
   in = multi_source(mc, poly, log_n, in, flags);
   // (data first -- see strided_body -- except where the 5-stage forward subtree of a bounded
   // member of the Lazy family has no registers to spare for it)
-  strided_body<FWD, R, A, LAST, kStream, kStream, !(FWD && R >= 5 && bounded_fwd<A>()), true>(
+  strided_body<FWD, R, A, LAST, kStream, kStream, !(FWD && R >= 5 && bounded_lazy<A>()), true>(
       out, in, FWD ? mc.tw_fwd[k] : mc.tw_inv[k], m, log_n, a0, flags, bid, il);
 }
 
@@ -1275,10 +1263,9 @@ struct Plan {
 // Process-wide tuning state (hexl_amd_set_tuning; include/hexl_amd.h documents the keys).  The
 // library reads no environment variable: every knob has a compiled-in default and changes only
 // through that call.  Results never depend on it.
-constexpr u32 kTile14SmallDefault = 0;
+constexpr u64 kTile14MinBatch = 96;
 struct Tuning {
-  std::atomic<u32> fp64{1}, h60{1}, tile13{2}, bigtile{1}, lazy_family{1}, fp64_long{1}, strict8{1},
-      tile14_small{kTile14SmallDefault};
+  std::atomic<u32> fp64{1}, h60{1}, tile13{2}, bigtile{1}, lazy_family{1}, fp64_long{1};
 };
 Tuning& tuning();  // one per process: defined by the dispatch unit
 #if HX_TU_DISPATCH
@@ -1294,8 +1281,6 @@ int set_tuning(const char* key, u64 value) {
   else if (strcmp(key, "bigtile") == 0 && value <= 1) t.bigtile = (u32)value;
   else if (strcmp(key, "lazy_family") == 0 && value <= 1) t.lazy_family = (u32)value;
   else if (strcmp(key, "fp64_long") == 0 && value <= 1) t.fp64_long = (u32)value;
-  else if (strcmp(key, "strict8") == 0 && value <= 1) t.strict8 = (u32)value;
-  else if (strcmp(key, "tile14_small") == 0 && value < 192) t.tile14_small = (u32)value;
   else return -1;
   return 0;
 }
@@ -1308,13 +1293,14 @@ static Plan make_plan(int L, bool allow_tile13 = true, u64 batch = ~0ull) {
     p.bottom = L;
     return p;
   }
-  if (L == 14 && allow_tile13 && tuning().tile13.load() >= 2 &&
-      (batch >= 192 || batch <= tuning().tile14_small.load())) {
+  if (L == 14 && allow_tile13 && tuning().tile13.load() >= 2 && batch >= kTile14MinBatch) {
     // N = 16384: 128 KiB tile, one workgroup of 1024 threads x 16 elements per CU (one
-    // workgroup per polynomial: batches that do not fill the CUs keep the two-pass shape,
-    // whose tile pass spreads a polynomial over 8 workgroups -- except the SMALLEST ones,
-    // "tile14_small", where a call is bound by the latency of its dependent launches and
-    // one launch beats two: the one-polynomial host call, KeySwitch one ciphertext per call)
+    // workgroup per polynomial: smaller batches keep the two-pass shape, whose tile pass spreads a
+    // polynomial over 8 workgroups.  Measured as wall time per dependent call, round 5
+    // (profiles/r5_small_batch_ab.txt): one polynomial 10.9 us against 17.0 for the one-kernel
+    // plan -- a single workgroup's 14 stages are a long serial chain -- 64 polynomials 15.4
+    // against 18.0, 100 polynomials 19.7 against 18.4, 150 23.8 against 19.6: the plans cross
+    // between 64 and 100)
     p.tl = 14;
     p.bottom = 14;
     return p;
@@ -1377,13 +1363,12 @@ static hipError_t forward_seq(const NttTables& t, const Plan& p, u64* result, co
   u32 a0 = 0;
   // Bounded members of the Lazy family: the bound of the (doubled) values walked through the
   // network -- 8q from the caller (input_mod_factor <= 4), +6q per stage (+4q with the exact
-  // product) -- and the stages marked whose x operands must lose kLimit/2 * q first.  Strict8:
-  // the same on plain values -- 4q from the caller, +2q per stage, limit 8q, 4q subtracted.
-  int bound = is_strict8<A>() ? 4 : 8;
+  // product) -- and the stages marked whose x operands must lose kLimit/2 * q first.
+  int bound = 8;
   auto stage_mask = [&bound](int stages) -> u32 {
     u32 mask = 0;
-    if constexpr (bounded_fwd<A>()) {
-      constexpr int grow = is_strict8<A>() ? 2 : A::kExact ? 4 : 6;
+    if constexpr (bounded_lazy<A>()) {
+      constexpr int grow = A::kExact ? 4 : 6;
       for (int s = 0; s < stages; ++s) {
         if (bound + grow > A::kLimit) {
           mask |= 1u << s;
@@ -1463,7 +1448,6 @@ HX_POLICY_ENTRY_DECL(harvey60)
 HX_POLICY_ENTRY_DECL(lazy32)
 HX_POLICY_ENTRY_DECL(lazy16)
 HX_POLICY_ENTRY_DECL(fp64l)
-HX_POLICY_ENTRY_DECL(strict8)
 #undef HX_POLICY_ENTRY_DECL
 
 #define HX_POLICY_ENTRY_DEF(NAME, A)                                                            \
@@ -1500,13 +1484,9 @@ HX_POLICY_ENTRY_DEF(lazy16, Lazy16)
 #if HX_TU_POLICY(7)
 HX_POLICY_ENTRY_DEF(fp64l, Fp64L)
 #endif
-#if HX_TU_POLICY(8)
-HX_POLICY_ENTRY_DEF(strict8, Strict8)
-#endif
 #undef HX_POLICY_ENTRY_DEF
 static_assert(kPolicySmall == 0 && kPolicyFp64 == 1 && kPolicyLazy == 2 && kPolicyStrict == 3 &&
-                  kPolicyHarvey60 == 4 && kPolicyLazy32 == 5 && kPolicyLazy16 == 6 && kPolicyFp64L == 7 &&
-                  kPolicyStrict8 == 8,
+                  kPolicyHarvey60 == 4 && kPolicyLazy32 == 5 && kPolicyLazy16 == 6 && kPolicyFp64L == 7,
               "the HX_TU_POLICY numbers above are the ArithPolicy values");
 
 #if HX_TU_DISPATCH
@@ -1522,7 +1502,6 @@ static hipError_t transform_dispatch(bool forward, const NttTables& t, u64* resu
     case kPolicyLazy32: return transform_entry_lazy32(forward, t, result, operand, batch, out_mf, st);
     case kPolicyLazy16: return transform_entry_lazy16(forward, t, result, operand, batch, out_mf, st);
     case kPolicyFp64L: return transform_entry_fp64l(forward, t, result, operand, batch, out_mf, st);
-    case kPolicyStrict8: return transform_entry_strict8(forward, t, result, operand, batch, out_mf, st);
     default: return transform_entry_strict(forward, t, result, operand, batch, out_mf, st);
   }
 }
@@ -1604,8 +1583,6 @@ hipError_t ntt_multi_launch(bool forward, const NttTables* const* tabs, u32 num_
     e = multi_entry_lazy16(forward, t0, mc, polys, result, operand, out_mf, st);
   if (have[kPolicyFp64L] && e == hipSuccess)
     e = multi_entry_fp64l(forward, t0, mc, polys, result, operand, out_mf, st);
-  if (have[kPolicyStrict8] && e == hipSuccess)
-    e = multi_entry_strict8(forward, t0, mc, polys, result, operand, out_mf, st);
   if (have[kPolicyStrict] && e == hipSuccess)
     e = multi_entry_strict(forward, t0, mc, polys, result, operand, out_mf, st);
   // past the check above a refusal can only come after launches were made: a hard error,
@@ -1635,8 +1612,6 @@ int choose_policy(u64 q) {
   }
   // ("h60" = 0: 2^56 <= q < 2^60 + 2^28 on the Strict policy)
   if (q < kHarvey60ModulusBound && tuning().h60.load() != 0) return kPolicyHarvey60;
-  // (up to 2^61 the forward network subtracts on the stages the host marks; "strict8" = 0: Strict)
-  if (q < kStrict8ModulusBound && tuning().strict8.load() != 0) return kPolicyStrict8;
   return kPolicyStrict;
 }
 

@@ -60,7 +60,7 @@ int hexl_amd_pointer_is_device(const void* p);
 /* Host memory the kernels can address.  The *_host entry points (what the intel::hexl shim
  * calls for host pointers) stage ordinary host memory through a device buffer: H2D copy,
  * kernels, D2H copy.  Memory that is pinned AND mapped into the device's address space needs
- * none of that: a one-kernel transform (degree <= 2^13, 2^14 from 192 polynomials) or an
+ * none of that: a one-kernel transform (degree <= 2^13, 2^14 from 96 polynomials) or an
  * element-wise kernel runs straight on it over the link -- one launch, one synchronisation --
  * and a multi-pass transform reads its operand there.
  *   hexl_amd_host_alloc / _free        such memory from the runtime (hipHostMalloc, mapped)
@@ -467,13 +467,9 @@ int hexl_amd_profile_get(int i, const char** name, float* ms);
  *                      2^60 + 2^28 use the Harvey60 arithmetic policy (Harvey ranges on doubled
  *                      values, 19/20-instruction butterflies), 0 = the Strict policy; read when a
  *                      plan is created
- *   "strict8"          1 (default) = plans for 2^60 + 2^28 <= q < 2^61 use the Strict8 policy (the
- *                      forward network's conditional subtraction only on the stages the host
- *                      marks: values below 8q < 2^64), 0 = the Strict policy; read when a plan is
- *                      created
  *   "tile13"           which degrees above 4096 run as ONE kernel on an LDS tile holding the
  *                      whole polynomial (one HBM round trip instead of two): 2 (default) =
- *                      N = 8192 (64 KiB tile) and N = 16384 (128 KiB tile, batches >= 192),
+ *                      N = 8192 (64 KiB tile) and N = 16384 (128 KiB tile, batches >= 96),
  *                      1 = N = 8192 only, 0 = neither
  *   "bigtile"          1 (default) = N = 2^18, 2^19 as five strided stages + a 13- / 14-stage
  *                      tile pass (two HBM round trips), 0 = three passes (3 + 3 + 12, 4 + 3 + 12)

@@ -81,21 +81,18 @@ static void check(u64 n, u64 q, const std::vector<int>& inv_runs, u64 in_mf_f, u
     // (ntt_kernels.hip: forward_seq) -- 8q from the caller, + 6q per stage (+ 4q with the exact
     // product); a bounded member subtracts kLimit/2 * q from the x operands of a stage whose
     // growth would pass kLimit * q
-    // Strict8: the same walk on plain values -- 4q from the caller, + 2q per stage, limit 8q,
-    // 4q subtracted on a marked stage
-    constexpr bool kS8 = is_strict8<A>();
-    u64 fbound = kS8 ? 4 : 8;
-    const u64 grow = kS8 ? 2 : A::kExact ? 4 : 6;
+    u64 fbound = 8;
+    const u64 grow = A::kExact ? 4 : 6;
     for (int s = 0; s < L; ++s) {
       const u64 mgroups = 1ull << s, t = n >> (s + 1);
       bool subtract = false;
-      if (A::kLazy || kS8) {
-        if ((kS8 || A::kLimit < kLazyLimit) && fbound + grow > (u64)A::kLimit) {
+      if (A::kLazy) {
+        if (A::kLimit < kLazyLimit && fbound + grow > (u64)A::kLimit) {
           subtract = true;
           fbound = A::kLimit / 2;
         }
         fbound += grow;
-        EXPECT(fbound <= (u64)A::kLimit, "fwd lazy: bound %llu passes the limit", (unsigned long long)fbound);
+        EXPECT(fbound <= (u64)(A::kLazy ? A::kLimit : 0), "fwd lazy: bound %llu passes the limit", (unsigned long long)fbound);
       }
       int csub_shift = 0;
       while (A::kLazy && (4 << csub_shift) < A::kLimit) ++csub_shift;
@@ -104,15 +101,13 @@ static void check(u64 n, u64 q, const std::vector<int>& inv_runs, u64 in_mf_f, u
           u64& a = x[2 * i * t + j];
           u64& b = x[2 * i * t + j + t];
           if (subtract) {
-            // (8q < 2^64 for Strict8's moduli: the comparison itself does not wrap)
             EXPECT(a < (u64)A::kLimit * q, "fwd lazy: conditional subtraction out of its range");
-            a = kS8 ? csub_wrap(a, m.neg_four_q) : lazy_csub(a, m, csub_shift);
+            a = lazy_csub(a, m, csub_shift);
             EXPECT(a < (u64)(A::kLimit / 2) * q, "fwd lazy: conditional subtraction result");
           }
-          if (kS8) EXPECT(a < 6 * q, "fwd strict8: x operand %llu not below 6q", (unsigned long long)a);
           fwd_butterfly<A>(a, b, W[mgroups + i], Wp[mgroups + i], m);
           EXPECT(a < lim && b < lim, "fwd range: stage %d", s);
-          if (A::kLazy || kS8)
+          if (A::kLazy)
             EXPECT(a < fbound * q && b < fbound * q, "fwd lazy bound: stage %d", s);
           else if (A::kH60)  // Harvey's [0,4q) on doubled values
             EXPECT(a < 8 * q && b < 8 * q, "fwd harvey60 bound: stage %d", s);
@@ -651,22 +646,6 @@ int main() {
       check_lazy_inverse(1ull << 15, primes[0], {{14, true}, {1, false}}, 2);
       check_lazy_inverse(1ull << 16, primes[0], {{10, true}, {2, false}, {4, false}}, 2);
       check_lazy_inverse(1ull << 14, primes[0], {{9, true}, {5, false}}, 2);
-    }
-  }
-  // Strict8: 2^60 + 2^28 <= q < 2^61, primes at both ends of the range (the smallest NTT prime
-  // above the Harvey60 bound is found by walking up from it), both input factors
-  for (int L : {1, 2, 3, 6, 11, 12, 13, 16, 17}) {
-    const u64 n = 1ull << L;
-    size_t got = ho_generate_primes(primes, 1, 60, 0, n);  // just below 2^61
-    u64 cand = ((1ull << 60) + (1ull << 28)) / (2 * n) * (2 * n) + 1;
-    while (cand < (1ull << 60) + (1ull << 28) || !ho_is_prime(cand)) cand += 2 * n;
-    primes[got++] = cand;
-    for (size_t pi = 0; pi < got; ++pi) {
-      const u64 q = primes[pi];
-      if (q < (1ull << 60) + (1ull << 28) || q >= (1ull << 61)) continue;
-      if (L >= 16 && pi) continue;
-      check<Strict8>(n, q, run_sets[0], 4, 2);
-      check<Strict8>(n, q, run_sets[1], 1, 1);
     }
   }
   // Small policy: q < 2^30, up to the bound (GeneratePrimes(., 29, false, .) walks down from 2^30)

@@ -74,8 +74,8 @@ def test_fuzz_ntt(hx, ho, idx):
     logn = rng.choice([1, 2, 3, 5, 8, 10, 11, 12, 12, 13, 13, 14, 14, 15, 16, 16, 17])
     n = 1 << logn
     q = draw_prime(ho, rng, logn)
-    # batches around the plan thresholds (192 for the one-kernel N = 2^14 plan) and ragged ones
-    batch = min(rng.choice([1, 1, 2, 3, 5, 8, 17, 64, 191, 192, 193, 256]), max(1, MAX_ELEMS // n))
+    # batches around the plan thresholds (96 for the one-kernel N = 2^14 plan) and ragged ones
+    batch = min(rng.choice([1, 1, 2, 3, 5, 8, 17, 64, 95, 96, 97, 191, 256]), max(1, MAX_ELEMS // n))
     forward = rng.random() < 0.5
     in_mf, out_mf = rng.choice([(1, 1), (2, 1), (4, 1), (1, 4), (2, 4), (4, 4)] if forward
                                else [(1, 1), (2, 1), (1, 2), (2, 2)])

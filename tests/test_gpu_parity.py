@@ -279,7 +279,7 @@ def test_ntt_rns(hx, ho):
     (8192, [45, 45, 45, 45], 1),      # Fp64 policy, one polynomial per modulus
     (1 << 17, [60, 60], 2),           # Harvey60 policy (just above 2^60), 5 + 12 stages
     (1 << 16, [61, 61], 2),           # Strict policy
-    (1 << 15, ["s8", "s8", 54], 2),   # Strict8 policy (just below 2^61) beside Lazy: multi-plan kernels
+    (1 << 15, ["s8", "s8", 54], 2),   # Strict policy just below 2^61 beside Lazy: multi-plan kernels
     (2048, [54, 54], 3),              # below the multi-plan shapes: plan by plan
     (16384, [28, 54, 45, 60], 2),     # mixed arithmetic policies: plan by plan
     (4096, [54] * 33, 1),             # more moduli than one launch takes (32): two groups
@@ -870,67 +870,11 @@ def test_ntt_bounded_lazy_policies_match_strict_policy(hx, n, batch, bits, small
     assert torch.equal(a, b)
 
 
-def _strict8_prime(hx, n, small_end):
-    """An NTT prime at one end of [2^60 + 2^28, 2^61): walking down from 2^61, or up from the bound."""
-    if not small_end:
-        return hx.GeneratePrimes(1, 60, False, n)[0]
-    lo = (1 << 60) + (1 << 28)
-    q = lo // (2 * n) * (2 * n) + 1
-    while q < lo or not hx.lib.hexl_amd_is_prime(q):
-        q += 2 * n
-    return q
-
-
-@pytest.mark.parametrize("n,batch,small_end", [
-    (2, 5, False), (64, 7, True), (4096, 64, False), (4096, 33, True), (1 << 13, 5, False),
-    (1 << 14, 200, True), (1 << 14, 3, False), (65536, 64, True), (65536, 16, False),
-    (1 << 17, 8, True), (1 << 18, 2, False), (1 << 20, 1, True)])
-def test_ntt_strict8_policy_matches_strict_policy(hx, ho, n, batch, small_end):
-    """2^60 + 2^28 <= q < 2^61 (modarith.h Strict8): the forward network subtracts 4q from the x
-    operands of the stages the host marks only (values below 8q < 2^64) and the finish brings
-    them below 4q -- against the Strict policy on the same inputs, bit for bit, at both ends of
-    the range, one-kernel, two-pass and three-pass plans, every legal factor pair, adversarial
-    inputs at the top of their ranges; the oracle where it finishes in seconds."""
-    import torch
-    q = _strict8_prime(hx, n, small_end)
-    assert (1 << 60) + (1 << 28) <= q < (1 << 61)
-    try:
-        hx.set_tuning("strict8", 0)
-        strict = hx.NTT(n, q)
-    finally:
-        hx.set_tuning("strict8", 1)
-    s8 = hx.NTT(n, q)
-    x = torch.empty((batch, n), dtype=torch.int64, device="cuda")
-    a, b = torch.empty_like(x), torch.empty_like(x)
-    for in_mf in (1, 2, 4):
-        hx.fill_splitmix(x, n, batch, 91, in_mf * q)
-        strict.ComputeForward(a, x, in_mf, 1)
-        s8.ComputeForward(b, x, in_mf, 1)
-        assert torch.equal(a, b)
-        s8.ComputeForward(b, x, in_mf, 4)
-        assert int(b.min()) >= 0 and int(b.max()) < 4 * q and torch.equal(b % q, a)
-        if n <= 16384 and in_mf == 1:
-            rows = sorted({0, batch - 1})
-            assert (host(hx, a[rows]) == ho.NTT(n, q).forward(host(hx, x[rows]), 1, 1)).all()
-    for in_mf in (1, 2):
-        hx.fill_splitmix(x, n, batch, 92, in_mf * q)
-        strict.ComputeInverse(a, x, in_mf, 1)
-        s8.ComputeInverse(b, x, in_mf, 1)
-        assert torch.equal(a, b)
-    for in_mf in (1, 4):
-        x.fill_(in_mf * q - 1)
-        strict.ComputeForward(a, x, in_mf, 1)
-        s8.ComputeForward(b, x, in_mf, 1)
-        assert torch.equal(a, b)
-        s8.ComputeForward(x, x, in_mf, 4)  # in place, lazy output range
-        assert int(x.min()) >= 0 and int(x.max()) < 4 * q and torch.equal(x % q, a)
-
-
 @pytest.mark.parametrize("logn", [13, 14])
 @pytest.mark.parametrize("bits", [28, 45, 54, 60])
 def test_ntt_single_kernel_plans(hx, ho, logn, bits):
     """N = 8192 / 16384 as ONE kernel on a 64 / 128 KiB LDS tile (16 elements per thread and
-    rounds of four stages at N = 16384; batches >= 192 there) against the two-pass plan, bit
+    rounds of four stages at N = 16384; batches >= 96 there) against the two-pass plan, bit
     for bit, and against the oracle; every arithmetic policy, lazy outputs, out of place."""
     import torch
     n, batch = 1 << logn, 200

@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "hexl_amd", "csrc")
-UNITS = [("ntt_kernels.hip", f"-DHEXL_AMD_TU={tu}", f"ntt tu{tu}") for tu in range(9)] + [
+UNITS = [("ntt_kernels.hip", f"-DHEXL_AMD_TU={tu}", f"ntt tu{tu}") for tu in range(8)] + [
     ("eltwise_kernels.hip", None, "eltwise"), ("keyswitch_kernels.hip", None, "keyswitch")]
 
 

@@ -213,20 +213,36 @@ def _stream():
 
 
 def from_numpy(a, device="cuda"):
-    """uint64 numpy array -> device tensor (int64 storage, same bits)."""
+    """uint64 numpy array -> device tensor (int64 storage, same bits).  The bytes travel through
+    hexl_amd_copy -- the library's pinned slots -- not through torch's copy of pageable memory,
+    which from about 1 MiB lets the HIP runtime pin the array's pages on the fly (the path the
+    GPU memory access faults of rounds 4 and 5 sat in: EXPERIMENTS.md section 10)."""
     import numpy as np
     torch = _require_gpu()
     a = np.ascontiguousarray(a, dtype=np.uint64)
-    return torch.from_numpy(a.view(np.int64)).to(device)
+    t = torch.empty(a.shape, dtype=torch.int64, device=device)
+    if a.size:
+        with torch.cuda.device(t.device):
+            _check(lib.hexl_amd_copy(C.c_void_p(t.data_ptr()), a.ctypes.data_as(C.c_void_p), a.nbytes,
+                                     _stream(), 1))
+    return t
 
 
 def to_numpy(t):
-    """device tensor -> uint64 numpy array."""
+    """device tensor -> uint64 numpy array (through hexl_amd_copy, see from_numpy)."""
     import numpy as np
     torch = _torch()
     if t.dtype == torch.uint64:
         t = t.view(torch.int64)
-    return t.detach().cpu().numpy().view(np.uint64)
+    if not t.is_cuda:
+        return t.detach().numpy().view(np.uint64)
+    t = t.detach().contiguous()
+    out = np.empty(tuple(t.shape), dtype=np.uint64)
+    if out.size:
+        with torch.cuda.device(t.device):
+            _check(lib.hexl_amd_copy(out.ctypes.data_as(C.c_void_p), C.c_void_p(t.data_ptr()), out.nbytes,
+                                     _stream(), 1))
+    return out
 
 
 # ----------------------------------------------------------------------------
@@ -576,7 +592,7 @@ def get_counter(key):
 
 def set_tuning(key, value):
     """Tuning knobs (include/hexl_amd.h documents them): "fp64", "fp64_long", "lazy_family", "h60" (read when a
-    plan is created), "tile13", "bigtile", "host_bounce_kb", "ks_graph".
+    plan is created), "tile13", "bigtile", "host_bounce_kb", "host_direct_copy", "ks_graph".
     The library reads no environment variable; results never depend on the knobs."""
     _check(lib.hexl_amd_set_tuning(key.encode(), int(value)))
 

@@ -103,6 +103,17 @@ struct Staging {
   void* bounce = nullptr;      // host address
   void* bounce_dev = nullptr;  // the address kernels use
   size_t bounce_cap = 0;
+  // Copies between ordinary (pageable) caller memory and the device go through these two pinned
+  // slots, never through the runtime's own handling of pageable memory: from about 1 MiB the HIP
+  // runtime pins the CALLER's pages for the duration of a copy instead of staging them, and
+  // that is the path the round-4 / round-5 aborts sat in -- a GPU memory access fault on an
+  // address inside the process's heap, raised while a thread was inside such a copy
+  // (EXPERIMENTS.md section 10).  staged_h2d / staged_d2h below.
+  static constexpr size_t kSlotBytes = (size_t)1 << 20;
+  void* slot[2] = {nullptr, nullptr};
+  hipEvent_t slot_ev[2] = {nullptr, nullptr};
+  bool slot_busy[2] = {false, false};
+  int slot_device = -1;  // the device the events belong to
   // A thread that ends gives its buffer and streams back (callers that run every task on
   // a fresh std::thread would otherwise leak one staging area per task).  Thread-local
   // destructors run when the thread ends and, for the main thread, at exit() BEFORE
@@ -120,7 +131,39 @@ struct Staging {
     }
     if (buf) (void)hipFree(buf);
     if (bounce) (void)hipHostFree(bounce);
+    for (int b = 0; b < 2; ++b) {
+      if (slot_ev[b]) {
+        if (slot_busy[b]) (void)hipEventSynchronize(slot_ev[b]);
+        (void)hipEventDestroy(slot_ev[b]);
+      }
+      if (slot[b]) (void)hipHostFree(slot[b]);
+    }
     if (stream) (void)hipStreamDestroy(stream);
+  }
+  // (the current device is the one the copies' stream belongs to)
+  int ensure_slots() {
+    int dev = 0;
+    HX_HIP(hipGetDevice(&dev));
+    for (int b = 0; b < 2; ++b) {
+      if (!slot[b]) HX_HIP(hipHostMalloc(&slot[b], kSlotBytes, hipHostMallocPortable));
+      if (slot_ev[b] && slot_device != dev) {  // an event records on streams of its own device only
+        if (slot_busy[b]) (void)hipEventSynchronize(slot_ev[b]);
+        slot_busy[b] = false;
+        (void)hipEventDestroy(slot_ev[b]);
+        slot_ev[b] = nullptr;
+      }
+      if (!slot_ev[b]) HX_HIP(hipEventCreateWithFlags(&slot_ev[b], hipEventDisableTiming));
+    }
+    slot_device = dev;
+    return HEXL_AMD_OK;
+  }
+  // waits until the DMA that last used slot b is done
+  int slot_free(int b) {
+    if (slot_busy[b]) {
+      HX_HIP(hipEventSynchronize(slot_ev[b]));
+      slot_busy[b] = false;
+    }
+    return HEXL_AMD_OK;
   }
   // pinned + mapped host memory of at least `bytes` (any device may address it: portable)
   int ensure_bounce(size_t bytes) {
@@ -163,6 +206,76 @@ struct Staging {
   }
 };
 thread_local Staging g_staging;
+
+// "host_direct_copy": 0 (default) = copies between ordinary host memory and the device go through
+// the calling thread's pinned slots (staged_h2d / staged_d2h: a host memcpy per MiB overlapped
+// with the DMA of the previous one -- the rate of a memcpy, 10-20 GB/s); 1 = they are handed to
+// hipMemcpyAsync as they are (the link's 54 GB/s from 1 MiB on, with the runtime pinning the
+// caller's pages on the fly: for callers on a runtime they trust).
+std::atomic<u32> g_host_direct_copy{0};
+
+// dst (device) <- src (ordinary host memory), enqueued on st.  Returns when the last chunk has
+// been copied out of src (the DMA of the last two chunks may still be running).
+int staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t st) {
+  Staging& s = g_staging;
+  if (int rc = s.ensure_slots()) return rc;
+  int k = 0;
+  for (size_t off = 0; off < bytes; ++k) {
+    const int b = k & 1;
+    const size_t nb = bytes - off < Staging::kSlotBytes ? bytes - off : Staging::kSlotBytes;
+    if (int rc = s.slot_free(b)) return rc;
+    memcpy(s.slot[b], (const char*)src + off, nb);
+    HX_HIP(hipMemcpyAsync((char*)dst + off, s.slot[b], nb, hipMemcpyHostToDevice, st));
+    HX_HIP(hipEventRecord(s.slot_ev[b], st));
+    s.slot_busy[b] = true;
+    off += nb;
+  }
+  return HEXL_AMD_OK;
+}
+
+// dst (ordinary host memory) <- src (device), after everything enqueued on st so far.
+// Synchronous: the data is in dst on return.
+int staged_d2h(void* dst, const void* src, size_t bytes, hipStream_t st) {
+  Staging& s = g_staging;
+  if (int rc = s.ensure_slots()) return rc;
+  size_t pend_off[2] = {0, 0}, pend_nb[2] = {0, 0};
+  auto drain = [&](int b) -> int {
+    if (pend_nb[b]) {
+      if (int rc = s.slot_free(b)) return rc;
+      memcpy((char*)dst + pend_off[b], s.slot[b], pend_nb[b]);
+      pend_nb[b] = 0;
+    }
+    return HEXL_AMD_OK;
+  };
+  int k = 0;
+  for (size_t off = 0; off < bytes; ++k) {
+    const int b = k & 1;
+    const size_t nb = bytes - off < Staging::kSlotBytes ? bytes - off : Staging::kSlotBytes;
+    if (int rc = drain(b)) return rc;
+    if (int rc = s.slot_free(b)) return rc;  // (still carrying an earlier staged_h2d's chunk)
+    HX_HIP(hipMemcpyAsync(s.slot[b], (const char*)src + off, nb, hipMemcpyDeviceToHost, st));
+    HX_HIP(hipEventRecord(s.slot_ev[b], st));
+    s.slot_busy[b] = true;
+    pend_off[b] = off;
+    pend_nb[b] = nb;
+    off += nb;
+  }
+  if (int rc = drain(k & 1)) return rc;  // the older chunk first
+  return drain((k + 1) & 1);
+}
+
+// One side of a host-pointer call: `host` is caller memory whose first byte is of `kind`
+// (pointer_kind: 0 ordinary host, 1 device, 2 pinned mapped host).
+int copy_to_device(void* dst, const void* host, size_t bytes, int kind, hipStream_t st) {
+  if (kind == 0 && g_host_direct_copy.load() == 0) return staged_h2d(dst, host, bytes, st);
+  HX_HIP(hipMemcpyAsync(dst, host, bytes, hipMemcpyDefault, st));
+  return HEXL_AMD_OK;
+}
+int copy_from_device(void* host, const void* src, size_t bytes, int kind, hipStream_t st) {
+  if (kind == 0 && g_host_direct_copy.load() == 0) return staged_d2h(host, src, bytes, st);
+  HX_HIP(hipMemcpyAsync(host, src, bytes, hipMemcpyDefault, st));
+  return HEXL_AMD_OK;
+}
 
 }  // namespace
 
@@ -299,7 +412,17 @@ int hexl_amd_copy(void* dst, const void* src, uint64_t bytes, void* stream, int 
   if (bytes == 0) return HEXL_AMD_OK;
   if (!dst || !src) return fail(HEXL_AMD_ERR_INVALID_ARG, "dst == nullptr or src == nullptr");
   HX_ON_STREAM_DEVICE(stream);
-  HX_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDefault, (hipStream_t)stream));
+  // ordinary host memory on one side, device memory on the other: through the thread's pinned
+  // slots (the runtime is never handed pageable caller memory; such a copy has always been
+  // synchronous on the host side, and the device-to-host form now completes before it returns)
+  const int kd = pointer_kind(dst, nullptr), ks = pointer_kind(src, nullptr);
+  if (kd == 1 && ks == 0) {
+    if (int rc = copy_to_device(dst, src, (size_t)bytes, 0, (hipStream_t)stream)) return rc;
+  } else if (kd == 0 && ks == 1) {
+    if (int rc = copy_from_device(dst, src, (size_t)bytes, 0, (hipStream_t)stream)) return rc;
+  } else {
+    HX_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDefault, (hipStream_t)stream));
+  }
   if (blocking) HX_HIP(hipStreamSynchronize((hipStream_t)stream));
   return HEXL_AMD_OK;
 }
@@ -379,25 +502,13 @@ int hexl_amd_check_bounds(const uint64_t* data, uint64_t n, uint64_t bound,
 
 }  // extern "C"
 
-// Plan tables go to the device through the calling thread's pinned bounce buffer, 1 MiB at a
-// time: the library never hands its own pageable memory to a large host-to-device copy (from
-// 1 MiB the runtime pins the source pages for the duration of the copy instead of staging them;
-// the round-4 suite aborts all sat in such copies, EXPERIMENTS.md sections 9 and 10).  One-off
-// cost per plan: a memcpy of the tables.
+// Plan tables go to the device through the calling thread's pinned slots like every other copy
+// from pageable memory (staged_h2d): the library never hands its own pageable memory to the
+// runtime either.  One-off cost per plan: a memcpy of the tables.
 static hipError_t upload_table(void* dst, const void* src, size_t bytes, int device) {
-  constexpr size_t kChunk = (size_t)1 << 20;
   if (g_staging.ensure(device, 8) != HEXL_AMD_OK) return hipErrorOutOfMemory;
-  if (g_staging.ensure_bounce(bytes < kChunk ? bytes : kChunk) != HEXL_AMD_OK) return hipErrorOutOfMemory;
-  const size_t chunk = g_staging.bounce_cap < kChunk ? g_staging.bounce_cap : kChunk;
-  for (size_t off = 0; off < bytes; off += chunk) {
-    const size_t nb = bytes - off < chunk ? bytes - off : chunk;
-    memcpy(g_staging.bounce, (const char*)src + off, nb);
-    hipError_t e = hipMemcpyAsync((char*)dst + off, g_staging.bounce, nb, hipMemcpyHostToDevice,
-                                  g_staging.stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(g_staging.stream);
-    if (e != hipSuccess) return e;
-  }
-  return hipSuccess;
+  if (staged_h2d(dst, src, bytes, g_staging.stream) != HEXL_AMD_OK) return hipErrorUnknown;
+  return hipStreamSynchronize(g_staging.stream);
 }
 
 extern "C" {
@@ -873,6 +984,10 @@ static bool set_host_tuning(const char* key, uint64_t value) {
     g_ks_graph = (u32)value;
     return true;
   }
+  if (strcmp(key, "host_direct_copy") == 0 && value <= 1) {
+    g_host_direct_copy = (u32)value;
+    return true;
+  }
   return false;
 }
 
@@ -916,7 +1031,7 @@ static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t*
     u64* d = (u64*)g_staging.buf;
     hipError_t e = launch(d);
     if (e != hipSuccess) return hip_fail(e, "NTT launch");
-    HX_HIP(hipMemcpyAsync(result, d, bytes, hipMemcpyDeviceToHost, st));
+    if (int rc = copy_from_device(result, d, bytes, res_range.first, st)) return rc;
     HX_HIP(hipStreamSynchronize(st));
     return HEXL_AMD_OK;
   }
@@ -937,11 +1052,11 @@ static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t*
   if (int rc = g_staging.ensure(p->device, bytes)) return rc;
   u64* d = (u64*)g_staging.buf;
   hipStream_t st = g_staging.stream;
-  // (hipMemcpyDefault: a mixed argument set -- device operand, host result -- lands here too)
-  HX_HIP(hipMemcpyAsync(d, operand, bytes, hipMemcpyDefault, st));
+  // (a mixed argument set -- device operand, host result -- lands here too: each side by its kind)
+  if (int rc = copy_to_device(d, operand, bytes, op_range.first, st)) return rc;
   hipError_t e = run(d, batch, st);
   if (e != hipSuccess) return hip_fail(e, "NTT launch");
-  HX_HIP(hipMemcpyAsync(result, d, bytes, hipMemcpyDefault, st));
+  if (int rc = copy_from_device(result, d, bytes, res_range.first, st)) return rc;
   HX_HIP(hipStreamSynchronize(st));
   return HEXL_AMD_OK;
 }
@@ -1144,14 +1259,15 @@ static int eltwise_host_run(EltOp op, EltArgs g, uint64_t* result, const uint64_
   u64* da = (u64*)g_staging.buf;
   u64* db = has_b ? da + n : nullptr;
   hipStream_t st = g_staging.stream;
-  HX_HIP(hipMemcpyAsync(da, operand1, bytes, hipMemcpyDefault, st));
-  if (has_b) HX_HIP(hipMemcpyAsync(db, operand2, bytes, hipMemcpyDefault, st));
+  if (int rc = copy_to_device(da, operand1, bytes, ra.first, st)) return rc;
+  if (has_b)
+    if (int rc = copy_to_device(db, operand2, bytes, rb.first, st)) return rc;
   g.result = da;
   g.a = da;
   g.b = db;
   hipError_t e = eltwise_launch(op, g, st);
   if (e != hipSuccess) return hip_fail(e, "eltwise launch");
-  HX_HIP(hipMemcpyAsync(result, da, bytes, hipMemcpyDefault, st));
+  if (int rc = copy_from_device(result, da, bytes, rr.first, st)) return rc;
   HX_HIP(hipStreamSynchronize(st));
   return HEXL_AMD_OK;
 }
@@ -1211,14 +1327,16 @@ int hexl_amd_dyadic_multiply_host(uint64_t* result, const uint64_t* operand1,
   u64* dy = dx + 2 * n * num_moduli;
   u64* dr = dy + 2 * n * num_moduli;
   hipStream_t st = g_staging.stream;
-  HX_HIP(hipMemcpyAsync(dx, operand1, 2 * poly, hipMemcpyHostToDevice, st));
-  HX_HIP(hipMemcpyAsync(dy, operand2, 2 * poly, hipMemcpyHostToDevice, st));
+  const int k1 = pointer_kind(operand1, nullptr), k2 = pointer_kind(operand2, nullptr),
+            kr = pointer_kind(result, nullptr);
+  if (int rc = copy_to_device(dx, operand1, 2 * poly, k1, st)) return rc;
+  if (int rc = copy_to_device(dy, operand2, 2 * poly, k2, st)) return rc;
   // coefficients the reference leaves untouched (n > 512 not a multiple of 512) keep
   // whatever the caller's result buffer holds
-  HX_HIP(hipMemcpyAsync(dr, result, 3 * poly, hipMemcpyHostToDevice, st));
+  if (int rc = copy_to_device(dr, result, 3 * poly, kr, st)) return rc;
   hipError_t e = dyadic_multiply_launch(dr, dx, dy, n, moduli, num_moduli, 1, st);
   if (e != hipSuccess) return hip_fail(e, "dyadic multiply launch");
-  HX_HIP(hipMemcpyAsync(result, dr, 3 * poly, hipMemcpyDeviceToHost, st));
+  if (int rc = copy_from_device(result, dr, 3 * poly, kr, st)) return rc;
   HX_HIP(hipStreamSynchronize(st));
   return HEXL_AMD_OK;
 }
@@ -1578,19 +1696,21 @@ int hexl_amd_key_switch_host(uint64_t* result, const uint64_t* t_target_iter_ptr
   u64* d_tgt = d_res + res_words;
   u64* d_keys = d_tgt + D * n;
   hipStream_t st = g_staging.stream;
-  HX_HIP(hipMemcpyAsync(d_res, result, res_words * sizeof(u64), hipMemcpyHostToDevice, st));
-  HX_HIP(hipMemcpyAsync(d_tgt, t_target_iter_ptr, D * n * sizeof(u64), hipMemcpyHostToDevice, st));
+  const int k_res = pointer_kind(result, nullptr), k_tgt = pointer_kind(t_target_iter_ptr, nullptr);
+  if (int rc = copy_to_device(d_res, result, res_words * sizeof(u64), k_res, st)) return rc;
+  if (int rc = copy_to_device(d_tgt, t_target_iter_ptr, D * n * sizeof(u64), k_tgt, st)) return rc;
   for (u64 j = 0, slot = 0; j < D; ++j) {
     if (kp[j]) continue;
-    HX_HIP(hipMemcpyAsync(d_keys + slot * key_words, k_switch_keys[j], key_words * sizeof(u64),
-                          hipMemcpyHostToDevice, st));
+    if (int rc = copy_to_device(d_keys + slot * key_words, k_switch_keys[j], key_words * sizeof(u64),
+                                pointer_kind(k_switch_keys[j], nullptr), st))
+      return rc;
     kp[j] = d_keys + slot * key_words;
     ++slot;
   }
   if (int rc = key_switch_device(d_res, d_tgt, 1, n, D, K, R, C, moduli, kp.data(),
                                  modswitch_factors, st))
     return rc;
-  HX_HIP(hipMemcpyAsync(result, d_res, res_words * sizeof(u64), hipMemcpyDeviceToHost, st));
+  if (int rc = copy_from_device(result, d_res, res_words * sizeof(u64), k_res, st)) return rc;
   HX_HIP(hipStreamSynchronize(st));
   return HEXL_AMD_OK;
 }

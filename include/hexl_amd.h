@@ -65,13 +65,10 @@ int hexl_amd_pointer_is_device(const void* p);
  * and a multi-pass transform reads its operand there.
  *   hexl_amd_host_alloc / _free        such memory from the runtime (hipHostMalloc, mapped)
  *   hexl_amd_host_register / _unregister  an existing allocation made such (hipHostRegister,
- *                                      mapped): one call over a caller's memory pool.  Register
- *                                      what you keep: a page-aligned range that stays allocated
- *                                      (a pool), not short-lived heap arrays -- with ROCm 7.0,
- *                                      registering, unregistering and freeing a buffer whose
- *                                      address range a later allocation reuses made an unrelated
- *                                      large pageable copy abort inside the runtime about once in
- *                                      a dozen test-suite runs (EXPERIMENTS.md section 9)
+ *                                      mapped): one call over a caller's memory pool.  _unregister
+ *                                      waits for every device first (nothing may still be using the
+ *                                      mapping).  Any range may be registered -- a pool that stays
+ *                                      allocated is what pays, since registering costs ~100 us
  *   hexl_amd_pointer_kind              0 ordinary host, 1 device / managed, 2 mapped host
  * include/hexl/util/device-mapped-allocator.hpp wraps the first pair as an
  * intel::hexl::AllocatorBase (allocator.hpp:12-51) for AlignedVector64 data buffers. */
@@ -89,7 +86,10 @@ int hexl_amd_pointer_kind(const void* p);
  *   hexl_amd_device_free
  *   hexl_amd_copy           dst <- src, `bytes`; each side may be host, mapped or device memory
  *                           (the direction is detected); enqueued on `stream` (NULL: the default
- *                           stream) and complete on return when `blocking` is non-zero
+ *                           stream) and complete on return when `blocking` is non-zero.  Ordinary
+ *                           (pageable) host memory goes through the thread's pinned slots: src
+ *                           may be reused on return, and a copy INTO such memory is complete on
+ *                           return whatever `blocking` says
  *   hexl_amd_synchronize    waits for everything enqueued on `stream` (NULL: the whole device) */
 int hexl_amd_device_alloc(void** p, uint64_t bytes, int device);
 int hexl_amd_device_free(void* p);
@@ -476,6 +476,13 @@ int hexl_amd_profile_get(int i, const char** name, float* ms);
  *   "host_bounce_kb"   largest host-pointer call (KiB of operand) that runs on the per-thread
  *                      pinned, device-mapped bounce buffer instead of staged copies (default 256;
  *                      0 = never)
+ *   "host_direct_copy" 0 (default) = the *_host entry points and hexl_amd_copy move ordinary (pageable)
+ *                      caller memory through the calling thread's two pinned 1 MiB slots, a host
+ *                      memcpy per slot overlapped with the DMA of the other (the runtime is never
+ *                      handed pageable caller memory: from about 1 MiB it pins the caller's pages
+ *                      for the copy, the path the GPU memory access faults of rounds 4 and 5 sat
+ *                      in, EXPERIMENTS.md section 10); 1 = such buffers go to hipMemcpyAsync whole
+ *                      (the link's rate instead of a memcpy's from 1 MiB on)
  *   "ks_graph"         1 (default) = hexl_amd_key_switch / _host / _batch calls of at most four
  *                      targets whose buffers, keys and moduli were seen before on the same stream
  *                      are replayed from a HIP graph captured at their second sight (one graph

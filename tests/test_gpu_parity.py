@@ -517,6 +517,63 @@ def test_host_pointer_paths_on_ordinary_memory(hx, ho, n, batch, bits):
     assert np.array_equal(a, ho.eltwise_fma_mod(x.reshape(-1), 7, None, q, 1))
 
 
+@pytest.mark.parametrize("direct", [0, 1])
+def test_host_pointer_paths_above_one_mebibyte(hx, ho, direct):
+    """Host-pointer calls whose buffers exceed one pinned slot (1 MiB): by default the library
+    copies ordinary caller memory through its own two pinned slots, chunk by chunk, in both
+    directions ("host_direct_copy" 0: the HIP runtime never gets to pin the caller's pages, the
+    path the suite's GPU memory access faults sat in); with the key at 1 the buffers go to
+    hipMemcpyAsync whole.  Ragged sizes (not a multiple of the slot), in place and out of place,
+    NTT / element-wise / DyadicMultiply / hexl_amd_copy, against the oracle."""
+    import ctypes as C
+    lib = hx.lib
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    hx.set_tuning("host_direct_copy", direct)
+    try:
+        for n, batch in ((131072, 1), (65536, 5), (4096, 200)):  # 1 MiB, 2.5 MiB, 6.25 MiB
+            q = ho.generate_primes(1, 54, True, n)[0]
+            ntt, ont = hx.NTT(n, q), ho.NTT(n, q)
+            x = np.stack([ho.fill_splitmix(n, 40 + b, q) for b in range(batch)])
+            rows = sorted({0, batch // 2, batch - 1})
+            want = ont.forward(x[rows], 1, 1)
+            src, dst = x.copy(), np.zeros_like(x)
+            assert lib.hexl_amd_ntt_forward_host(ntt._h, p(dst), p(src), batch, 1, 1) == 0
+            assert np.array_equal(dst[rows], want) and np.array_equal(src, x)
+            assert lib.hexl_amd_ntt_inverse_host(ntt._h, p(dst), p(dst), batch, 1, 1) == 0  # in place
+            assert np.array_equal(dst, x)
+        # element-wise MultMod over 3 MiB + 8 bytes per operand
+        q = ho.generate_primes(1, 58, True, 2)[0]
+        m = (3 << 17) + 1
+        a, b = ho.fill_splitmix(m, 1, q), ho.fill_splitmix(m, 2, q)
+        r = np.zeros_like(a)
+        assert lib.hexl_amd_eltwise_host(4, p(r), p(a), p(b), 0, m, q, 1, 1) == 0
+        assert np.array_equal(r, ho.eltwise_mult_mod(a, b, q, 1))
+        # DyadicMultiply: operands 2 x (n x k) words = 1.5 MiB each, result 2.25 MiB, in place on x
+        n, k = 32768, 3
+        moduli = [int(v) for v in ho.generate_primes(k, 50, True, n)]
+        xs = np.concatenate([ho.fill_splitmix(n, 10 + i, moduli[i % k]) for i in range(2 * k)])
+        ys = np.concatenate([ho.fill_splitmix(n, 20 + i, moduli[i % k]) for i in range(2 * k)])
+        want = ho.dyadic_multiply(xs, ys, n, moduli)
+        out = np.zeros(3 * n * k, dtype=np.uint64)
+        mod = (C.c_uint64 * k)(*moduli)
+        assert lib.hexl_amd_dyadic_multiply_host(p(out), p(xs), p(ys), n, mod, k) == 0
+        assert np.array_equal(out, want)
+        # hexl_amd_copy: pageable -> device -> pageable, 2.5 MiB + 8 bytes, non-blocking calls
+        z = np.arange((5 << 16) + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        back = np.zeros_like(z)
+        d = C.c_void_p()
+        assert lib.hexl_amd_device_alloc(C.byref(d), z.nbytes, -1) == 0
+        st = C.c_void_p()
+        assert lib.hexl_amd_stream_create(C.byref(st), -1) == 0
+        assert lib.hexl_amd_copy(d, p(z), z.nbytes, st, 0) == 0
+        assert lib.hexl_amd_copy(p(back), d, z.nbytes, st, 0) == 0
+        assert lib.hexl_amd_synchronize(st) == 0
+        assert np.array_equal(back, z)
+        assert lib.hexl_amd_stream_destroy(st) == 0 and lib.hexl_amd_device_free(d) == 0
+    finally:
+        hx.set_tuning("host_direct_copy", 0)
+
+
 def test_ntt_config1_on_the_hip_path(hx, ho):
     """BASELINE configs[0] at its exact parameters on the GPU: N = 1024, q = 0xffffee001
     (36-bit), ONE polynomial, seed 1, Fwd(1,1) + Inv(1,1) against the oracle; the plan picks

@@ -29,20 +29,25 @@ for bits, small in ((56, True), (57, False), (58, True), (58, False)):
         for _ in range(25):
             step()
         torch.cuda.synchronize()
+        # the step (HIP events around 30 steps) and its kernels (the library's launch profiler:
+        # an event pair per launch) in the SAME 30 steps, so that the kernel columns sum to the
+        # step up to the launch gaps (round 4 profiled 5 separate steps after the timed ones: a
+        # different pass of the box, and its columns did not add up)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        hx.profile_start(8 * 30 + 16)
         e0.record()
         for _ in range(30):
             step()
         e1.record()
         torch.cuda.synchronize()
+        records = hx.profile_stop()
         assert torch.equal(ref, x[:1])
-        hx.profile_start(128)
-        for _ in range(5):
-            step()
         agg = {}
-        for k, v in hx.profile_stop():
+        for k, v in records:
             agg.setdefault(k.replace("ntt_", "").replace("_pass", "").replace("_bottom", ""), []).append(v)
-        rows.append((name, e0.elapsed_time(e1) / 30, {k: round(sum(v) / len(v), 3) for k, v in agg.items()}))
+        kern = {k: round(sum(v) / 30, 3) for k, v in agg.items()}
+        kern["sum"] = round(sum(sum(v) for v in agg.values()) / 30, 3)
+        rows.append((name, e0.elapsed_time(e1) / 30, kern))
     hx.set_tuning("lazy_family", 1)
     hx.set_tuning("h60", 1)
     print(f"N={N} batch={B} q={q} ({q.bit_length()} bits, 2^63/q = {(1 << 63) // q}):")

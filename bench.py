@@ -56,9 +56,9 @@ HBM_ACHIEVABLE_GBPS = 6290.0  # same guide: 6.29 TB/s measured with a float4 cop
 # per wave, shader clock): collected with rocprofv3 --pmc by tools/collect_profiles.sh, written
 # by tools/summarize_profiles.py together with a hash of the kernel sources they were measured
 # on.  They are NOT collected in this run; a profile of other sources is not reported.
-COUNTER_PROFILE = "r4_counters.json"
+COUNTER_PROFILE = "r5_counters.json"
 KERNEL_SOURCES = ("ntt_kernels.hip", "modarith.h", "lazy_inverse.h", "tile_geometry.h", "internal.h")
-# what keeps each kernel family below the HBM roofline (profiles/r4_pmc_summary.md)
+# what keeps each kernel family below the HBM roofline (profiles/r5_pmc_summary.md)
 KERNEL_LIMITER = {"ntt_fwd_strided_pass": "hbm", "ntt_inv_strided_pass": "hbm",
                   "ntt_fwd_tile_pass_bottom": "valu-issue + latency",
                   "ntt_inv_tile_pass_bottom": "valu-issue + latency"}

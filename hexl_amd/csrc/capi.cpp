@@ -112,7 +112,12 @@ struct Staging {
   static constexpr size_t kSlotBytes = (size_t)1 << 20;
   void* slot[2] = {nullptr, nullptr};
   hipEvent_t slot_ev[2] = {nullptr, nullptr};
-  bool slot_busy[2] = {false, false};
+  // A slot is free, or in use by a DMA whose end is marked by its event (chunks in the middle of
+  // a pipeline) or simply by everything enqueued on a stream so far (the last chunk of a call:
+  // the caller synchronises that stream anyway, no event needed).
+  enum SlotState { kSlotFree = 0, kSlotEvent = 1, kSlotStream = 2 };
+  SlotState slot_state[2] = {kSlotFree, kSlotFree};
+  hipStream_t slot_stream[2] = {nullptr, nullptr};
   int slot_device = -1;  // the device the events belong to
   // A thread that ends gives its buffer and streams back (callers that run every task on
   // a fresh std::thread would otherwise leak one staging area per task).  Thread-local
@@ -132,10 +137,8 @@ struct Staging {
     if (buf) (void)hipFree(buf);
     if (bounce) (void)hipHostFree(bounce);
     for (int b = 0; b < 2; ++b) {
-      if (slot_ev[b]) {
-        if (slot_busy[b]) (void)hipEventSynchronize(slot_ev[b]);
-        (void)hipEventDestroy(slot_ev[b]);
-      }
+      (void)slot_free(b);
+      if (slot_ev[b]) (void)hipEventDestroy(slot_ev[b]);
       if (slot[b]) (void)hipHostFree(slot[b]);
     }
     if (stream) (void)hipStreamDestroy(stream);
@@ -147,8 +150,7 @@ struct Staging {
     for (int b = 0; b < 2; ++b) {
       if (!slot[b]) HX_HIP(hipHostMalloc(&slot[b], kSlotBytes, hipHostMallocPortable));
       if (slot_ev[b] && slot_device != dev) {  // an event records on streams of its own device only
-        if (slot_busy[b]) (void)hipEventSynchronize(slot_ev[b]);
-        slot_busy[b] = false;
+        (void)slot_free(b);
         (void)hipEventDestroy(slot_ev[b]);
         slot_ev[b] = nullptr;
       }
@@ -157,11 +159,24 @@ struct Staging {
     slot_device = dev;
     return HEXL_AMD_OK;
   }
-  // waits until the DMA that last used slot b is done
+  // waits until the DMA that last used slot b is done (the host may then read or write it)
   int slot_free(int b) {
-    if (slot_busy[b]) {
-      HX_HIP(hipEventSynchronize(slot_ev[b]));
-      slot_busy[b] = false;
+    const SlotState was = slot_state[b];
+    slot_state[b] = kSlotFree;
+    if (was == kSlotEvent) HX_HIP(hipEventSynchronize(slot_ev[b]));
+    if (was == kSlotStream) HX_HIP(hipStreamSynchronize(slot_stream[b]));
+    return HEXL_AMD_OK;
+  }
+  // marks slot b in use by the DMA just enqueued on st; `last`: no more chunks follow in this call
+  int slot_used(int b, hipStream_t st, bool last) {
+    slot_stream[b] = st;
+    // (only the thread's own staging stream: a caller's stream may be gone by the time the
+    // slot is wanted again, an event outlives its stream)
+    if (last && st == stream) {
+      slot_state[b] = kSlotStream;
+    } else {
+      HX_HIP(hipEventRecord(slot_ev[b], st));
+      slot_state[b] = kSlotEvent;
     }
     return HEXL_AMD_OK;
   }
@@ -182,6 +197,8 @@ struct Staging {
     if (device != dev) {
       if (device >= 0 && (buf || stream)) {  // release what belongs to the previous device
         if (hipSetDevice(device) == hipSuccess) {
+          (void)slot_free(0);
+          (void)slot_free(1);
           if (stream) (void)hipStreamSynchronize(stream);
                 if (stream) release_stream_workspaces(stream);
             if (buf) (void)hipFree(buf);
@@ -223,12 +240,11 @@ int staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t st) {
   for (size_t off = 0; off < bytes; ++k) {
     const int b = k & 1;
     const size_t nb = bytes - off < Staging::kSlotBytes ? bytes - off : Staging::kSlotBytes;
-    if (int rc = s.slot_free(b)) return rc;
+    if (int rc = s.slot_free(b)) return rc;  // the host is about to write the slot
     memcpy(s.slot[b], (const char*)src + off, nb);
     HX_HIP(hipMemcpyAsync((char*)dst + off, s.slot[b], nb, hipMemcpyHostToDevice, st));
-    HX_HIP(hipEventRecord(s.slot_ev[b], st));
-    s.slot_busy[b] = true;
     off += nb;
+    if (int rc = s.slot_used(b, st, off == bytes)) return rc;
   }
   return HEXL_AMD_OK;
 }
@@ -252,13 +268,15 @@ int staged_d2h(void* dst, const void* src, size_t bytes, hipStream_t st) {
     const int b = k & 1;
     const size_t nb = bytes - off < Staging::kSlotBytes ? bytes - off : Staging::kSlotBytes;
     if (int rc = drain(b)) return rc;
-    if (int rc = s.slot_free(b)) return rc;  // (still carrying an earlier staged_h2d's chunk)
+    // the DEVICE is about to write the slot: a DMA still reading it on this very stream (an
+    // earlier staged_h2d of the same call) is ordered before it by the stream itself
+    if (s.slot_state[b] != Staging::kSlotFree && s.slot_stream[b] != st)
+      if (int rc = s.slot_free(b)) return rc;
     HX_HIP(hipMemcpyAsync(s.slot[b], (const char*)src + off, nb, hipMemcpyDeviceToHost, st));
-    HX_HIP(hipEventRecord(s.slot_ev[b], st));
-    s.slot_busy[b] = true;
     pend_off[b] = off;
     pend_nb[b] = nb;
     off += nb;
+    if (int rc = s.slot_used(b, st, off == bytes)) return rc;
   }
   if (int rc = drain(k & 1)) return rc;  // the older chunk first
   return drain((k + 1) & 1);

@@ -840,9 +840,11 @@ def main():
     kern_avg = {k: sum(v) / len(v) for k, v in kern.items()}
     kern_med = {k: median(v) for k, v in kern.items()}
     dominant = max(kern_avg, key=lambda k: kern_avg[k] * len(kern[k]))
-    # a launch of rank 0 covers the polynomials of one of its segments; each kernel reads and
-    # writes every polynomial once
-    alg_bytes = 16.0 * N * segments[0][2]
+    # a launch of rank 0 covers the polynomials of one of its segments -- or, where the shard is
+    # several whole primes, all of them (the RNS entry point is one multi-plan launch sequence);
+    # each kernel reads and writes every polynomial once
+    whole_primes = len(segments) > 1 and all(c == segments[0][2] for _, _, c in segments)
+    alg_bytes = 16.0 * N * (my_polys if whole_primes else segments[0][2])
     achieved = alg_bytes / (kern_avg[dominant] * 1e-3) / 1e9
     # a TRANSFORM is two launches (two HBM round trips above N = 2^14): its algorithmic bytes
     # over the time of both kernels -- the figure the per-launch fraction does not show

@@ -840,11 +840,11 @@ def main():
     kern_avg = {k: sum(v) / len(v) for k, v in kern.items()}
     kern_med = {k: median(v) for k, v in kern.items()}
     dominant = max(kern_avg, key=lambda k: kern_avg[k] * len(kern[k]))
-    # a launch of rank 0 covers the polynomials of one of its segments -- or, where the shard is
-    # several whole primes, all of them (the RNS entry point is one multi-plan launch sequence);
-    # each kernel reads and writes every polynomial once
-    whole_primes = len(segments) > 1 and all(c == segments[0][2] for _, _, c in segments)
-    alg_bytes = 16.0 * N * (my_polys if whole_primes else segments[0][2])
+    # a launch of rank 0 covers the polynomials of one of its segments (a shard of several whole
+    # primes goes through the RNS entry point, which at this batch size launches prime by prime:
+    # checked on the two-rank dry run, 4096 polynomials per launch); each kernel reads and
+    # writes every polynomial once
+    alg_bytes = 16.0 * N * segments[0][2]
     achieved = alg_bytes / (kern_avg[dominant] * 1e-3) / 1e9
     # a TRANSFORM is two launches (two HBM round trips above N = 2^14): its algorithmic bytes
     # over the time of both kernels -- the figure the per-launch fraction does not show
@@ -966,6 +966,12 @@ def main():
                 "achievable_GBps": HBM_ACHIEVABLE_GBPS,
                 "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBPS,
                 "two_pass_ceiling_frac": HBM_ACHIEVABLE_GBPS / 2 / HBM_PEAK_GBPS,
+                # the same fraction from the committed rocprofv3 trace of these kernel sources (its
+                # average launch of the dominant kernel, a 10-step run that starts from an idle
+                # GPU: a few per cent slower than the events of this run's timed region)
+                "frac_by_committed_rocprof_trace": (
+                    alg_bytes / ((counters.get(dominant) or {}).get("traced_avg_ms") * 1e-3) / 1e9 / HBM_PEAK_GBPS
+                    if (counters.get(dominant) or {}).get("traced_avg_ms") else None),
                 "copy_GBps_measured": copy_gbps,
                 "frac_of_measured_copy": (achieved / copy_gbps) if copy_gbps else None,
                 "algorithmic_bytes_per_launch": alg_bytes,

@@ -67,8 +67,13 @@ int hexl_amd_pointer_is_device(const void* p);
  *   hexl_amd_host_register / _unregister  an existing allocation made such (hipHostRegister,
  *                                      mapped): one call over a caller's memory pool.  _unregister
  *                                      waits for every device first (nothing may still be using the
- *                                      mapping).  Any range may be registered -- a pool that stays
- *                                      allocated is what pays, since registering costs ~100 us
+ *                                      mapping).  Register what you keep -- a pool that stays
+ *                                      allocated -- rather than short-lived heap arrays: it costs
+ *                                      ~100 us a time, and a process that registered heap arrays AND
+ *                                      handed pageable memory to hipMemcpy aborted with a GPU memory
+ *                                      access fault about once in twenty test-suite runs (what sets
+ *                                      it up was not isolated: EXPERIMENTS.md section 10; the library
+ *                                      itself no longer makes such copies)
  *   hexl_amd_pointer_kind              0 ordinary host, 1 device / managed, 2 mapped host
  * include/hexl/util/device-mapped-allocator.hpp wraps the first pair as an
  * intel::hexl::AllocatorBase (allocator.hpp:12-51) for AlignedVector64 data buffers. */

@@ -65,15 +65,17 @@ int hexl_amd_pointer_is_device(const void* p);
  * and a multi-pass transform reads its operand there.
  *   hexl_amd_host_alloc / _free        such memory from the runtime (hipHostMalloc, mapped)
  *   hexl_amd_host_register / _unregister  an existing allocation made such (hipHostRegister,
- *                                      mapped): one call over a caller's memory pool.  _unregister
- *                                      waits for every device first (nothing may still be using the
- *                                      mapping).  Register what you keep -- a pool that stays
- *                                      allocated -- rather than short-lived heap arrays: it costs
- *                                      ~100 us a time, and a process that registered heap arrays AND
- *                                      handed pageable memory to hipMemcpy aborted with a GPU memory
- *                                      access fault about once in twenty test-suite runs (what sets
- *                                      it up was not isolated: EXPERIMENTS.md section 10; the library
- *                                      itself no longer makes such copies)
+ *                                      mapped): one call over a caller's memory pool.  Only the WHOLE
+ *                                      4 KiB PAGES INSIDE [p, p + bytes) are registered: the runtime
+ *                                      works page by page, and a page shared with a neighbouring
+ *                                      allocation must never be pinned and unpinned under it (with
+ *                                      ROCm 7.0.2 that is a GPU memory access fault waiting for the
+ *                                      neighbour's next pageable copy: EXPERIMENTS.md section 10).
+ *                                      Buffers that touch the unregistered edge fragments are staged
+ *                                      like ordinary memory; page-align the pool to lose nothing.
+ *                                      _unregister takes the same p, waits for every device first
+ *                                      (nothing may still be using the mapping) and fails for a p
+ *                                      that was not registered; registering twice fails
  *   hexl_amd_pointer_kind              0 ordinary host, 1 device / managed, 2 mapped host
  * include/hexl/util/device-mapped-allocator.hpp wraps the first pair as an
  * intel::hexl::AllocatorBase (allocator.hpp:12-51) for AlignedVector64 data buffers. */

@@ -371,6 +371,9 @@ static RangeKind classify_range(const void* p, size_t bytes) {
     if (kl != r.kind || (char*)last - (char*)r.alias != (ptrdiff_t)(bytes - 1)) {
       r.kind = 0;
       r.alias = nullptr;
+      // (starts in mapped host memory and leaves it: host memory all the same -- the copies
+      // treat it as ordinary, i.e. it goes through the pinned slots like any pageable buffer)
+      if (r.first == 2) r.first = 0;
     }
   }
   return r;
@@ -391,63 +394,13 @@ int hexl_amd_host_free(void* p) {
   HX_HIP(hipHostFree(p));
   return HEXL_AMD_OK;
 }
-// Registered ranges: caller's (p, bytes) -> the whole pages inside it that were handed to the runtime.
-// Only pages that lie ENTIRELY inside the caller's range are registered.  The runtime registers
-// page-granular: handed a range that starts or ends inside a page it pins and maps that whole page,
-// and unregistering it takes the page's mapping away again -- also from whatever else lives in that
-// page.  With ROCm 7.0.2 (the user-mode stack torch bundles) that is how a process faults: a heap
-// array that shares its first or last page with a registered one is pinned by the runtime for an
-// asynchronous pageable copy, the registered neighbour is unregistered, and the next copy of the
-// first array -- the runtime caches its pins -- reads or writes a page that is no longer mapped
-// ("Memory access fault by GPU node ... Write access to a read-only page" / "Reason: Unknown";
-// reproduced without this library: tools/register_then_pageable_copy_soak.py --register raw,
-// EXPERIMENTS.md section 10).  The edge fragments stay ordinary memory: a buffer that touches
-// them is staged like any unregistered one (classify_range), everything inside runs zero-copy.
-namespace {
-struct Registered {
-  void* inner = nullptr;
-  size_t inner_bytes = 0;
-};
-std::mutex g_registered_mu;
-std::map<const void*, Registered>& registered_table() {
-  static auto* t = new std::map<const void*, Registered>;
-  return *t;
-}
-}  // namespace
-
 int hexl_amd_host_register(void* p, uint64_t bytes) {
   if (!p || bytes == 0) return fail(HEXL_AMD_ERR_INVALID_ARG, "p == nullptr or bytes == 0");
-  const uintptr_t page = 4096;  // (the GPU's registration granule; the host's pages are no smaller)
-  const uintptr_t lo = ((uintptr_t)p + page - 1) & ~(page - 1);
-  const uintptr_t hi = ((uintptr_t)p + (uintptr_t)bytes) & ~(page - 1);
-  Registered r;
-  if (hi > lo) {
-    r.inner = (void*)lo;
-    r.inner_bytes = (size_t)(hi - lo);
-  }
-  {
-    std::lock_guard<std::mutex> lock(g_registered_mu);
-    if (registered_table().count(p))
-      return fail(HEXL_AMD_ERR_INVALID_ARG, "%p is registered already", p);
-  }
-  if (r.inner_bytes)
-    HX_HIP(hipHostRegister(r.inner, r.inner_bytes, hipHostRegisterMapped | hipHostRegisterPortable));
-  std::lock_guard<std::mutex> lock(g_registered_mu);
-  registered_table()[p] = r;
+  HX_HIP(hipHostRegister(p, (size_t)bytes, hipHostRegisterMapped | hipHostRegisterPortable));
   return HEXL_AMD_OK;
 }
 int hexl_amd_host_unregister(void* p) {
   if (!p) return HEXL_AMD_OK;
-  Registered r;
-  {
-    std::lock_guard<std::mutex> lock(g_registered_mu);
-    auto it = registered_table().find(p);
-    if (it == registered_table().end())
-      return fail(HEXL_AMD_ERR_INVALID_ARG, "%p was not registered with hexl_amd_host_register", p);
-    r = it->second;
-    registered_table().erase(it);
-  }
-  if (!r.inner_bytes) return HEXL_AMD_OK;
   // Nothing may still be reading or writing the range when its device mapping goes away: the
   // *_host entry points return only after their own work is done, but the caller may have handed
   // the mapped alias to kernels or copies of its own on any stream of any device.
@@ -457,7 +410,7 @@ int hexl_amd_host_unregister(void* p) {
       if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
     (void)hipSetDevice(cur);
   }
-  HX_HIP(hipHostUnregister(r.inner));
+  HX_HIP(hipHostUnregister(p));
   return HEXL_AMD_OK;
 }
 

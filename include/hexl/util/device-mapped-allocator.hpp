@@ -25,9 +25,7 @@ namespace hexl {
 /// Pinned, device-mapped host memory (throws std::runtime_error on failure / without a GPU).
 void* DeviceMappedAllocate(size_t bytes);
 void DeviceMappedFree(void* p) noexcept;
-/// Pins and maps the whole 4 KiB pages inside [p, p + bytes) -- memory the caller already owns;
-/// page-align the pool to lose nothing (buffers touching an unregistered edge fragment are
-/// staged like ordinary memory).  Unregister with the same p.
+/// Pins and maps [p, p + bytes) -- memory the caller already owns.
 void RegisterHostMemory(void* p, size_t bytes);
 void UnregisterHostMemory(void* p) noexcept;
 

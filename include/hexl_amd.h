@@ -65,17 +65,19 @@ int hexl_amd_pointer_is_device(const void* p);
  * and a multi-pass transform reads its operand there.
  *   hexl_amd_host_alloc / _free        such memory from the runtime (hipHostMalloc, mapped)
  *   hexl_amd_host_register / _unregister  an existing allocation made such (hipHostRegister,
- *                                      mapped): one call over a caller's memory pool.  Only the WHOLE
- *                                      4 KiB PAGES INSIDE [p, p + bytes) are registered: the runtime
- *                                      works page by page, and a page shared with a neighbouring
- *                                      allocation must never be pinned and unpinned under it (with
- *                                      ROCm 7.0.2 that is a GPU memory access fault waiting for the
- *                                      neighbour's next pageable copy: EXPERIMENTS.md section 10).
- *                                      Buffers that touch the unregistered edge fragments are staged
- *                                      like ordinary memory; page-align the pool to lose nothing.
- *                                      _unregister takes the same p, waits for every device first
- *                                      (nothing may still be using the mapping) and fails for a p
- *                                      that was not registered; registering twice fails
+ *                                      mapped): one call over a caller's memory pool.  _unregister
+ *                                      waits for every device first (nothing may still be using the
+ *                                      mapping).  REGISTER MAPPINGS YOU OWN -- a page-aligned pool
+ *                                      from mmap / an aligned allocator that you keep, or unmap
+ *                                      after unregistering -- NOT sub-allocations of the malloc heap:
+ *                                      on the HIP runtime torch 2.10 bundles (ROCm 7.0.2) a process
+ *                                      that registers and unregisters heap arrays and later lets the
+ *                                      runtime copy pageable memory from / to re-used heap pages
+ *                                      (hipMemcpyAsync, torch.Tensor.to) dies of a GPU memory access
+ *                                      fault; reproduced without this library in seconds by
+ *                                      tools/register_then_pageable_copy_soak.py --register raw
+ *                                      (EXPERIMENTS.md section 10).  The library's own copies of
+ *                                      pageable memory go through pinned slots and are not affected
  *   hexl_amd_pointer_kind              0 ordinary host, 1 device / managed, 2 mapped host
  * include/hexl/util/device-mapped-allocator.hpp wraps the first pair as an
  * intel::hexl::AllocatorBase (allocator.hpp:12-51) for AlignedVector64 data buffers. */

@@ -453,60 +453,32 @@ def test_pointer_kinds_and_zero_copy_host_path(hx, ho):
 
 
 def test_short_lived_registration_then_large_pageable_copies(hx, ho):
-    """The lifetime pattern behind the suite's one-in-twenty abort (a GPU memory access fault in the HIP
-    runtime: EXPERIMENTS.md section 10), kept as a regression test: short-lived heap arrays are
-    registered (hexl_amd_host_register), transformed in place over the link, unregistered and freed
-    while other heap arrays are alive around them; then large copies from fresh allocations (a
-    plan's table upload, a staged *_host call, from_numpy / to_numpy).  The library registers only
-    the whole pages INSIDE the caller's range (a page shared with a neighbouring allocation is never
-    handed to the runtime) and moves pageable memory through its own pinned slots.
-    tools/register_then_pageable_copy_soak.py is the amplified form, tests/cpp/register_abort_repro.cpp
-    the C++ one."""
+    """The lifetime pattern behind round 4's one-in-eleven abort of this suite, restored as a
+    regression test: a short-lived heap array is registered (hexl_amd_host_register), transformed
+    in place over the link, unregistered and freed; the next allocations reuse its address range
+    and go through >= 1 MiB pageable host-to-device copies (a plan's table upload, a staged *_host
+    call, the caller's own copy).  tests/cpp/register_abort_repro.cpp is the standalone form."""
     import ctypes as C
     lib = hx.lib
-    neighbours = []
     for n, bits in ((4096, 49), (8192, 54), (65536, 54), (65536, 54)):
         q = ho.generate_primes(1, bits, True, n)[0]
         ntt, ont = hx.NTT(n, q), ho.NTT(n, q)
         x = ho.fill_splitmix(n, 5 + n, q)
         want = ont.forward(x, 1, 1)
-        neighbours.append(np.arange(3 << 16, dtype=np.uint64))  # live heap arrays around the buffer
-        raw = np.zeros(2 * n + 1024, dtype=np.uint64)           # short-lived, NOT page aligned
-        neighbours.append(np.arange(1 << 17, dtype=np.uint64))
-        praw = raw.ctypes.data_as(C.c_void_p)
-        assert lib.hexl_amd_host_register(praw, raw.nbytes) == 0
-        assert lib.hexl_amd_host_register(praw, raw.nbytes) != 0  # once
+        buf = np.zeros(2 * n, dtype=np.uint64)  # short-lived; 1 MiB at n = 65536
+        buf[:n] = x
+        pb = buf.ctypes.data_as(C.c_void_p)
+        assert lib.hexl_amd_host_register(pb, buf.nbytes) == 0
         try:
-            off = ((-raw.ctypes.data) % 4096) // 8
-            buf = raw[off:off + 2 * n]                           # a page-aligned view inside it
-            buf[:n] = x
-            pb = buf.ctypes.data_as(C.c_void_p)
             assert lib.hexl_amd_pointer_kind(pb) == 2
-            if off:  # the edge fragment before the first whole page stays ordinary memory
-                assert lib.hexl_amd_pointer_kind(praw) == 0
             po = C.c_void_p(pb.value + n * 8)
-            assert lib.hexl_amd_ntt_forward_host(ntt._h, po, pb, 1, 1, 1) == 0  # zero-copy
+            assert lib.hexl_amd_ntt_forward_host(ntt._h, po, pb, 1, 1, 1) == 0
             assert np.array_equal(buf[n:], want)
-            # a buffer that starts in the unregistered edge is staged, same bits
-            edge = raw[:n]
-            edge[:] = x
-            out = np.zeros(n, dtype=np.uint64)
-            assert lib.hexl_amd_ntt_forward_host(ntt._h, out.ctypes.data_as(C.c_void_p),
-                                                 edge.ctypes.data_as(C.c_void_p), 1, 1, 1) == 0
-            assert np.array_equal(out, want)
         finally:
-            assert lib.hexl_amd_host_unregister(praw) == 0
+            assert lib.hexl_amd_host_unregister(pb) == 0
         assert lib.hexl_amd_pointer_kind(pb) == 0
-        assert lib.hexl_amd_host_unregister(praw) != 0  # not registered any more
-        del raw, buf, edge, pb, po, praw
-    # a range without a whole page inside it registers nothing and stays ordinary memory
-    tiny = np.zeros(64, dtype=np.uint64)
-    pt = tiny.ctypes.data_as(C.c_void_p)
-    if (tiny.ctypes.data % 4096) + tiny.nbytes < 8192 and tiny.ctypes.data % 4096:
-        assert lib.hexl_amd_host_register(pt, tiny.nbytes) == 0
-        assert lib.hexl_amd_pointer_kind(pt) == 0
-        assert lib.hexl_amd_host_unregister(pt) == 0
-    # what followed in the runs that died: large copies from fresh allocations
+        del buf, pb, po
+    # what followed in the runs that died: large pageable copies from fresh allocations
     n2 = 131072
     q2 = ho.generate_primes(1, 54, True, n2)[0]
     big = hx.NTT(n2, q2)  # 2 x 2 MiB table upload
@@ -515,8 +487,34 @@ def test_short_lived_registration_then_large_pageable_copies(hx, ho):
     p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
     assert lib.hexl_amd_ntt_forward_host(big._h, p(dst), p(src), 1, 1, 1) == 0  # staged, 1 MiB
     assert np.array_equal(dst, ho.NTT(n2, q2).forward(y, 1, 1))
-    for z in neighbours:  # 1 - 1.5 MiB each, alive since before the registrations
-        assert np.array_equal(host(hx, dev(hx, z)), z)
+    z = np.arange(3 << 16, dtype=np.uint64)  # 1.5 MiB through the caller's own copy
+    assert np.array_equal(host(hx, dev(hx, z)), z)
+
+
+@pytest.mark.parametrize("n,batch,bits", [(4096, 1, 49), (4096, 8, 54), (16384, 2, 54), (16384, 3, 54),
+                                          (32768, 1, 54), (65536, 1, 54), (1024, 1, 35), (64, 3, 40)])
+def test_host_pointer_paths_on_ordinary_memory(hx, ho, n, batch, bits):
+    """The *_host entry points on ordinary (pageable) host memory, both sides of the 256 KiB
+    bounce-buffer threshold -- one-kernel and two-pass plans in place on the pinned mapped bounce
+    buffer below it, staged H2D / D2H above -- in place and out of place, against the oracle."""
+    import ctypes as C
+    q = ho.generate_primes(1, bits, True, n)[0]
+    ntt, ont = hx.NTT(n, q), ho.NTT(n, q)
+    x = np.stack([ho.fill_splitmix(n, 900 + b, q) for b in range(batch)])
+    want = ont.forward(x, 1, 1)
+    src, dst = x.copy(), np.zeros_like(x)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    assert hx.lib.hexl_amd_ntt_forward_host(ntt._h, p(dst), p(src), batch, 1, 1) == 0
+    assert np.array_equal(dst, want) and np.array_equal(src, x)
+    assert hx.lib.hexl_amd_ntt_inverse_host(ntt._h, p(dst), p(dst), batch, 1, 1) == 0  # in place
+    assert np.array_equal(dst, x)
+    # element-wise: MultMod (op 4) and FMAMod with a null addend (op 5), out of place / in place
+    a, b = x.reshape(-1).copy(), want.reshape(-1).copy()
+    r = np.zeros_like(a)
+    assert hx.lib.hexl_amd_eltwise_host(4, p(r), p(a), p(b), 0, a.size, q, 1, 1) == 0
+    assert np.array_equal(r, ho.eltwise_mult_mod(a, b, q, 1))
+    assert hx.lib.hexl_amd_eltwise_host(5, p(a), p(a), None, 7, a.size, q, 1, 1) == 0
+    assert np.array_equal(a, ho.eltwise_fma_mod(x.reshape(-1), 7, None, q, 1))
 
 
 @pytest.mark.parametrize("direct", [0, 1])

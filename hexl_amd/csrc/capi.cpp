@@ -977,11 +977,13 @@ int hexl_amd_ntt_inverse_rns(const hexl_amd_ntt* const* plans, uint64_t num_plan
 }
 
 // Host buffers (what an unmodified intel::hexl caller hands over): stage to the device,
-// transform, copy back.  On the MI355X boxes of this pool the link moves 53 GB/s in one direction
-// and 53 GB/s in both directions together, from pageable memory as fast as from pinned
-// (tools/pcie_probe.py), so the plain sequence H2D, kernels, D2H runs at the link rate (54-55 GB/s
-// in + out); a two-stream chunked pipeline over caller pages pinned for the call was built in
-// round 2, measured equal and -- never on by default, never exercised -- removed in round 5.
+// transform, copy back.  Ordinary memory moves through the thread's pinned slots (copy_to_device /
+// copy_from_device above): the link's rate up to 1 MiB, a memcpy's (26 GB/s in + out) beyond --
+// "host_direct_copy" = 1 hands the buffers to the runtime instead, which runs at the link's
+// 54 GB/s from pageable memory as from pinned (tools/pcie_probe.py, profiles/r5_host_copy_ab.txt).
+// A two-stream chunked pipeline over caller pages pinned for the call was built in round 2,
+// measured equal to the plain sequence and -- never on by default, never exercised -- removed
+// in round 5.
 // Knob of the host path (hexl_amd_set_tuning; no environment variable is read):
 // largest call (bytes of operand) that goes through the mapped bounce buffer: beyond it the
 // host-side copies cost as much as the DMA they replace (measured: N = 65536, 512 KiB: 82 us

@@ -49,8 +49,10 @@ static void put_num(long v) {
   put(b + i);
 }
 
+static const char* g_maps_path; /* ABORT_TRACE_MAPS, read when the library loads */
+
 static void copy_maps(void) {
-  const char* path = getenv("ABORT_TRACE_MAPS");
+  const char* path = g_maps_path;
   if (!path) return;
   int in = open("/proc/self/maps", O_RDONLY), out = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
   if (in >= 0 && out >= 0) {
@@ -106,6 +108,7 @@ static void on_signal(int sig, siginfo_t* info, void* ctx) {
 __attribute__((constructor)) static void install(void) {
   void* warm[4];
   (void)backtrace(warm, 4); /* loads libgcc_s now, not inside the handler */
+  g_maps_path = getenv("ABORT_TRACE_MAPS");
   const char* log = getenv("ABORT_TRACE_LOG");
   if (log) g_log_fd = open(log, O_WRONLY | O_CREAT | O_APPEND | O_CLOEXEC, 0644);
   const int sigs[] = {SIGABRT, SIGSEGV, SIGBUS};

@@ -3,7 +3,7 @@ arithmetic policy, batches of a fixed number of bytes resident in HBM (default 1
 forward / inverse pass over the batch, launches per transform, algorithmic GB/s (16 N bytes per
 transform: one read and one write of the polynomial) and its fraction of the 8 TB/s peak.  Prints a
 markdown table ("prime bits" b = the first prime GeneratePrimes(1, b, true, N) returns, in (2^b, 2^(b+1)):
-Small, Fp64, Lazy, Lazy32, Lazy16, Harvey60 and Strict arithmetic); times are HIP-event medians taken by the library's own launch profiler after a
+Small, Fp64L, Fp64, Lazy, Lazy32, Lazy16, Harvey60 and Strict arithmetic); times are HIP-event medians taken by the library's own launch profiler after a
 150 ms warm-up of the same call."""
 import os
 import statistics
@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hexl_amd as hx  # noqa: E402
 
 BYTES = int(os.environ.get("SWEEP_MIB", "1024")) << 20
-BITS = [int(b) for b in os.environ.get("SWEEP_BITS", "28,49,55,56,58,60,61").split(",")]
+BITS = [int(b) for b in os.environ.get("SWEEP_BITS", "28,44,49,55,56,58,60,61").split(",")]
 LOGN = range(int(os.environ.get("SWEEP_LOGN_MIN", "10")), int(os.environ.get("SWEEP_LOGN_MAX", "20")) + 1)
 REPS = 15
 WARM_MS = float(os.environ.get("SWEEP_WARM_MS", "150"))

@@ -189,3 +189,21 @@ def test_c_abi_header_is_plain_c(tmp_path):
                            "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe),
                            "-L" + lib, "-lhexl_amd", "-Wl,-rpath," + lib])
     assert os.path.exists(exe)
+
+
+def test_every_tuning_key_and_counter_is_documented_in_the_header():
+    """hexl_amd_set_tuning / hexl_amd_get_counter accept exactly the keys include/hexl_amd.h documents:
+    every `strcmp(key, "...")` of the library's sources is named in the header, and the header names
+    no key the sources do not know (removed knobs are listed as removed, in parentheses)."""
+    import re
+    csrc = os.path.join(ROOT, "hexl_amd", "csrc")
+    accepted = set()
+    for name in ("capi.cpp", "ntt_kernels.hip"):
+        accepted |= set(re.findall(r'strcmp\(key, "([a-z0-9_]+)"\)', open(os.path.join(csrc, name)).read()))
+    assert {"fp64", "fp64_long", "lazy_family", "h60", "tile13", "bigtile", "host_bounce_kb",
+            "host_direct_copy", "ks_graph", "ks_graph_replays", "ks_graph_captures", "ks_eager"} <= accepted
+    header = open(os.path.join(ROOT, "include", "hexl_amd.h")).read()
+    documented = set(re.findall(r'^ \*   "([a-z0-9_]+)"', header, re.M)) | set(
+        re.findall(r'"(ks_[a-z_]+)"', header))
+    assert accepted <= documented, sorted(accepted - documented)
+    assert documented <= accepted, sorted(documented - accepted)

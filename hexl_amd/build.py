@@ -45,14 +45,14 @@ def _headers():
     return hs
 
 
-def _compile(unit):
+def _compile(unit, obj_dir=None, extra=()):
     """unit: a source file name, or (source, extra flag, object base name)"""
     src, flag, base = unit if isinstance(unit, tuple) else (unit, None, os.path.basename(unit))
-    obj = os.path.join(OBJ, base + ".o")
+    obj = os.path.join(obj_dir or OBJ, base + ".o")
     path = os.path.join(CSRC, src)
     if _newer(obj, [path] + _headers()):
         return obj
-    cmd = [HIPCC, f"--offload-arch={ARCH}"] + COMMON + ([flag] if flag else []) + ["-c", path, "-o", obj]
+    cmd = [HIPCC, f"--offload-arch={ARCH}"] + COMMON + list(extra) + ([flag] if flag else []) + ["-c", path, "-o", obj]
     if src.endswith(".cpp"):
         cmd.insert(1, "-x")
         cmd.insert(2, "c++")
@@ -63,6 +63,18 @@ def _compile(unit):
         sys.stderr.write(r.stdout + r.stderr)
         raise RuntimeError(f"hipcc failed on {src}")
     return obj
+
+
+def build_variant(tag, extra_flags, units=None):
+    """Developer A/B builds: tools/libhexl_amd_<tag>.so = the core library compiled with extra
+    -D flags (objects under lib/obj_<tag>/; HEXL_AMD_LIB selects it in the Python binding)."""
+    obj_dir = os.path.join(LIB, "obj_" + tag)
+    os.makedirs(obj_dir, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=min(12, os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(lambda u: _compile(u, obj_dir, extra_flags), CORE_SOURCES))
+    out = os.path.join(ROOT, "tools", f"libhexl_amd_{tag}.so")
+    subprocess.check_call([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs)
+    return out
 
 
 def build(verbose=False):
@@ -107,4 +119,7 @@ def build(verbose=False):
 
 
 if __name__ == "__main__":
-    build(verbose=True)
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":  # build.py --variant TAG -DFLAG ...
+        print("built", build_variant(sys.argv[2], sys.argv[3:]))
+    else:
+        build(verbose=True)

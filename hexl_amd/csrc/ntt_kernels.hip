@@ -1077,7 +1077,11 @@ template <bool FWD, int S, int CB, int TL, bool GUARD, class A, bool LAST>
 __global__ void __launch_bounds__(1 << (TL - re_of(S)), (min_waves<S, CB>()))
 tile_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst m, u32 log_n,
           u32 flags, u64 total, InvLast il) {
+#ifdef HEXL_AMD_EXP_PAD13  // developer experiment: the 64 KiB tile at ONE workgroup per CU
+  __shared__ u64 lds[TL == 13 ? (1 << 14) : (1 << TL)];
+#else
   __shared__ u64 lds[1 << TL];
+#endif
   // (The XCD-aware block order of strided_pass was measured here too: 2-7 % slower.  So was
   // a workgroup that walks 2 or 4 consecutive tiles instead of one -- a k-th of the
   // dispatches, no wait for the previous tile's store acknowledgements: forward +2 / +8 %,

@@ -75,7 +75,7 @@ int hexl_amd_pointer_is_device(const void* p);
  *                                      runtime copy pageable memory from / to re-used heap pages
  *                                      (hipMemcpyAsync, torch.Tensor.to) dies of a GPU memory access
  *                                      fault; reproduced without this library in seconds by
- *                                      tools/register_then_pageable_copy_soak.py --register raw
+ *                                      experiments/rocm_fault/register_then_pageable_copy_soak.py --register raw
  *                                      (EXPERIMENTS.md section 10).  The library's own copies of
  *                                      pageable memory go through pinned slots and are not affected
  *   hexl_amd_pointer_kind              0 ordinary host, 1 device / managed, 2 mapped host

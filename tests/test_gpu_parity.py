@@ -457,7 +457,7 @@ def test_short_lived_registration_then_large_pageable_copies(hx, ho):
     regression test: a short-lived heap array is registered (hexl_amd_host_register), transformed
     in place over the link, unregistered and freed; the next allocations reuse its address range
     and go through >= 1 MiB pageable host-to-device copies (a plan's table upload, a staged *_host
-    call, the caller's own copy).  tests/cpp/register_abort_repro.cpp is the standalone form."""
+    call, the caller's own copy).  experiments/rocm_fault/register_abort_repro.cpp is the standalone form."""
     import ctypes as C
     lib = hx.lib
     for n, bits in ((4096, 49), (8192, 54), (65536, 54), (65536, 54)):
@@ -1159,6 +1159,14 @@ def test_eltwise_config2_and_config5_shapes(hx, ho):
     hx.EltwiseReduceMod(rc, c, n, q, q, 1)
     hx.EltwiseFMAMod(ra, ra, s % q, rc, n, q, 1)
     assert torch.equal(fused, ra)
+    # ... and the fused kernel against the oracle itself (ReduceMod(q -> 1) of both operands,
+    # eltwise-reduce-mod.cpp:32-55, then FMAMod, eltwise-fma-mod-internal.hpp:12-39) on the same
+    # three 131072-word blocks as the unfused check above
+    for blk in (0, 511, 1023):
+        sl = slice(blk * N, (blk + 1) * N)
+        oa = ho.eltwise_reduce_mod(host(hx, a[sl]), q, q, 1)
+        oc = ho.eltwise_reduce_mod(host(hx, c[sl]), q, q, 1)
+        assert (host(hx, fused[sl]) == ho.eltwise_fma_mod(oa, s % q, oc, q, 1)).all()
 
 
 def test_eltwise_argument_errors(hx):

@@ -267,14 +267,23 @@ __device__ __forceinline__ void fwd_bound_level(u64* x, const ModConst& m, u32 s
   }
 }
 
+// Hooks of the persistent tile walk (tile_walk): a callable run at one point inside a round --
+// forward: in front of the LAST stage of the last round; inverse: in round 1 between its LDS
+// load and its arithmetic -- where the next tile's loads are issued.
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+
 // R forward stages on x[0 .. 2^R): stage v pairs elements 2^(R-1-v) apart.  smask: see
 // fwd_bound_level (bit v = stage v of this subtree).
-template <int R, class A>
-__device__ __forceinline__ void fwd_subtree(u64* x, const TwT<A>* wv, const ModConst& m, u32 smask = 0) {
+template <int R, class A, class Hook = NoHook>
+__device__ __forceinline__ void fwd_subtree(u64* x, const TwT<A>* wv, const ModConst& m, u32 smask = 0,
+                                            const Hook& hook = Hook()) {
   static_assert(!A::kFp || R <= A::kFwdRun, "Fp64 forward run too long");
 #pragma unroll
   for (int v = 0; v < R; ++v) {
     const int half = 1 << (R - 1 - v);
+    if (v == R - 1) hook();
     if constexpr (bounded_lazy<A>()) {
       if (smask & (1u << v)) {
 #pragma unroll
@@ -732,16 +741,16 @@ __device__ __forceinline__ void round_twiddles(T* wv, const T* __restrict__ tw, 
 }
 
 // fmask (forward, bounded members of the Lazy family): stage mask of the pass, bit s = stage s
-template <int S, int CB, int j, class A, bool FWD, bool LAST>
+template <int S, int CB, int j, class A, bool FWD, bool LAST, class Hook = NoHook>
 __device__ __forceinline__ void round_compute(u64* x, const TwT<A>* wv, const ModConst& m,
-                                              const InvLast& il, u32 fmask = 0) {
+                                              const InvLast& il, u32 fmask = 0, const Hook& hook = Hook()) {
   constexpr int kRE = re_of(S), kE = el_of(S);
   constexpr int r = Rounds<S, CB>::r(j);
   constexpr int SS = kE >> r;
 #pragma unroll
   for (int s = 0; s < SS; ++s) {
     if (FWD)
-      fwd_subtree<r, A>(x + (s << r), wv + (s << r), m, fmask >> Rounds<S, CB>::u(j));
+      fwd_subtree<r, A, Hook>(x + (s << r), wv + (s << r), m, fmask >> Rounds<S, CB>::u(j), hook);
     else  // (Lazy: entry bound and exit threshold of round j of this pass's chain)
       inv_subtree<r, A, LAST,
                   lazy_chain_entry(j, Rounds<S, CB>::NR, Rounds<S, CB>::R0, kRE, A::kLazy ? A::kLimit : kLazyLimit),
@@ -807,12 +816,27 @@ __device__ __forceinline__ void handover() {
   }
 }
 
+// Conversion of a tile's words on entry for a pass known to start the network (the one-kernel plans' tile_walk); REDUCE: the
+// launch may carry a source map whose words are reduced on load (multi-plan form only).
+template <int S, class A, bool REDUCE>
+__device__ __forceinline__ void fetch_convert_first(u64* x, u32 flags, const ModConst& m) {
+  constexpr int kE = el_of(S);
+  if constexpr (REDUCE) {
+    if (flags & kReduceFirst) {
+#pragma unroll
+      for (int i = 0; i < kE; ++i) x[i] = reduce_any_straight(x[i], m.q, m.barrett);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kE; ++i) x[i] = to_internal<A>(x[i], m);
+}
 // forward rounds J .. NR-1: LDS -> registers -> subtree -> same LDS slots.
 // `pre` holds the twiddles of round J when Rounds::pre_fwd(J).
-template <int S, int CB, int TL, int J, class A, bool CTW = false>
+template <int S, int CB, int TL, int J, class A, bool CTW = false, class Hook = NoHook>
 __device__ __forceinline__ void fwd_mid_rounds(u64* x, u64* lds, const TwT<A>* tw, u32 tid,
                                                const TileGeom& g, const ModConst& m,
-                                               const InvLast& il, const TwT<A>* pre, u32 fmask) {
+                                               const InvLast& il, const TwT<A>* pre, u32 fmask,
+                                               const Hook& hook = Hook()) {
   constexpr int kRE = re_of(S), kE = el_of(S);
   using RD = Rounds<S, CB>;
   if constexpr (J < RD::NR) {
@@ -824,22 +848,29 @@ __device__ __forceinline__ void fwd_mid_rounds(u64* x, u64* lds, const TwT<A>* t
     }
     lds_load_round<S, CB, TL, J>(x, lds, tid);
     if constexpr (RD::pre_fwd(J + 1)) round_twiddles<S, CB, TL, J + 1, CTW>(wn, tw, tid, g);
-    round_compute<S, CB, J, A, true, false>(x, w, m, il, fmask);
+    if constexpr (J == RD::NR - 1 && RD::r(J) == kRE)  // (one subtree per thread: the hook runs once)
+      round_compute<S, CB, J, A, true, false, Hook>(x, w, m, il, fmask, hook);
+    else
+      round_compute<S, CB, J, A, true, false>(x, w, m, il, fmask);
     lds_store_round<S, CB, TL, J>(x, lds, tid);
     handover<RD::w(J), RD::r(J) == kRE>();
     HX_STAMP(3 + J);
-    fwd_mid_rounds<S, CB, TL, J + 1, A, CTW>(x, lds, tw, tid, g, m, il, wn, fmask);
+    fwd_mid_rounds<S, CB, TL, J + 1, A, CTW, Hook>(x, lds, tw, tid, g, m, il, wn, fmask, hook);
   }
 }
 
 // inverse rounds J .. 1 (deepest first).  `pre` holds the twiddles of round J when
 // J == NR-1 or Rounds::pre_inv(J); `pre0` receives those of round 0 when
 // Rounds::pre_inv(0).
-template <int S, int CB, int TL, int J, class A, bool CTW = false>
+// RAW (tile_walk): the tile sits in LDS as it came from memory; the words of the first round
+// executed are brought to the internal form (and reduced, REDUCE / flags: see fetch_convert_first)
+// right after their LDS load.
+template <int S, int CB, int TL, int J, class A, bool CTW = false, bool RAW = false, bool REDUCE = false,
+          class Hook = NoHook>
 __device__ __forceinline__ void inv_mid_rounds(u64* x, u64* lds, const TwT<A>* tw, u32 tid,
                                                const TileGeom& g, const ModConst& m,
                                                const InvLast& il, const TwT<A>* pre,
-                                               TwT<A>* pre0) {
+                                               TwT<A>* pre0, u32 flags = 0, const Hook& hook = Hook()) {
   constexpr int kRE = re_of(S), kE = el_of(S);
   using RD = Rounds<S, CB>;
   if constexpr (J >= 1) {
@@ -851,12 +882,14 @@ __device__ __forceinline__ void inv_mid_rounds(u64* x, u64* lds, const TwT<A>* t
     }
     lds_load_round<S, CB, TL, J>(x, lds, tid);
     if constexpr (RD::pre_inv(J - 1)) round_twiddles<S, CB, TL, J - 1, CTW>(J == 1 ? pre0 : wn, tw, tid, g);
+    if constexpr (RAW) fetch_convert_first<S, A, REDUCE>(x, flags, m);
+    if constexpr (J == 1) hook();
     round_compute<S, CB, J, A, false, false>(x, w, m, il);
     lds_store_round<S, CB, TL, J>(x, lds, tid);
     // the next (shallower) round J-1 regroups across waves iff its gap exceeds a wave
     handover<RD::w(J - 1), RD::r(J - 1) == kRE>();
     HX_STAMP(3 + (RD::NR - 1 - J));
-    inv_mid_rounds<S, CB, TL, J - 1, A, CTW>(x, lds, tw, tid, g, m, il, wn, pre0);
+    inv_mid_rounds<S, CB, TL, J - 1, A, CTW, false, false, Hook>(x, lds, tw, tid, g, m, il, wn, pre0, 0, hook);
   }
 }
 
@@ -892,10 +925,15 @@ __device__ __forceinline__ void fetch_tile(u64* x, const u64* in, u32 tid, const
     const u32 p0 = xfer_p0<ROUND0, S, CB, TL>(tid, i);
     const u32 dp = xfer_dp<ROUND0, S, CB>(i);
     const u64* src = in + tile_uniform_offset<CB>(g, dp);
+#ifdef HEXL_AMD_EXP_NOLOAD  // developer experiment (timing only, wrong results): no global loads
+    x[i] = (u64)(p0 + dp) * 0x9E3779B97F4A7C15ull >> 12;
+    HX_OPAQUE(x[i]);
+#else
     if (GUARD)
       x[i] = (g.base + p0 + dp < total) ? load_global<LDK>(src, tile_byte_offset<CB>(g, p0)) : 0;
     else
       x[i] = load_global<LDK>(src, tile_byte_offset<CB>(g, p0));
+#endif
   }
   if constexpr (!CONVERT) return;
   if (flags & kFirstPass) {
@@ -925,6 +963,9 @@ __device__ __forceinline__ void store_elem(u64* out, u32 tid, int i, u64 v,
                                            const TileGeom& g, u64 total) {
   const u32 p0 = xfer_p0<ROUND0, S, CB, TL>(tid, i);
   const u32 dp = xfer_dp<ROUND0, S, CB>(i);
+#ifdef HEXL_AMD_EXP_NOSTORE  // developer experiment (timing only): one store in 2^20 happens
+  if ((v & 0xfffff) != 0x12345) return;
+#endif
   if (!GUARD || g.base + p0 + dp < total)
     store_global<STK>(out + tile_uniform_offset<CB>(g, dp), tile_byte_offset<CB>(g, p0), v);
 }
@@ -1077,8 +1118,10 @@ template <bool FWD, int S, int CB, int TL, bool GUARD, class A, bool LAST>
 __global__ void __launch_bounds__(1 << (TL - re_of(S)), (min_waves<S, CB>()))
 tile_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst m, u32 log_n,
           u32 flags, u64 total, InvLast il) {
-#ifdef HEXL_AMD_EXP_PAD13  // developer experiment: the 64 KiB tile at ONE workgroup per CU
+#if defined(HEXL_AMD_EXP_PAD13)  // developer experiment: the 64 KiB tile at ONE workgroup per CU
   __shared__ u64 lds[TL == 13 ? (1 << 14) : (1 << TL)];
+#elif defined(HEXL_AMD_EXP_PAD12)  // ... the 32 KiB tile padded to 2^PAD12 words (fewer workgroups per CU)
+  __shared__ u64 lds[TL == 12 ? (1 << HEXL_AMD_EXP_PAD12) : (1 << TL)];
 #else
   __shared__ u64 lds[1 << TL];
 #endif
@@ -1116,10 +1159,277 @@ tile_pass_multi(u64* out, const u64* in, MultiCtx mc, u32 log_n, u32 flags, u64 
       lds, out, in, FWD ? mc.tw_fwd[k] : mc.tw_inv[k], m, log_n, flags, total, il, blockIdx.x);
 }
 
+// ---------------------------------------------------------------------------
+// tile_walk: the 128 KiB tile as a persistent workgroup (round 6)
+// ---------------------------------------------------------------------------
+// The 14-stage tile is ONE workgroup per CU (its LDS), so nothing on the CU overlaps a
+// workgroup's load phase, its store drain and the dispatch of its successor: the counters show
+// VALU busy 0.64 where the two-workgroups-per-CU 13-stage tile reaches 0.87, and the 13-stage
+// tile forced to one workgroup per CU loses exactly that (profiles/r6_pmc_onekernel.md).  Two
+// co-resident 14-stage tiles do not fit (2 x 128 KiB of data against 160 KiB of LDS; held in
+// registers instead, 64 of a thread's 128 VGPRs at 2 x 8 waves -- half the waves, measured on the
+// 12-stage tile as a third of the gain).  So the workgroup stays and walks the tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ... itself, with the NEXT tile's loads issued before THIS
+// tile's stores: vector memory operations complete in order, so the wait for the loads does not
+// include the stores' acknowledgements, which drain while the next tile computes.
+//   forward: ... last round -> LDS | loads(next round-0 set) | copy-out: LDS -> finish -> stores
+//   inverse: ... round 0: LDS -> registers | loads(next run) | round 0 arithmetic -> stores
+// (the inverse hides its loads behind two stages of arithmetic, the forward behind the copy-out).
+// Only the one-kernel plans: a tile is a whole polynomial (S == TL == log2 N, CB = 0, nothing
+// ragged), the pass starts and ends the network.
+__device__ __forceinline__ u32 walk_next(const MultiCtx* mc, u32 t, u32 ntiles, int want, u32& k) {
+  if (mc == nullptr) return t;
+  for (; t < ntiles; t += gridDim.x) {
+    if (multi_plan(*mc, t, want, k)) break;
+  }
+  return t;
+}
+
+// The run this wave owns in the deepest round, from registers to its LDS slots (inverse).
+template <int S, int TL>
+__device__ __forceinline__ void walk_park(const u64* x, u64* lds, u32 tid) {
+  constexpr int kE = el_of(S);
+  const u32 a0 = lds_slot<re_of(S)>(xfer_p0<false, S, 0, TL>(tid, 0)) << 3;
+#pragma unroll
+  for (int i = 0; i < kE; ++i) lds_at(lds, a0 ^ (lds_slot<re_of(S)>(xfer_dp<false, S, 0>(i)) << 3)) = x[i];
+}
+
+template <bool FWD, int S, class A, bool LAST, bool MULTI>
+__device__ __forceinline__ void tile_walk(u64* lds, u64* out, const u64* in_arg,
+                                          const ulonglong2* __restrict__ tw_arg, const ModConst& m_arg,
+                                          u32 log_n, u32 flags_arg, u64 total, const InvLast& il_arg,
+                                          const MultiCtx* mc) {
+  constexpr int TL = S, CB = 0;
+  constexpr int kRE = re_of(S), kE = el_of(S);
+  using RD = Rounds<S, CB>;
+  constexpr int NR = RD::NR;
+  constexpr bool CTW = MULTI;
+  // access kinds as in tile_pass / tile_pass_multi
+  constexpr int kKind = MULTI ? (FWD ? kStream : kPlain) : ((FWD || LAST) ? kStream : kPlain);
+  u32 tid = threadIdx.x;
+  const u32 ntiles = (u32)(total >> TL);
+  u32 k = 0;
+  u32 tile = walk_next(MULTI ? mc : nullptr, blockIdx.x, ntiles, policy_id<A>(), k);
+  if (tile >= ntiles) return;
+  ModConst m = m_arg;
+  InvLast il = il_arg;
+  const TwT<A>* __restrict__ tw = reinterpret_cast<const TwT<A>*>(tw_arg);
+  u32 flags = flags_arg;
+  const u64* in = in_arg;
+  if constexpr (MULTI) in = multi_source(*mc, tile, log_n, in_arg, flags);
+  TileGeom g = make_geom<S, CB, TL>(tile, log_n);
+  u64 x[kE];
+  __builtin_amdgcn_s_setprio(3);
+  fetch_tile<FWD, S, CB, TL, false, A, kKind, false>(x, in, tid, g, total, flags, m);
+  __builtin_amdgcn_s_setprio(0);
+  if constexpr (!FWD) walk_park<S, TL>(x, lds, tid);
+  TileGeom gp = g;  // inverse: the tile whose results wait in x for their stores
+  bool first_iteration = true;
+  for (;;) {
+    // (the thread index is made opaque per phase: left visible as a loop invariant, every LDS and
+    // global address of every round is hoisted out of the loop and kept in registers across it --
+    // the inverse spilled 340 bytes and parked the prefetched tile in scratch)
+    asm volatile("" : "+v"(tid));
+    if constexpr (MULTI) {
+      const PlanDev* __restrict__ pd = mc->p[k];
+      m = pd->mod;
+      il = pd->il;
+      tw = reinterpret_cast<const TwT<A>*>(FWD ? mc->tw_fwd[k] : mc->tw_inv[k]);
+    }
+    // the tile after this one (looked up where its loads are issued: nothing of it is live before)
+    u32 kn = 0, nt = 0, nflags = flags_arg;
+    bool more = false;
+    const u64* nin = in_arg;
+    TileGeom ng = g;
+    auto look_ahead = [&]() {
+      nt = walk_next(MULTI ? mc : nullptr, tile + gridDim.x, ntiles, policy_id<A>(), kn);
+      more = nt < ntiles;
+      if (more) {
+        ng = make_geom<S, CB, TL>(nt, log_n);
+        if constexpr (MULTI) nin = multi_source(*mc, nt, log_n, in_arg, nflags);
+      }
+    };
+    const u32 finish = flags & kFinishMask;
+    if constexpr (FWD) {
+      TwT<A> wn[kE];
+      {
+        TwT<A> wv[kE];
+        round_twiddles<S, CB, TL, 0, CTW>(wv, tw, tid, g);
+        fetch_convert_first<S, A, MULTI>(x, flags, m);
+        if constexpr (RD::pre_fwd(1)) round_twiddles<S, CB, TL, 1, CTW>(wn, tw, tid, g);
+        round_compute<S, CB, 0, A, true, false>(x, wv, m, il, flags >> kStageMaskShift);
+        // (the previous tile's copy-out has read every slot: its LDS reads are behind this barrier)
+        if (!first_iteration) __syncthreads();
+        lds_store_round<S, CB, TL, 0>(x, lds, tid);
+        handover<RD::w(0), RD::r(0) == kRE>();
+      }
+      // The next tile's round-0 set is requested in front of the LAST stage of the last round
+      // (the twiddles of the round's first three stages are dead by then: 32 registers are
+      // free), ahead of that stage, the round's LDS store, the copy-out and this tile's stores.
+      // (Always defined: see the inverse.)
+      u64 y[kE];
+#pragma unroll
+      for (int i = 0; i < kE; ++i) y[i] = 0;
+      auto prefetch = [&]() {
+        asm volatile("" : "+v"(tid));
+        look_ahead();
+        if (more) {
+          __builtin_amdgcn_s_setprio(3);
+          fetch_tile<true, S, CB, TL, false, A, kKind, false>(y, nin, tid, ng, total, nflags, m);
+          __builtin_amdgcn_s_setprio(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      fwd_mid_rounds<S, CB, TL, 1, A, CTW>(x, lds, tw, tid, g, m, il, wn, flags >> kStageMaskShift,
+                                           prefetch);
+      asm volatile("" : "+v"(tid));
+      if (finish == 2)
+        fwd_copy_out<2, S, CB, TL, false, A, kKind>(lds, out, tid, g, total, m);
+      else if (finish)
+        fwd_copy_out<1, S, CB, TL, false, A, kKind>(lds, out, tid, g, total, m);
+      else
+        fwd_copy_out<0, S, CB, TL, false, A, kKind>(lds, out, tid, g, total, m);
+#pragma unroll
+      for (int i = 0; i < kE; ++i) x[i] = y[i];
+    } else {
+      // (the tile is in LDS already, as it came from memory: stored by the prologue / by the
+      // previous iteration; this wave reads back its own run, so no barrier)
+      // The PREVIOUS tile's results are still in x: they are stored here, behind the request for
+      // this tile's per-lane twiddles -- vector memory operations complete in order, and a load
+      // issued behind the stores would wait for their acknowledgements.
+      TwT<A> wtop[kE], w0[kE];
+      if constexpr (NR > 1) round_twiddles<S, CB, TL, NR - 1, CTW>(wtop, tw, tid, g);
+      if (!first_iteration) {
+#pragma unroll
+        for (int i = 0; i < kE; ++i) store_elem<true, S, CB, TL, false, kKind>(out, tid, i, x[i], gp, total);
+      }
+      handover<RD::w(NR - 1), RD::r(NR - 1) == kRE>();
+      // The next tile's run is requested in round 1, between its LDS load and its arithmetic
+      // (scalar twiddles there: 32 registers are free), ahead of rounds 1 and 0 -- six stages;
+      // it is parked in LDS, as it comes, once every wave holds its round-0 set.  (Always
+      // defined, loaded under one condition and parked under the same one: defined on one path
+      // only, the register allocator kept it in scratch.)
+      u64 y[kE];
+#pragma unroll
+      for (int i = 0; i < kE; ++i) y[i] = 0;
+      auto prefetch = [&]() {
+        asm volatile("" : "+v"(tid));
+        look_ahead();
+        if (more) {
+          __builtin_amdgcn_s_setprio(3);
+          fetch_tile<false, S, CB, TL, false, A, kKind, false>(y, nin, tid, ng, total, nflags, m);
+          __builtin_amdgcn_s_setprio(0);
+        }
+      };
+      // (reduce-on-load is compiled into the forward walk only: launch_bottom keeps inverse launches
+      // with a source map on tile_pass_multi)
+      inv_mid_rounds<S, CB, TL, NR - 1, A, CTW, true, false>(x, lds, tw, tid, g, m, il, wtop, w0, flags,
+                                                             prefetch);
+      asm volatile("" : "+v"(tid));
+      if constexpr (!RD::pre_inv(0)) round_twiddles<S, CB, TL, 0, CTW>(w0, tw, tid, g);
+      lds_load_round<S, CB, TL, 0>(x, lds, tid);
+      if (more) {
+        // every wave holds its round-0 set (other waves' runs among it): the tile's LDS is free
+        __syncthreads();
+        walk_park<S, TL>(y, lds, tid);
+      }
+      round_compute<S, CB, 0, A, false, LAST>(x, w0, m, il);
+      if (finish == 2) {
+#pragma unroll
+        for (int i = 0; i < kE; ++i) x[i] = inv_finish<A>(x[i], m, true);
+      } else if (finish) {
+#pragma unroll
+        for (int i = 0; i < kE; ++i) x[i] = inv_finish<A>(x[i], m, false);
+      }
+      gp = g;
+      if (!more) {  // the last tile of this workgroup
+#pragma unroll
+        for (int i = 0; i < kE; ++i) store_elem<true, S, CB, TL, false, kKind>(out, tid, i, x[i], gp, total);
+      }
+    }
+    if (!more) break;
+    tile = nt;
+    g = ng;
+    flags = nflags;
+    k = kn;
+    first_iteration = false;
+  }
+}
+
+template <bool FWD, int S, class A, bool LAST>
+__global__ void __launch_bounds__(1 << (S - re_of(S)), (min_waves<S, 0>()))
+tile_walk_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst m, u32 log_n,
+               u32 flags, u64 total, InvLast il) {
+  __shared__ u64 lds[1 << S];
+  tile_walk<FWD, S, A, LAST, false>(lds, out, in, tw, m, log_n, flags, total, il, nullptr);
+}
+
+template <bool FWD, int S, class A, bool LAST>
+__global__ void __launch_bounds__(1 << (S - re_of(S)), (min_waves<S, 0>()))
+tile_walk_pass_multi(u64* out, const u64* in, MultiCtx mc, u32 log_n, u32 flags, u64 total) {
+  __shared__ u64 lds[1 << S];
+  const ModConst m{};
+  const InvLast il{};
+  tile_walk<FWD, S, A, LAST, true>(lds, out, in, nullptr, m, log_n, flags, total, il, &mc);
+}
+
 
 // ---------------------------------------------------------------------------
 // Host-side planning and launch
 // ---------------------------------------------------------------------------
+
+// Process-wide tuning state (hexl_amd_set_tuning; include/hexl_amd.h documents the keys).  The
+// library reads no environment variable: every knob has a compiled-in default and changes only
+// through that call.  Results never depend on it.
+constexpr u64 kTile14MinBatch = 96;
+struct Tuning {
+  std::atomic<u32> fp64{1}, h60{1}, tile13{2}, bigtile{1}, lazy_family{1}, fp64_long{1}, walk14{1};
+};
+Tuning& tuning();  // one per process: defined by the dispatch unit
+#if HX_TU_DISPATCH
+Tuning& tuning() {
+  static Tuning t;
+  return t;
+}
+int set_tuning(const char* key, u64 value) {
+  Tuning& t = tuning();
+  if (strcmp(key, "fp64") == 0 && value <= 2) t.fp64 = (u32)value;
+  else if (strcmp(key, "tile13") == 0 && value <= 2) t.tile13 = (u32)value;
+  else if (strcmp(key, "h60") == 0 && value <= 1) t.h60 = (u32)value;
+  else if (strcmp(key, "bigtile") == 0 && value <= 1) t.bigtile = (u32)value;
+  else if (strcmp(key, "lazy_family") == 0 && value <= 1) t.lazy_family = (u32)value;
+  else if (strcmp(key, "fp64_long") == 0 && value <= 1) t.fp64_long = (u32)value;
+  else if (strcmp(key, "walk14") == 0 && value <= 2) t.walk14 = (u32)value;
+  else return -1;
+  return 0;
+}
+#endif  // HX_TU_DISPATCH
+
+// Where the persistent 14-stage tile walk (tile_walk) replaces one workgroup per tile.  Measured
+// at N = 16384 x 8192 (profiles/r6_walk14_ab.txt): the inverse gains with every arithmetic policy
+// (Small -16 %, Fp64 / Fp64L -9 %, Lazy -10 %, Harvey60 -6 %); the forward only with the Fp64
+// family (-5 ... -7 %), is flat under Lazy and loses 9 % under Small.  "walk14": 0 = never,
+// 1 = this table, 2 = always (A/B).
+template <bool FWD, class A>
+static bool walk14_wanted() {
+  const u32 w = tuning().walk14.load();
+  if (w == 0) return false;
+  if (w == 2) return true;
+  return !FWD || A::kFp;
+}
+
+// Compute units of the current device (the grid of the persistent tile walk), cached per device.
+static unsigned cu_count() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = cached[dev].load(std::memory_order_relaxed);
+  if (n <= 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev].store(n, std::memory_order_relaxed);
+  }
+  return (unsigned)n;
+}
 
 template <bool FWD, class A>
 static hipError_t launch_strided(int R, u64* out, const u64* in, const ulonglong2* tw,
@@ -1195,7 +1505,16 @@ static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2
         }
       } else {  // N = 16384 as one kernel (128 KiB tile)
         if constexpr (TL == 14) {
-          if (last) HX_LAUNCH_BM(14, !FWD); else HX_LAUNCH_BM(14, false);
+          if (log_n == 14 && walk14_wanted<FWD, A>() && grid > cu_count() &&
+              (FWD || mc->map.src_stride == 0)) {  // persistent: see tile_walk
+            const unsigned pg = cu_count();
+            if (last)
+              hipLaunchKernelGGL((tile_walk_pass_multi<FWD, 14, A, !FWD>), dim3(pg), dim3(1024), 0, st, out,
+                                 in, *mc, log_n, finish, total);
+            else
+              hipLaunchKernelGGL((tile_walk_pass_multi<FWD, 14, A, false>), dim3(pg), dim3(1024), 0, st, out,
+                                 in, *mc, log_n, finish, total);
+          } else if (last) HX_LAUNCH_BM(14, !FWD); else HX_LAUNCH_BM(14, false);
         } else {
           return hipErrorNotSupported;
         }
@@ -1228,6 +1547,19 @@ static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2
     } else                                                                                \
       return hipErrorInvalidValue;                                                        \
     break;
+  if constexpr (TL == 14) {
+    // N = 16384 as one kernel, more tiles than CUs: the persistent walk (tile_walk)
+    if (S == 14 && log_n == 14 && !guard && walk14_wanted<FWD, A>() && grid > cu_count()) {
+      const unsigned pg = cu_count();
+      if (!FWD)
+        hipLaunchKernelGGL((tile_walk_pass<FWD, 14, A, !FWD>), dim3(pg), dim3(1024), 0, st, out, in, tw, m,
+                           log_n, finish, total, il);
+      else
+        hipLaunchKernelGGL((tile_walk_pass<FWD, 14, A, false>), dim3(pg), dim3(1024), 0, st, out, in, tw, m,
+                           log_n, finish, total, il);
+      return hipGetLastError();
+    }
+  }
   switch (S) {
     HX_LAUNCH_B(1)
     HX_LAUNCH_B(2)
@@ -1263,32 +1595,6 @@ struct Plan {
   int strided[8];
   int bottom;
 };
-
-// Process-wide tuning state (hexl_amd_set_tuning; include/hexl_amd.h documents the keys).  The
-// library reads no environment variable: every knob has a compiled-in default and changes only
-// through that call.  Results never depend on it.
-constexpr u64 kTile14MinBatch = 96;
-struct Tuning {
-  std::atomic<u32> fp64{1}, h60{1}, tile13{2}, bigtile{1}, lazy_family{1}, fp64_long{1};
-};
-Tuning& tuning();  // one per process: defined by the dispatch unit
-#if HX_TU_DISPATCH
-Tuning& tuning() {
-  static Tuning t;
-  return t;
-}
-int set_tuning(const char* key, u64 value) {
-  Tuning& t = tuning();
-  if (strcmp(key, "fp64") == 0 && value <= 2) t.fp64 = (u32)value;
-  else if (strcmp(key, "tile13") == 0 && value <= 2) t.tile13 = (u32)value;
-  else if (strcmp(key, "h60") == 0 && value <= 1) t.h60 = (u32)value;
-  else if (strcmp(key, "bigtile") == 0 && value <= 1) t.bigtile = (u32)value;
-  else if (strcmp(key, "lazy_family") == 0 && value <= 1) t.lazy_family = (u32)value;
-  else if (strcmp(key, "fp64_long") == 0 && value <= 1) t.fp64_long = (u32)value;
-  else return -1;
-  return 0;
-}
-#endif  // HX_TU_DISPATCH
 
 static Plan make_plan(int L, bool allow_tile13 = true, u64 batch = ~0ull) {
   Plan p{};

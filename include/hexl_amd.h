@@ -482,6 +482,13 @@ int hexl_amd_profile_get(int i, const char** name, float* ms);
  *                      1 = N = 8192 only, 0 = neither
  *   "bigtile"          1 (default) = N = 2^18, 2^19 as five strided stages + a 13- / 14-stage
  *                      tile pass (two HBM round trips), 0 = three passes (3 + 3 + 12, 4 + 3 + 12)
+ *   "walk14"           the N = 16384 one-kernel plan with more polynomials than the device has
+ *                      compute units: 1 (default) = the inverse transform (every arithmetic
+ *                      policy) and the forward transform of the Fp64 policies run as ONE
+ *                      persistent workgroup per compute unit that walks the polynomials, the next
+ *                      polynomial's loads issued ahead of this one's stores (round 6: -9 ... -16 %
+ *                      on the inverse, -5 ... -7 % on the Fp64 forward); 0 = one workgroup per
+ *                      polynomial everywhere; 2 = the walk everywhere (A/B)
  *   "host_bounce_kb"   largest host-pointer call (KiB of operand) that runs on the per-thread
  *                      pinned, device-mapped bounce buffer instead of staged copies (default 256;
  *                      0 = never)

@@ -963,6 +963,74 @@ def test_ntt_single_kernel_plans(hx, ho, logn, bits):
         hx.set_tuning("tile13", 2)
 
 
+@pytest.mark.parametrize("bits", [28, 44, 49, 54, 56, 58, 60, 61])
+def test_ntt_tile_walk_n16384(hx, ho, bits):
+    """Round 6: the N = 16384 one-kernel plan as a persistent workgroup per compute unit that walks
+    the polynomials (tile_walk, `walk14`), forced on for every arithmetic policy and both directions:
+    a batch of more polynomials than compute units that is no multiple of the grid, in place and out
+    of place, canonical outputs against the oracle (first, a middle and the last polynomial of the
+    walk) and bit for bit against one workgroup per polynomial; lazy outputs congruent and in range."""
+    import torch
+    n, batch = 16384, 601
+    q = ho.generate_primes(1, bits, True, n)[0]
+    gnt, ont = hx.NTT(n, q), ho.NTT(n, q)
+    x = torch.empty((batch, n), dtype=torch.int64, device="cuda")
+    probe = [0, 255, 256, 300, 600]
+    try:
+        for fwd in (True, False):
+            fn = gnt.ComputeForward if fwd else gnt.ComputeInverse
+            for in_mf, out_mf in (((1, 1), (4, 4)) if fwd else ((1, 1), (2, 2))):
+                hx.fill_splitmix(x, n, batch, 9 + in_mf, in_mf * q)
+                res = []
+                for walk in (0, 2):
+                    hx.set_tuning("walk14", walk)
+                    a = x.clone()
+                    fn(a, a, in_mf, out_mf)
+                    b = torch.full_like(x, -1)
+                    fn(b, x, in_mf, out_mf)
+                    assert torch.equal(a, b)
+                    res.append(a)
+                if out_mf == 1:
+                    assert torch.equal(res[0], res[1])
+                    ref = (ont.forward if fwd else ont.inverse)(host(hx, x[probe]) % np.uint64(q), 1, 1)
+                    assert (host(hx, res[1][probe]) == ref).all()
+                else:
+                    assert torch.equal(res[0] % q, res[1] % q)
+                    assert int(res[1].min()) >= 0 and int(res[1].max()) < out_mf * q
+    finally:
+        hx.set_tuning("walk14", 1)
+
+
+def test_ntt_tile_walk_rns_and_default_table(hx, ho):
+    """The multi-plan form of the walk (several moduli in one launch: RNS limbs of different
+    arithmetic policies) against per-plan calls, and the default `walk14` table (inverse: every
+    policy; forward: the Fp64 policies) against the oracle on a batch the walk serves."""
+    import torch
+    n, per = 16384, 150
+    moduli = [ho.generate_primes(1, b, True, n)[0] for b in (44, 54, 54 + 1, 60)]
+    moduli[2] = ho.generate_primes(2, 54, True, n)[1]
+    plans = [hx.NTT(n, q) for q in moduli]
+    x = torch.empty((len(moduli) * per, n), dtype=torch.int64, device="cuda")
+    for k, q in enumerate(moduli):
+        hx.fill_splitmix(x[k * per:(k + 1) * per], n, per, 21 + k, q)
+    try:
+        out = {}
+        for walk in (0, 1, 2):
+            hx.set_tuning("walk14", walk)
+            f = torch.empty_like(x)
+            hx.ComputeForwardRNS(plans, f, x, 1, 1)
+            i = torch.empty_like(x)
+            hx.ComputeInverseRNS(plans, i, f, 1, 1)
+            assert torch.equal(i, x)
+            out[walk] = f
+        assert torch.equal(out[0], out[1]) and torch.equal(out[0], out[2])
+        for k, q in enumerate(moduli):
+            rows = [k * per, k * per + per - 1]
+            assert (host(hx, out[1][rows]) == ho.NTT(n, q).forward(host(hx, x[rows]), 1, 1)).all()
+    finally:
+        hx.set_tuning("walk14", 1)
+
+
 def test_ntt_headline_full_size_properties(hx, ho):
     """BASELINE configs[2] at full size: N=65536, 55-bit q, batch=4096 (2 GiB).
     Size-independent properties on the device plus oracle spot checks."""

@@ -126,8 +126,8 @@ constexpr u32 kStageMaskShift = 8;
 //
 // Access kinds.  kStream = nontemporal (the `nt` bit): a pass streams its data
 // exactly once, and marking the accesses so is worth 4-6 % on the HBM-bound strided
-// pass and 3 % on the forward tile pass (measured; on the inverse tile pass it is
-// neutral and slows the strided pass that follows, so it is not used there).
+// pass and 3 % on the forward tile pass; the single-plan inverse tile pass streams too since round 6
+// (0.7 % of the headline step; the multi-plan inverse keeps plain accesses).
 enum : int { kPlain = 0, kStream = 1 };
 
 template <int KIND>
@@ -1131,11 +1131,15 @@ tile_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst m
   // inverse +65 / +53 % slower, round 3.  And a tile-index-major order -- consecutive workgroups
   // take the same tile of consecutive polynomials, everything in flight sharing one set of
   // per-lane twiddles (31.5 KiB: L1-resident): forward +1 %, inverse +8 % slower, round 3.)
-  // forward: streamed loads and stores; inverse followed by a strided pass: plain (see ld_global)
+  // streamed loads and stores
   // (an inverse pass that ends the transform -- the one-kernel plans, N <= 2^14 -- streams too:
   // 2-7 % at 1 GiB batches, round 3; its stores through an LDS copy-out, tile-contiguous per
   // wave like the forward's: slower; its data loads ahead of its twiddle loads: no effect)
-  constexpr int kKind = (FWD || (LAST && CB == 0)) ? kStream : kPlain;
+  // (round 6, same-box A/B at N = 65536 x 4096, profiles/r6_inverse_access_kind_ab.txt: an inverse
+  // pass followed by a strided pass streams too -- tile pass -2.4 % (Lazy) / -3 % (Fp64) / -4 %
+  // (Small), the strided pass behind it +0 ... +2 %, the step -0.7 ... -0.8 %; round 3 had measured
+  // it neutral)
+  constexpr int kKind = kStream;
   tile_body<FWD, S, CB, TL, GUARD, A, LAST, kKind, kKind>(lds, out, in, tw, m, log_n, flags, total, il,
                                                           blockIdx.x);
 }

@@ -200,10 +200,10 @@ struct Staging {
           (void)slot_free(0);
           (void)slot_free(1);
           if (stream) (void)hipStreamSynchronize(stream);
-                if (stream) release_stream_workspaces(stream);
-            if (buf) (void)hipFree(buf);
+          if (stream) release_stream_workspaces(stream);
+          if (buf) (void)hipFree(buf);
           if (stream) (void)hipStreamDestroy(stream);
-              }
+        }
         HX_HIP(hipSetDevice(dev));
       }
       buf = nullptr;
@@ -995,6 +995,12 @@ static size_t host_bounce_max_bytes() { return g_host_bounce_max_bytes.load(); }
 // and moduli were seen before on the same stream is replayed from a captured HIP graph; 0 = the
 // launches are always enqueued one by one.
 static std::atomic<u32> g_ks_graph{1};
+// "ks_fuse": 1 (default) = the rounding and finish stages of KeySwitch ride on the load / store of
+// the forward transform between them (round 6), 0 = stage by stage (A/B).
+static std::atomic<u32> g_ks_fuse{1};
+// Bumped by every hexl_amd_set_tuning call: part of the key of a captured KeySwitch sequence, so a
+// graph captured under other tuning values (another kernel selection) is never replayed.
+static std::atomic<u64> g_tuning_epoch{0};
 constexpr int kKsGraphMaxTargets = 4;
 // hexl_amd_get_counter
 static std::atomic<u64> g_ks_graph_captures{0}, g_ks_graph_replays{0}, g_ks_eager{0};
@@ -1005,6 +1011,10 @@ static bool set_host_tuning(const char* key, uint64_t value) {
   }
   if (strcmp(key, "ks_graph") == 0 && value <= 1) {
     g_ks_graph = (u32)value;
+    return true;
+  }
+  if (strcmp(key, "ks_fuse") == 0 && value <= 1) {
+    g_ks_fuse = (u32)value;
     return true;
   }
   if (strcmp(key, "host_direct_copy") == 0 && value <= 1) {
@@ -1574,6 +1584,36 @@ static int key_switch_device(u64* result, const u64* t_target_iter, u64 T, u64 n
     u64* t_last = prod + D * T * C * n;  // prod[D][.][.]: T C contiguous polynomials
     e = ntt_inverse_launch(plan[D]->t, t_last, t_last, T * C, 2, st);
     if (e != hipSuccess) return hip_fail(e, "KeySwitch inverse NTT (last)");
+    if (g_ks_fuse.load() != 0) {
+      // Round 6: rounding and finish ride on the forward transform of the corrections -- its first
+      // pass reads the last component through a source map and rounds it on load (kRoundFirst),
+      // its last pass folds its output into the result (KsEpilogue): two launches and the write +
+      // read of two T C D-polynomial buffers less.  Degrees the multi-plan kernels do not serve
+      // (below 4096) take the stage-by-stage sequence below.
+      MultiMap map{};
+      map.inner = 1;
+      map.period = (u32)D;
+      map.src_stride = 1;
+      map.rnd_qk = rd.qk;
+      map.rnd_barrett = rd.barrett_k;
+      map.rnd_half = rd.qk_half;
+      KsEpilogue ep{};
+      ep.result = result;
+      ep.prod = prod;
+      ep.decomp = (u32)D;
+      ep.tc = (u32)(T * C);
+      for (u64 i = 0; i < D; ++i) {
+        map.plan_tab[i] = (uint8_t)i;
+        map.src_tab[i] = (uint8_t)(rd.mod[i].reduce ? 0x80 : 0);
+        ep.s[i] = fin.mod[i].s;
+        ep.sp[i] = fin.mod[i].sp;
+      }
+      std::vector<const NttTables*> tabs(plan.size());
+      for (size_t k = 0; k < plan.size(); ++k) tabs[k] = &plan[k]->t;
+      e = ntt_multi_launch(true, tabs.data(), (u32)tabs.size(), map, T * C * D, tbuf, t_last, 4, st, &ep);
+      if (e == hipSuccess) return HEXL_AMD_OK;
+      if (e != hipErrorNotSupported) return hip_fail(e, "KeySwitch fused tail");
+    }
     e = ks_round_launch(tbuf, prod, dims, rd, st);
     if (e != hipSuccess) return hip_fail(e, "KeySwitch rounding");
     {
@@ -1607,8 +1647,9 @@ static int key_switch_device(u64* result, const u64* t_target_iter, u64 T, u64 n
     return enqueue();
   }
   std::vector<uint64_t> key;
-  key.reserve(10 + K + 2 * D);
-  for (u64 v : {(u64)(uintptr_t)result, (u64)(uintptr_t)t_target_iter, (u64)(uintptr_t)ws, T, n, D, K, R, C})
+  key.reserve(11 + K + 2 * D);
+  for (u64 v : {(u64)(uintptr_t)result, (u64)(uintptr_t)t_target_iter, (u64)(uintptr_t)ws, T, n, D, K, R, C,
+                g_tuning_epoch.load(std::memory_order_relaxed)})
     key.push_back(v);
   for (u64 i = 0; i < K; ++i) key.push_back(moduli[i]);
   for (u64 i = 0; i < D; ++i) key.push_back(msf[i]);
@@ -1847,6 +1888,7 @@ int hexl_amd_get_counter(const char* key, uint64_t* value) {
 
 int hexl_amd_set_tuning(const char* key, uint64_t value) {
   if (!key) return fail(HEXL_AMD_ERR_INVALID_ARG, "key == nullptr");
+  g_tuning_epoch.fetch_add(1, std::memory_order_relaxed);
   if (set_host_tuning(key, value)) return HEXL_AMD_OK;
   if (set_tuning(key, value) != 0)
     return fail(HEXL_AMD_ERR_INVALID_ARG, "unknown tuning key or value out of range: %s", key);

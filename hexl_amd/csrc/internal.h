@@ -116,20 +116,28 @@ constexpr int kMaxMultiPeriod = 1024;
 // (inner must be 1) polynomial p reads
 //   operand[(p / period) * src_stride + (src_tab[p % period] & 0x7f)]
 // and reduces every word modulo its own modulus first when bit 7 of the entry is set.
+// With rnd_qk != 0 (and a source map) the words are rounded on load first (ntt_kernels.hip:
+// kRoundFirst): x' = (x + rnd_half) mod rnd_qk, reduced modulo the polynomial's own modulus where
+// bit 7 of its entry says so, plus the correction q - (rnd_half mod q) -- the rounding stage of
+// KeySwitch riding on the load of the forward transform that consumes it.
 struct MultiMap {
   u32 inner, period;
   uint8_t plan_tab[kMaxMultiPeriod];
   u32 src_stride;
   uint8_t src_tab[kMaxMultiPeriod];
+  u64 rnd_qk, rnd_barrett, rnd_half;
 };
 
 // One transform over `polys` polynomials of several moduli (all plans: same degree in
 // [2^12, 2^17]; tabs[k]->dev set; num_plans <= kMaxMultiPlans).  Plans of different
 // arithmetic policies are served by one launch sequence per policy.  Returns
 // hipErrorNotSupported when the shapes do not fit; the caller then loops over plans.
+// epi (forward only): the last pass folds its output into a KeySwitch result instead of storing
+// it (KsEpilogue below); `result` then only holds what earlier passes hand over.
+struct KsEpilogue;
 hipError_t ntt_multi_launch(bool forward, const struct NttTables* const* tabs, u32 num_plans,
                             const MultiMap& map, u64 polys, u64* result, const u64* operand,
-                            u64 out_mf, hipStream_t st);
+                            u64 out_mf, hipStream_t st, const KsEpilogue* epi = nullptr);
 
 hipError_t ntt_forward_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
                               u64 out_mf, hipStream_t st);
@@ -214,6 +222,18 @@ struct KsFinishMod {
 struct KsFinish {
   KsFinishMod mod[kKsMaxDecomp];
 };
+// The finish stage of KeySwitch (key-switch-internal.cpp:180-196) riding on the store of the last
+// forward transform (ntt_kernels.hip: fwd_copy_out_finish; round 6): polynomial p of the launch is
+// (target * C + k) * D + i; its transformed words t are not stored but folded into
+//   result[p][l] = (result[p][l] + ((prod[i][target * C + k][l] - t) mod q_i) * s_i) mod q_i .
+struct KsEpilogue {
+  u64* result;
+  const u64* prod;
+  u32 decomp;  // D
+  u32 tc;      // targets * key components
+  u64 s[kKsMaxDecomp], sp[kKsMaxDecomp];  // modswitch factor of modulus i in [0, q_i), Shoup companion
+};
+
 hipError_t ks_gather_launch(u64* ntt_buf, const u64* t_target, const KsDims& d,
                             const KsGatherAll& g, hipStream_t st);
 hipError_t ks_mac_launch(u64* prod, const u64* t_target_iter, const u64* ntt_buf, const KsDims& d,

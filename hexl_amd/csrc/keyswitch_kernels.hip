@@ -57,6 +57,8 @@ ks_gather_kernel(u64* ntt_buf, const u64* t_target, KsDims d, KsGatherAll g) {
 // components -- to kMacTargets targets: the keys (D * C * (D + 1) polynomials, the largest
 // operand of the whole KeySwitch) are read once per tile of targets instead of once per
 // target, and a target's operands once per pair of components instead of once per component.
+// (2, 4 and 8 targets per tile measured equal within 2 % of the whole call at 256 targets, n = 16384,
+// round 6: the keys come out of the L2 / Infinity Cache either way)
 constexpr int kMacTargets = 4;
 __global__ void __launch_bounds__(256)
 ks_mac_kernel(u64* prod, const u64* t_target_iter, const u64* ntt_buf, KsDims d, KsMacAll m) {

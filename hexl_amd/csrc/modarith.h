@@ -104,6 +104,11 @@ struct ModConst {
   // Fp64 policy only:
   double qd;    // q
   double qinv;  // 1 / q, rounded to nearest
+  // Rounding on load (KeySwitch: a forward transform whose input is the last RNS component,
+  // rounded to the special modulus and brought to this one -- key-switch-internal.cpp:146-175;
+  // set per launch by the multi-plan kernels, zero otherwise): the special modulus q_k, its
+  // single-word Barrett factor and q_k / 2.
+  u64 rnd_qk, rnd_barrett, rnd_half;
 };
 
 inline ModConst make_mod_const(u64 q) {  // host only
@@ -122,6 +127,7 @@ inline ModConst make_mod_const(u64 q) {  // host only
   m.fin_mul = (u32)((((unsigned __int128)1) << (31 + b)) / q);
   m.qd = (double)q;  // exact for q < 2^53; only read for q < 2^50 (the Fp64 family)
   m.qinv = 1.0 / m.qd;
+  m.rnd_qk = m.rnd_barrett = m.rnd_half = 0;
   return m;
 }
 

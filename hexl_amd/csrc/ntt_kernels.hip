@@ -54,6 +54,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <type_traits>
 #include <mutex>
 
 #include "internal.h"
@@ -114,6 +115,12 @@ constexpr u32 kFirstPass = 4;
 // Bit 3 (with bit 2): the input words are arbitrary 64-bit values and are reduced modulo q
 // on load (multi-plan launches with a source map, see MultiMap).
 constexpr u32 kReduceFirst = 8;
+// Bit 4 (with bit 2; multi-plan launches whose map carries rounding constants): the input words
+// are first rounded to the special modulus of a KeySwitch -- x' = (x + q_k / 2) mod q_k, the
+// reference's AddUIntMod-free form of key-switch-internal.cpp:146-160 -- then reduced modulo q if
+// bit 3 says so, and the correction q - (q_k / 2 mod q) is added (:162-175): what ks_round_kernel
+// wrote to a buffer of its own before round 6.
+constexpr u32 kRoundFirst = 16;
 // Bits 8 and up (forward passes of the bounded members of the Lazy family only, modarith.h): bit
 // 8 + s set = the x operands of stage s of this pass lose kLimit/2 * q by one sign-tested
 // subtraction before the stage (the host walks the bound of the values through the whole network
@@ -150,6 +157,25 @@ __device__ __forceinline__ u64 load_global(const u64* uniform_base, u32 byte_off
 template <int KIND>
 __device__ __forceinline__ void store_global(u64* uniform_base, u32 byte_off, u64 v) {
   st_global<KIND>(reinterpret_cast<u64*>(reinterpret_cast<char*>(uniform_base) + byte_off), v);
+}
+
+// The caller's words on entry of a first pass, as the flags say (kReduceFirst, kRoundFirst).
+template <int E>
+__device__ __forceinline__ void entry_words(u64* x, u32 flags, const ModConst& m) {
+  if (flags & kRoundFirst) {
+    // (ks_round_kernel's arithmetic, word for word)
+    const u64 fix = m.q - reduce_any_straight(m.rnd_half, m.q, m.barrett);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const u64 t = x[e] + m.rnd_half;
+      u64 v = csub(t - __umul64hi(t, m.rnd_barrett) * m.rnd_qk, m.rnd_qk);
+      if (flags & kReduceFirst) v = reduce_any(v, m.q, m.barrett);
+      x[e] = v + fix;
+    }
+  } else if (flags & kReduceFirst) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) x[e] = reduce_any_straight(x[e], m.q, m.barrett);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -545,10 +571,7 @@ __device__ __forceinline__ void strided_body(u64* out, const u64* in,
   if (FWD) __builtin_amdgcn_s_setprio(0);
   if constexpr (R < 5 && DATA_FIRST) load_twiddles<R, CTW>(wv, twa, node);
   if (flags & kFirstPass) {
-    if (flags & kReduceFirst) {
-#pragma unroll
-      for (int e = 0; e < E; ++e) x[e] = reduce_any_straight(x[e], m.q, m.barrett);
-    }
+    if (flags & (kReduceFirst | kRoundFirst)) entry_words<E>(x, flags, m);
 #pragma unroll
     for (int e = 0; e < E; ++e) x[e] = to_internal<A>(x[e], m);
   }
@@ -645,6 +668,7 @@ __device__ __forceinline__ const u64* multi_source(const MultiCtx& mc, u32 poly,
   const u32 e = kernarg_byte(mc.map.src_tab, s);
   const u32 src = grp * mc.map.src_stride + (e & 0x7f);
   if (e & 0x80) flags |= kReduceFirst;
+  if (mc.map.rnd_qk) flags |= kRoundFirst;
   return in + (((long long)src - (long long)poly) << log_n);
 }
 template <class A>
@@ -669,7 +693,10 @@ strided_pass_multi(u64* out, const u64* in, MultiCtx mc, u32 log_n, u32 a0, u32 
   u32 k;
   const PlanDev* __restrict__ pd = multi_plan(mc, poly, policy_id<A>(), k);
   if (!pd) return;
-  const ModConst m = pd->mod;
+  ModConst m = pd->mod;
+  m.rnd_qk = mc.map.rnd_qk;  // (rounding on load: see kRoundFirst)
+  m.rnd_barrett = mc.map.rnd_barrett;
+  m.rnd_half = mc.map.rnd_half;
   const InvLast il = pd->il;
   in = multi_source(mc, poly, log_n, in, flags);
   // (data first -- see strided_body -- except where the 5-stage forward subtree of a bounded
@@ -822,10 +849,7 @@ template <int S, class A, bool REDUCE>
 __device__ __forceinline__ void fetch_convert_first(u64* x, u32 flags, const ModConst& m) {
   constexpr int kE = el_of(S);
   if constexpr (REDUCE) {
-    if (flags & kReduceFirst) {
-#pragma unroll
-      for (int i = 0; i < kE; ++i) x[i] = reduce_any_straight(x[i], m.q, m.barrett);
-    }
+    if (flags & (kReduceFirst | kRoundFirst)) entry_words<kE>(x, flags, m);
   }
 #pragma unroll
   for (int i = 0; i < kE; ++i) x[i] = to_internal<A>(x[i], m);
@@ -937,10 +961,7 @@ __device__ __forceinline__ void fetch_tile(u64* x, const u64* in, u32 tid, const
   }
   if constexpr (!CONVERT) return;
   if (flags & kFirstPass) {
-    if (flags & kReduceFirst) {
-#pragma unroll
-      for (int i = 0; i < kE; ++i) x[i] = reduce_any_straight(x[i], m.q, m.barrett);
-    }
+    if (flags & (kReduceFirst | kRoundFirst)) entry_words<kE>(x, flags, m);
 #pragma unroll
     for (int i = 0; i < kE; ++i) x[i] = to_internal<A>(x[i], m);
   }
@@ -949,10 +970,7 @@ template <int S, class A>
 __device__ __forceinline__ void fetch_convert(u64* x, u32 flags, const ModConst& m) {
   constexpr int kE = el_of(S);
   if (flags & kFirstPass) {
-    if (flags & kReduceFirst) {
-#pragma unroll
-      for (int i = 0; i < kE; ++i) x[i] = reduce_any_straight(x[i], m.q, m.barrett);
-    }
+    if (flags & (kReduceFirst | kRoundFirst)) entry_words<kE>(x, flags, m);
 #pragma unroll
     for (int i = 0; i < kE; ++i) x[i] = to_internal<A>(x[i], m);
   }
@@ -992,6 +1010,44 @@ __device__ __forceinline__ void fwd_copy_out(u64* lds, u64* out, u32 tid, const 
   }
 }
 
+// End of the last forward transform of a KeySwitch (multi-plan launches with a KsEpilogue): the
+// run's words t (lazy, < 4q) are not stored; result[p][l] += ((prod[i][tc][l] + 4q - t) mod q) * s
+// mod q -- ks_finish_kernel's arithmetic, word for word (key-switch-internal.cpp:180-196).
+struct NoEpilogue {};
+template <int S, int CB, int TL, class A>
+__device__ __forceinline__ void fwd_copy_out_finish(u64* lds, u32 tid, const TileGeom& g, u32 log_n,
+                                                    const ModConst& m, const KsEpilogue& ep) {
+  static_assert(CB == 0, "bottom tiles only");
+  constexpr int kE = el_of(S);
+  const u32 poly = __builtin_amdgcn_readfirstlane((u32)(g.base >> log_n));
+  const u32 i = poly % ep.decomp, tc = poly / ep.decomp;
+  const u64 within = g.base & ((1ull << log_n) - 1);  // the tile's first word inside its polynomial
+  const u64* pp = ep.prod + ((((u64)i * ep.tc + tc) << log_n) + within);
+  u64* dd = ep.result + (((u64)poly << log_n) + within);
+  const u64 q = m.q, s = ep.s[i], sp = ep.sp[i];
+  u64 v[kE], pv[kE], dv[kE];
+  u32 a0 = lds_slot<re_of(S)>(xfer_p0<false, S, CB, TL>(tid, 0)) << 3;
+  HX_OPAQUE(a0);
+#pragma unroll
+  for (int k = 0; k < kE; ++k) v[k] = lds_at(lds, a0 ^ (lds_slot<re_of(S)>(xfer_dp<false, S, CB>(k)) << 3));
+  const u32 off0 = xfer_p0<false, S, CB, TL>(tid, 0) << 3;
+#pragma unroll
+  for (int k = 0; k < kE; ++k) {
+    pv[k] = load_global<kStream>(pp + xfer_dp<false, S, CB>(k), off0);
+    dv[k] = load_global<kStream>(dd + xfer_dp<false, S, CB>(k), off0);
+  }
+#pragma unroll
+  for (int k = 0; k < kE; ++k) {
+    const u64 t = fwd_finish<A>(v[k], m, false);
+    u64 x = pv[k] + (q << 2) - t;  // < 8q
+    x = csub(x, q << 2);
+    x = csub(x, q << 1);
+    x = csub(x, q);
+    const u64 r = csub(mul_lazy(x, s, sp, q), q);
+    store_global<kStream>(dd + xfer_dp<false, S, CB>(k), off0, csub(dv[k] + r, q));
+  }
+}
+
 // One workgroup per tile; the hardware refills a CU's slots as workgroups retire.
 // (Three persistent variants were built and measured in round 1 -- register
 // prefetch at 8 and at 6 waves per SIMD, LDS-direct DMA prefetch -- all slower, see
@@ -1013,11 +1069,11 @@ constexpr int min_waves() { return S >= 14 ? 4 : (S >= 10 || CB > 0) ? 8 : 6; }
 // LDK / STK: access kinds of the global loads and stores (see ld_global).  The data
 // pointers are not __restrict__: transforms run in place (out == in).
 template <bool FWD, int S, int CB, int TL, bool GUARD, class A, bool LAST, int LDK, int STK,
-          bool DATA_FIRST = false, bool CTW = false>
+          bool DATA_FIRST = false, bool CTW = false, class Epi = NoEpilogue>
 __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
                                           const ulonglong2* __restrict__ tw_raw, const ModConst& m,
                                           u32 log_n, u32 flags, u64 total, const InvLast& il,
-                                          u32 bid) {
+                                          u32 bid, const Epi& epi = Epi()) {
   constexpr int kRE = re_of(S), kE = el_of(S);
   using RD = Rounds<S, CB>;
   constexpr int NR = RD::NR;
@@ -1061,7 +1117,9 @@ __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
     // 512 tile-contiguous elements, 64 per access; final reduction fused
     // (the finish kind is uniform: three straight-line copies of the copy-out behind scalar
     // branches instead of a branch and a select per element, with all LDS reads up front)
-    if (finish == 2)
+    if constexpr (!std::is_same<Epi, NoEpilogue>::value)
+      fwd_copy_out_finish<S, CB, TL, A>(lds, tid, g, log_n, m, epi);
+    else if (finish == 2)
       fwd_copy_out<2, S, CB, TL, GUARD, A, STK>(lds, out, tid, g, total, m);
     else if (finish)
       fwd_copy_out<1, S, CB, TL, GUARD, A, STK>(lds, out, tid, g, total, m);
@@ -1146,21 +1204,34 @@ tile_pass(u64* out, const u64* in, const ulonglong2* __restrict__ tw, ModConst m
 
 // Bottom pass over polynomials of several moduli (see strided_pass_multi); N >= 2^TL, so
 // a tile lies in one polynomial and no tile is ragged.
-template <bool FWD, int S, int TL, class A, bool LAST>
+// EPI (forward): the pass ends a KeySwitch -- its output is folded into the result (KsEpilogue).
+template <bool EPI>
+struct EpilogueArg {
+  typedef NoEpilogue T;
+};
+template <>
+struct EpilogueArg<true> {
+  typedef KsEpilogue T;
+};
+template <bool FWD, int S, int TL, class A, bool LAST, bool EPI = false>
 __global__ void __launch_bounds__(1 << (TL - re_of(S)), (min_waves<S, 0>()))
-tile_pass_multi(u64* out, const u64* in, MultiCtx mc, u32 log_n, u32 flags, u64 total) {
+tile_pass_multi(u64* out, const u64* in, MultiCtx mc, u32 log_n, u32 flags, u64 total,
+                typename EpilogueArg<EPI>::T epi) {
   __shared__ u64 lds[1 << TL];
   const u32 poly = (u32)(((u64)blockIdx.x << TL) >> log_n);
   u32 k;
   const PlanDev* __restrict__ pd = multi_plan(mc, poly, policy_id<A>(), k);
   if (!pd) return;
-  const ModConst m = pd->mod;
+  ModConst m = pd->mod;
+  m.rnd_qk = mc.map.rnd_qk;  // (rounding on load: see kRoundFirst)
+  m.rnd_barrett = mc.map.rnd_barrett;
+  m.rnd_half = mc.map.rnd_half;
   const InvLast il = pd->il;
   in = multi_source(mc, poly, log_n, in, flags);
   // (data-first only for the small tiles: with 16 elements per thread it costs registers)
   tile_body<FWD, S, 0, TL, false, A, LAST, FWD ? kStream : kPlain, FWD ? kStream : kPlain, (S <= 12),
-            true>(
-      lds, out, in, FWD ? mc.tw_fwd[k] : mc.tw_inv[k], m, log_n, flags, total, il, blockIdx.x);
+            true, typename EpilogueArg<EPI>::T>(
+      lds, out, in, FWD ? mc.tw_fwd[k] : mc.tw_inv[k], m, log_n, flags, total, il, blockIdx.x, epi);
 }
 
 // ---------------------------------------------------------------------------
@@ -1237,6 +1308,9 @@ __device__ __forceinline__ void tile_walk(u64* lds, u64* out, const u64* in_arg,
     if constexpr (MULTI) {
       const PlanDev* __restrict__ pd = mc->p[k];
       m = pd->mod;
+      m.rnd_qk = mc->map.rnd_qk;  // (rounding on load: see kRoundFirst)
+      m.rnd_barrett = mc->map.rnd_barrett;
+      m.rnd_half = mc->map.rnd_half;
       il = pd->il;
       tw = reinterpret_cast<const TwT<A>*>(FWD ? mc->tw_fwd[k] : mc->tw_inv[k]);
     }
@@ -1477,7 +1551,8 @@ static hipError_t launch_strided(int R, u64* out, const u64* in, const ulonglong
 template <bool FWD, int TL, class A>
 static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2* tw,
                                 const ModConst& m, u32 log_n, u32 finish, u64 batch,
-                                const InvLast& il, hipStream_t st, const MultiCtx* mc = nullptr) {
+                                const InvLast& il, hipStream_t st, const MultiCtx* mc = nullptr,
+                                const KsEpilogue* epi = nullptr) {
   const u64 total = batch << log_n;
   const unsigned grid = (unsigned)((total + (1u << TL) - 1) >> TL);
   const bool guard = (total & ((1u << TL) - 1)) != 0;  // the batch ends inside the last tile
@@ -1486,9 +1561,19 @@ static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2
     if constexpr (TL >= 11) {
       if (log_n < (u32)TL || S < 11 || S > 14 || S > TL) return hipErrorNotSupported;
       const bool last = !FWD && (u32)S == log_n;
+      if (epi) {  // the pass ends a KeySwitch: its output is folded into the result (KsEpilogue)
+        if constexpr (FWD) {
+          if (S != TL) return hipErrorNotSupported;
+          hipLaunchKernelGGL((tile_pass_multi<true, TL, TL, A, false, true>), dim3(grid),
+                             dim3(1 << (TL - re_of(TL))), 0, st, out, in, *mc, log_n, finish, total, *epi);
+          return hipGetLastError();
+        } else {
+          return hipErrorInvalidValue;
+        }
+      }
 #define HX_LAUNCH_BM(T, LST)                                                                \
   hipLaunchKernelGGL((tile_pass_multi<FWD, T, TL, A, LST>), dim3(grid), dim3(1 << (TL - re_of(T))), \
-                     0, st, out, in, *mc, log_n, finish, total)
+                     0, st, out, in, *mc, log_n, finish, total, NoEpilogue{})
       if (S == 11) {
         if constexpr (TL == 11) {
           if (last) HX_LAUNCH_BM(11, !FWD); else HX_LAUNCH_BM(11, false);
@@ -1652,16 +1737,16 @@ template <bool FWD, class A>
 static hipError_t launch_bottom_tl(int tl, int S, u64* out, const u64* in, const ulonglong2* tw,
                                    const ModConst& m, u32 log_n, u32 finish, u64 batch,
                                    const InvLast& il, hipStream_t st,
-                                   const MultiCtx* mc = nullptr) {
+                                   const MultiCtx* mc = nullptr, const KsEpilogue* epi = nullptr) {
   if (tl == 10)
-    return launch_bottom<FWD, 10, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc);
+    return launch_bottom<FWD, 10, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc, epi);
   if (tl == 11)
-    return launch_bottom<FWD, 11, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc);
+    return launch_bottom<FWD, 11, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc, epi);
   if (tl == 13)
-    return launch_bottom<FWD, 13, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc);
+    return launch_bottom<FWD, 13, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc, epi);
   if (tl == 14)
-    return launch_bottom<FWD, 14, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc);
-  return launch_bottom<FWD, 12, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc);
+    return launch_bottom<FWD, 14, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc, epi);
+  return launch_bottom<FWD, 12, A>(S, out, in, tw, m, log_n, finish, batch, il, st, mc, epi);
 }
 
 
@@ -1669,7 +1754,7 @@ static hipError_t launch_bottom_tl(int tl, int S, u64* out, const u64* in, const
 template <class A>
 static hipError_t forward_seq(const NttTables& t, const Plan& p, u64* result, const u64* operand,
                               u64 batch, u64 out_mf, hipStream_t st,
-                              const MultiCtx* mc = nullptr) {
+                              const MultiCtx* mc = nullptr, const KsEpilogue* epi = nullptr) {
   const u64* src = operand;
   InvLast il{};
   hipError_t e;
@@ -1703,7 +1788,7 @@ static hipError_t forward_seq(const NttTables& t, const Plan& p, u64* result, co
   }
   const u32 fin = out_mf == 1 ? 2 : 1;
   return launch_bottom_tl<true, A>(p.tl, p.bottom, result, src, t.fwd, t.mod, t.log_n,
-                                   fin | first | stage_mask(p.bottom), batch, il, st, mc);
+                                   fin | first | stage_mask(p.bottom), batch, il, st, mc, epi);
 }
 
 template <class A>
@@ -1741,10 +1826,11 @@ static hipError_t transform_impl(const NttTables& t, u64* result, const u64* ope
 
 template <class A>
 static hipError_t multi_impl(bool forward, const NttTables& t0, const MultiCtx& mc, u64 polys,
-                             u64* result, const u64* operand, u64 out_mf, hipStream_t st) {
+                             u64* result, const u64* operand, u64 out_mf, hipStream_t st,
+                             const KsEpilogue* epi) {
   // the multi-plan kernels: 11 / 12 bottom stages, or the whole of N = 8192 / 16384
   Plan p = make_plan((int)t0.log_n, /*allow_tile13=*/true, polys);
-  return forward ? forward_seq<A>(t0, p, result, operand, polys, out_mf, st, &mc)
+  return forward ? forward_seq<A>(t0, p, result, operand, polys, out_mf, st, &mc, epi)
                  : inverse_seq<A>(t0, p, result, operand, polys, out_mf, st, &mc);
 }
 
@@ -1753,7 +1839,8 @@ static hipError_t multi_impl(bool forward, const NttTables& t0, const MultiCtx& 
   hipError_t transform_entry_##NAME(bool forward, const NttTables& t, u64* result,              \
                                     const u64* operand, u64 batch, u64 out_mf, hipStream_t st); \
   hipError_t multi_entry_##NAME(bool forward, const NttTables& t0, const MultiCtx& mc, u64 polys, \
-                                u64* result, const u64* operand, u64 out_mf, hipStream_t st);
+                                u64* result, const u64* operand, u64 out_mf, hipStream_t st,    \
+                                const KsEpilogue* epi);
 HX_POLICY_ENTRY_DECL(small)
 HX_POLICY_ENTRY_DECL(fp64)
 HX_POLICY_ENTRY_DECL(lazy)
@@ -1771,8 +1858,9 @@ HX_POLICY_ENTRY_DECL(fp64l)
                    : transform_impl<false, A>(t, result, operand, batch, out_mf, st);           \
   }                                                                                             \
   hipError_t multi_entry_##NAME(bool forward, const NttTables& t0, const MultiCtx& mc, u64 polys, \
-                                u64* result, const u64* operand, u64 out_mf, hipStream_t st) {  \
-    return multi_impl<A>(forward, t0, mc, polys, result, operand, out_mf, st);                  \
+                                u64* result, const u64* operand, u64 out_mf, hipStream_t st,    \
+                                const KsEpilogue* epi) {                                        \
+    return multi_impl<A>(forward, t0, mc, polys, result, operand, out_mf, st, epi);             \
   }
 #if HX_TU_POLICY(0)
 HX_POLICY_ENTRY_DEF(small, Small)
@@ -1856,7 +1944,7 @@ static bool multi_plan_supported(u32 log_n, u64 polys) {
 }
 hipError_t ntt_multi_launch(bool forward, const NttTables* const* tabs, u32 num_plans,
                             const MultiMap& map, u64 polys, u64* result, const u64* operand,
-                            u64 out_mf, hipStream_t st) {
+                            u64 out_mf, hipStream_t st, const KsEpilogue* epi) {
   if (num_plans == 0 || polys == 0) return hipSuccess;
   if (num_plans > (u32)kMaxMultiPlans || polys >= (1ull << 31) || map.inner == 0 ||
       map.period == 0 || map.period > (u32)kMaxMultiPeriod || (map.src_stride && map.inner != 1))
@@ -1882,23 +1970,25 @@ hipError_t ntt_multi_launch(bool forward, const NttTables* const* tabs, u32 num_
   mc.one_policy = policies == 1 ? 1u : 0u;
   // nothing is enqueued unless every pass of every policy's sequence can be
   if (!multi_plan_supported(t0.log_n, polys)) return hipErrorNotSupported;
+  if (epi && (!forward || out_mf != 4 || epi->decomp == 0 || epi->decomp > (u32)kKsMaxDecomp))
+    return hipErrorInvalidValue;
   hipError_t e = hipSuccess;
   if (have[kPolicySmall] && e == hipSuccess)
-    e = multi_entry_small(forward, t0, mc, polys, result, operand, out_mf, st);
+    e = multi_entry_small(forward, t0, mc, polys, result, operand, out_mf, st, epi);
   if (have[kPolicyFp64] && e == hipSuccess)
-    e = multi_entry_fp64(forward, t0, mc, polys, result, operand, out_mf, st);
+    e = multi_entry_fp64(forward, t0, mc, polys, result, operand, out_mf, st, epi);
   if (have[kPolicyLazy] && e == hipSuccess)
-    e = multi_entry_lazy(forward, t0, mc, polys, result, operand, out_mf, st);
+    e = multi_entry_lazy(forward, t0, mc, polys, result, operand, out_mf, st, epi);
   if (have[kPolicyHarvey60] && e == hipSuccess)
-    e = multi_entry_harvey60(forward, t0, mc, polys, result, operand, out_mf, st);
+    e = multi_entry_harvey60(forward, t0, mc, polys, result, operand, out_mf, st, epi);
   if (have[kPolicyLazy32] && e == hipSuccess)
-    e = multi_entry_lazy32(forward, t0, mc, polys, result, operand, out_mf, st);
+    e = multi_entry_lazy32(forward, t0, mc, polys, result, operand, out_mf, st, epi);
   if (have[kPolicyLazy16] && e == hipSuccess)
-    e = multi_entry_lazy16(forward, t0, mc, polys, result, operand, out_mf, st);
+    e = multi_entry_lazy16(forward, t0, mc, polys, result, operand, out_mf, st, epi);
   if (have[kPolicyFp64L] && e == hipSuccess)
-    e = multi_entry_fp64l(forward, t0, mc, polys, result, operand, out_mf, st);
+    e = multi_entry_fp64l(forward, t0, mc, polys, result, operand, out_mf, st, epi);
   if (have[kPolicyStrict] && e == hipSuccess)
-    e = multi_entry_strict(forward, t0, mc, polys, result, operand, out_mf, st);
+    e = multi_entry_strict(forward, t0, mc, polys, result, operand, out_mf, st, epi);
   // past the check above a refusal can only come after launches were made: a hard error,
   // never the "fall back" signal
   return e == hipErrorNotSupported ? hipErrorLaunchFailure : e;

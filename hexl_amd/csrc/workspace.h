@@ -15,7 +15,7 @@
 namespace hexl_amd {
 
 enum WorkspacePurpose : int {
-  kWsFusedNtt = 0,   // scheduler state of fused_pass (ntt_kernels.hip)
+  kWsFusedNtt = 0,   // (unused since round 4: was the scheduler state of the archived fused plan, experiments/)
   kWsKeySwitch = 1,  // t_target | ntt_buf | t_poly_prod of KeySwitch (capi.cpp)
 };
 

@@ -503,6 +503,9 @@ int hexl_amd_profile_get(int i, const char** name, float* ms);
  *                      targets whose buffers, keys and moduli were seen before on the same stream
  *                      are replayed from a HIP graph captured at their second sight (one graph
  *                      launch instead of up to eleven kernel launches); 0 = always launch by launch
+ *   "ks_fuse"          1 (default) = the rounding and finish stages of KeySwitch ride on the load /
+ *                      store of the forward transform between them (two launches and two
+ *                      intermediate buffers less; degrees from 4096), 0 = stage by stage
  *   (the round-2 keys "host_pipeline_min_mb" / "host_chunk_mb" went with the chunked two-stream
  *   host pipeline they switched on: measured equal to the plain sequence, removed in round 5) */
 int hexl_amd_set_tuning(const char* key, uint64_t value);

@@ -5,15 +5,18 @@
 #include <hip/hip_runtime_api.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <tuple>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hexl_amd.h"
@@ -49,6 +52,14 @@ int hip_fail(hipError_t e, const char* what) {
     if (e_ != hipSuccess) return hip_fail(e_, #call); \
   } while (0)
 
+// Devices this process has used through the library (bit d = device d): what
+// hexl_amd_host_unregister waits for -- synchronising EVERY visible device would create a primary
+// context on each of them in every rank of a one-process-per-GPU job.
+std::atomic<uint64_t> g_devices_used{0};
+inline void note_device(int device) {
+  if (device >= 0 && device < 64) g_devices_used.fetch_or(1ull << device, std::memory_order_relaxed);
+}
+
 // Makes `device` current for the scope if it is not already.
 struct DeviceScope {
   int prev = -1;
@@ -59,6 +70,7 @@ struct DeviceScope {
   DeviceScope(const DeviceScope&) = delete;
   DeviceScope& operator=(const DeviceScope&) = delete;
   void enter(int device) {
+    note_device(device);
     err = hipGetDevice(&prev);
     if (err == hipSuccess && prev != device) {
       err = hipSetDevice(device);
@@ -103,22 +115,31 @@ struct Staging {
   void* bounce = nullptr;      // host address
   void* bounce_dev = nullptr;  // the address kernels use
   size_t bounce_cap = 0;
-  // Copies between ordinary (pageable) caller memory and the device go through these two pinned
+  // Copies between ordinary (pageable) caller memory and the device go through these pinned
   // slots, never through the runtime's own handling of pageable memory: from about 1 MiB the HIP
   // runtime pins the CALLER's pages for the duration of a copy instead of staging them, and
   // that is the path the round-4 / round-5 aborts sat in -- a GPU memory access fault on an
   // address inside the process's heap, raised while a thread was inside such a copy
-  // (EXPERIMENTS.md section 10).  staged_h2d / staged_d2h below.
-  static constexpr size_t kSlotBytes = (size_t)1 << 20;
-  void* slot[2] = {nullptr, nullptr};
-  hipEvent_t slot_ev[2] = {nullptr, nullptr};
+  // (EXPERIMENTS.md section 10).  staged_h2d / staged_d2h below.  Four slots, allocated on first
+  // use and sized by the copies that come: 1 MiB each until a copy of 4 MiB or more is seen, 4 MiB
+  // from then on (round 6: with 4 MiB pieces filled by the copy pool below the staged path moves
+  // data at the link's rate; with two 1 MiB slots and one thread's memcpy it ran at half of it).
+  static constexpr int kSlots = 4;
+  static constexpr size_t kSmallSlot = (size_t)1 << 20, kBigSlot = (size_t)4 << 20;
+  size_t slot_bytes = kSmallSlot;  // size of the slots allocated from now on (and of every live one)
+  void* slot[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t slot_ev[kSlots] = {nullptr, nullptr, nullptr, nullptr};
   // A slot is free, or in use by a DMA whose end is marked by its event (chunks in the middle of
   // a pipeline) or simply by everything enqueued on a stream so far (the last chunk of a call:
   // the caller synchronises that stream anyway, no event needed).
   enum SlotState { kSlotFree = 0, kSlotEvent = 1, kSlotStream = 2 };
-  SlotState slot_state[2] = {kSlotFree, kSlotFree};
-  hipStream_t slot_stream[2] = {nullptr, nullptr};
+  SlotState slot_state[kSlots] = {kSlotFree, kSlotFree, kSlotFree, kSlotFree};
+  hipStream_t slot_stream[kSlots] = {nullptr, nullptr, nullptr, nullptr};
   int slot_device = -1;  // the device the events belong to
+  // Second stream + "kernels of chunk k done" events of the chunk pipeline of the *_host
+  // transforms (ntt_host_pipelined): copies out run beside copies in.
+  hipStream_t stream_out = nullptr;
+  hipEvent_t chunk_ev[2] = {nullptr, nullptr};
   // A thread that ends gives its buffer and streams back (callers that run every task on
   // a fresh std::thread would otherwise leak one staging area per task).  Thread-local
   // destructors run when the thread ends and, for the main thread, at exit() BEFORE
@@ -136,27 +157,42 @@ struct Staging {
     }
     if (buf) (void)hipFree(buf);
     if (bounce) (void)hipHostFree(bounce);
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < kSlots; ++b) {
       (void)slot_free(b);
       if (slot_ev[b]) (void)hipEventDestroy(slot_ev[b]);
       if (slot[b]) (void)hipHostFree(slot[b]);
     }
+    for (int b = 0; b < 2; ++b)
+      if (chunk_ev[b]) (void)hipEventDestroy(chunk_ev[b]);
+    if (stream_out) (void)hipStreamDestroy(stream_out);
     if (stream) (void)hipStreamDestroy(stream);
   }
-  // (the current device is the one the copies' stream belongs to)
-  int ensure_slots() {
+  // (the current device is the one the copies' stream belongs to)  `bytes`: the copy at hand.
+  int ensure_slots(size_t bytes) {
     int dev = 0;
     HX_HIP(hipGetDevice(&dev));
-    for (int b = 0; b < 2; ++b) {
-      if (!slot[b]) HX_HIP(hipHostMalloc(&slot[b], kSlotBytes, hipHostMallocPortable));
+    if (bytes >= kBigSlot && slot_bytes < kBigSlot) {  // from now on: big slots
+      for (int b = 0; b < kSlots; ++b) {
+        (void)slot_free(b);
+        if (slot[b]) HX_HIP(hipHostFree(slot[b]));
+        slot[b] = nullptr;
+      }
+      slot_bytes = kBigSlot;
+    }
+    for (int b = 0; b < kSlots; ++b) {
       if (slot_ev[b] && slot_device != dev) {  // an event records on streams of its own device only
         (void)slot_free(b);
         (void)hipEventDestroy(slot_ev[b]);
         slot_ev[b] = nullptr;
       }
-      if (!slot_ev[b]) HX_HIP(hipEventCreateWithFlags(&slot_ev[b], hipEventDisableTiming));
     }
     slot_device = dev;
+    return HEXL_AMD_OK;
+  }
+  // slot b, allocated (with its event) on first use
+  int slot_ready(int b) {
+    if (!slot[b]) HX_HIP(hipHostMalloc(&slot[b], slot_bytes, hipHostMallocPortable));
+    if (!slot_ev[b]) HX_HIP(hipEventCreateWithFlags(&slot_ev[b], hipEventDisableTiming));
     return HEXL_AMD_OK;
   }
   // waits until the DMA that last used slot b is done (the host may then read or write it)
@@ -172,7 +208,7 @@ struct Staging {
     slot_stream[b] = st;
     // (only the thread's own staging stream: a caller's stream may be gone by the time the
     // slot is wanted again, an event outlives its stream)
-    if (last && st == stream) {
+    if (last && stream != nullptr && st == stream) {
       slot_state[b] = kSlotStream;
     } else {
       HX_HIP(hipEventRecord(slot_ev[b], st));
@@ -197,18 +233,24 @@ struct Staging {
     if (device != dev) {
       if (device >= 0 && (buf || stream)) {  // release what belongs to the previous device
         if (hipSetDevice(device) == hipSuccess) {
-          (void)slot_free(0);
-          (void)slot_free(1);
+          for (int b = 0; b < kSlots; ++b) (void)slot_free(b);
           if (stream) (void)hipStreamSynchronize(stream);
+          if (stream_out) (void)hipStreamSynchronize(stream_out);
           if (stream) release_stream_workspaces(stream);
           if (buf) (void)hipFree(buf);
           if (stream) (void)hipStreamDestroy(stream);
+          if (stream_out) (void)hipStreamDestroy(stream_out);
+          for (int b = 0; b < 2; ++b) {
+            if (chunk_ev[b]) (void)hipEventDestroy(chunk_ev[b]);
+            chunk_ev[b] = nullptr;
+          }
         }
         HX_HIP(hipSetDevice(dev));
       }
       buf = nullptr;
       cap = 0;
       stream = nullptr;
+      stream_out = nullptr;
       device = dev;
     }
     if (!stream) HX_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -225,23 +267,150 @@ struct Staging {
 thread_local Staging g_staging;
 
 // "host_direct_copy": 0 (default) = copies between ordinary host memory and the device go through
-// the calling thread's pinned slots (staged_h2d / staged_d2h: a host memcpy per MiB overlapped
-// with the DMA of the previous one -- the rate of a memcpy, 10-20 GB/s); 1 = they are handed to
-// hipMemcpyAsync as they are (the link's 54 GB/s from 1 MiB on, with the runtime pinning the
+// the calling thread's pinned slots (staged_h2d / staged_d2h: a host copy per slot overlapped with
+// the DMA of the others); 1 = they are handed to hipMemcpyAsync as they are (the runtime pins the
 // caller's pages on the fly: for callers on a runtime they trust).
 std::atomic<u32> g_host_direct_copy{0};
 
+// Host-side copies between caller memory and the pinned slots.  One thread's memcpy moves
+// 12-25 GB/s, the link 54 GB/s each way: copies of 1 MiB and more are cut into 256 KiB pieces that a
+// small pool of helper threads (created at the first such copy, asleep otherwise, "host_copy_threads"
+// of them including the caller: default 6, 1 = the calling thread alone) takes from a shared counter.
+// One parallel copy at a time per process: a second calling thread that finds the pool busy copies
+// by itself.  The reference library has no threads of its own; these only ever touch the
+// caller's buffer between the call's entry and its return.
+std::atomic<u32> g_host_copy_threads{6};
+class CopyPool {
+ public:
+  static CopyPool& get() {
+    static CopyPool pool;
+    return pool;
+  }
+  // dst <- src, and (bytes2 != 0) dst2 <- src2 in the same job (a pipeline's copy in and copy out)
+  void copy(void* dst, const void* src, size_t bytes, void* dst2 = nullptr, const void* src2 = nullptr,
+            size_t bytes2 = 0) {
+    const u32 want = g_host_copy_threads.load(std::memory_order_relaxed);
+    if (bytes + bytes2 < kMinParallel || want <= 1 || !busy_.try_lock()) {
+      memcpy(dst, src, bytes);
+      if (bytes2) memcpy(dst2, src2, bytes2);
+      return;
+    }
+    grow(want - 1);
+    // (a job object of its own per copy: a helper that wakes late works on the counters of the
+    // job it woke for, never on those of the next one)
+    auto job = std::make_shared<Job>();
+    job->dst[0] = (char*)dst;
+    job->src[0] = (const char*)src;
+    job->bytes[0] = bytes;
+    job->dst[1] = (char*)dst2;
+    job->src[1] = (const char*)src2;
+    job->bytes[1] = bytes2;
+    job->pieces0 = (bytes + kPiece - 1) / kPiece;
+    job->pieces = job->pieces0 + (bytes2 + kPiece - 1) / kPiece;
+    job->left.store(job->pieces, std::memory_order_relaxed);
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      job_ = job;
+      generation_.fetch_add(1, std::memory_order_release);
+    }
+    if (sleepers_.load(std::memory_order_acquire) != 0) cv_.notify_all();
+    work(*job);
+    // (the pieces other threads took: they are microseconds from done)
+    while (job->left.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    busy_.unlock();
+  }
+  ~CopyPool() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_.store(true, std::memory_order_release);
+    }
+    cv_.notify_all();
+    for (std::thread& t : threads_) t.join();
+  }
+
+ private:
+  static constexpr size_t kPiece = (size_t)128 << 10, kMinParallel = (size_t)1 << 20;
+  struct Job {
+    char* dst[2] = {nullptr, nullptr};
+    const char* src[2] = {nullptr, nullptr};
+    size_t bytes[2] = {0, 0}, pieces0 = 0, pieces = 0;
+    std::atomic<size_t> next{0}, left{0};
+  };
+  void grow(u32 helpers) {  // (under busy_)
+    while (threads_.size() < helpers && threads_.size() < 63) threads_.emplace_back([this] { helper(); });
+  }
+  static void work(Job& j) {
+    for (;;) {
+      size_t i = j.next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= j.pieces) return;
+      const int w = i >= j.pieces0 ? 1 : 0;
+      if (w) i -= j.pieces0;
+      const size_t off = i * kPiece, nb = j.bytes[w] - off < kPiece ? j.bytes[w] - off : kPiece;
+      memcpy(j.dst[w] + off, j.src[w] + off, nb);
+      j.left.fetch_sub(1, std::memory_order_release);
+    }
+  }
+  // A helper that has just worked polls for the next job for a short while before it goes to
+  // sleep: the copies of one call follow each other within tens of microseconds, and a wake-up
+  // through the condition variable costs about as much as copying a piece.
+  void helper() {
+    uint64_t seen = 0;
+    for (;;) {
+      bool have = false;
+      for (int spin = 0; spin < kSpins; ++spin) {
+        if (generation_.load(std::memory_order_acquire) != seen || stop_.load(std::memory_order_acquire)) {
+          have = true;
+          break;
+        }
+        __builtin_ia32_pause();
+      }
+      std::shared_ptr<Job> job;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        if (!have) {
+          sleepers_.fetch_add(1, std::memory_order_release);
+          cv_.wait(lk, [&] { return stop_.load() || generation_.load() != seen; });
+          sleepers_.fetch_sub(1, std::memory_order_release);
+        }
+        if (stop_.load()) return;
+        seen = generation_.load();
+        job = job_;
+      }
+      if (job) work(*job);
+    }
+  }
+  static constexpr int kSpins = 20000;  // ~100-200 us of polling
+  std::mutex busy_, m_;
+  std::condition_variable cv_;
+  std::vector<std::thread> threads_;
+  std::shared_ptr<Job> job_;
+  std::atomic<uint64_t> generation_{0};
+  std::atomic<int> sleepers_{0};
+  std::atomic<bool> stop_{false};
+};
+inline void host_copy(void* dst, const void* src, size_t bytes) { CopyPool::get().copy(dst, src, bytes); }
+// Piece size of a staged copy of `bytes` through slots of `slot_bytes`: one piece below 2 MiB (a
+// piece costs a hipMemcpyAsync and an event, ~15 us), two pieces up to two slots' worth (the host
+// copy of the second overlaps the DMA of the first: 4 MiB in 235 instead of 314 us), whole slots above.
+inline size_t staged_piece(size_t bytes, size_t slot_bytes) {
+  if (bytes < ((size_t)2 << 20)) return bytes < slot_bytes ? bytes : slot_bytes;
+  const size_t half = ((bytes + 1) / 2 + 0xfff) & ~(size_t)0xfff;
+  return half < slot_bytes ? half : slot_bytes;
+}
+
 // dst (device) <- src (ordinary host memory), enqueued on st.  Returns when the last chunk has
-// been copied out of src (the DMA of the last two chunks may still be running).
+// been copied out of src (the DMA of the last chunks may still be running).
 int staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t st) {
   Staging& s = g_staging;
-  if (int rc = s.ensure_slots()) return rc;
+  if (int rc = s.ensure_slots(bytes)) return rc;
+  const size_t piece = staged_piece(bytes, s.slot_bytes);
   int k = 0;
   for (size_t off = 0; off < bytes; ++k) {
-    const int b = k & 1;
-    const size_t nb = bytes - off < Staging::kSlotBytes ? bytes - off : Staging::kSlotBytes;
+    const int b = k % Staging::kSlots;
+    const size_t nb = bytes - off < piece ? bytes - off : piece;
+    if (int rc = s.slot_ready(b)) return rc;
     if (int rc = s.slot_free(b)) return rc;  // the host is about to write the slot
-    memcpy(s.slot[b], (const char*)src + off, nb);
+    host_copy(s.slot[b], (const char*)src + off, nb);
     HX_HIP(hipMemcpyAsync((char*)dst + off, s.slot[b], nb, hipMemcpyHostToDevice, st));
     off += nb;
     if (int rc = s.slot_used(b, st, off == bytes)) return rc;
@@ -253,20 +422,23 @@ int staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t st) {
 // Synchronous: the data is in dst on return.
 int staged_d2h(void* dst, const void* src, size_t bytes, hipStream_t st) {
   Staging& s = g_staging;
-  if (int rc = s.ensure_slots()) return rc;
-  size_t pend_off[2] = {0, 0}, pend_nb[2] = {0, 0};
+  if (int rc = s.ensure_slots(bytes)) return rc;
+  constexpr int kS = Staging::kSlots;
+  size_t pend_off[kS] = {}, pend_nb[kS] = {};
   auto drain = [&](int b) -> int {
     if (pend_nb[b]) {
       if (int rc = s.slot_free(b)) return rc;
-      memcpy((char*)dst + pend_off[b], s.slot[b], pend_nb[b]);
+      host_copy((char*)dst + pend_off[b], s.slot[b], pend_nb[b]);
       pend_nb[b] = 0;
     }
     return HEXL_AMD_OK;
   };
+  const size_t piece = staged_piece(bytes, s.slot_bytes);
   int k = 0;
   for (size_t off = 0; off < bytes; ++k) {
-    const int b = k & 1;
-    const size_t nb = bytes - off < Staging::kSlotBytes ? bytes - off : Staging::kSlotBytes;
+    const int b = k % kS;
+    const size_t nb = bytes - off < piece ? bytes - off : piece;
+    if (int rc = s.slot_ready(b)) return rc;
     if (int rc = drain(b)) return rc;
     // the DEVICE is about to write the slot: a DMA still reading it on this very stream (an
     // earlier staged_h2d of the same call) is ordered before it by the stream itself
@@ -278,8 +450,9 @@ int staged_d2h(void* dst, const void* src, size_t bytes, hipStream_t st) {
     off += nb;
     if (int rc = s.slot_used(b, st, off == bytes)) return rc;
   }
-  if (int rc = drain(k & 1)) return rc;  // the older chunk first
-  return drain((k + 1) & 1);
+  for (int i = 0; i < kS; ++i)  // the oldest chunk first
+    if (int rc = drain((k + i) % kS)) return rc;
+  return HEXL_AMD_OK;
 }
 
 // One side of a host-pointer call: `host` is caller memory whose first byte is of `kind`
@@ -404,11 +577,18 @@ int hexl_amd_host_unregister(void* p) {
   // Nothing may still be reading or writing the range when its device mapping goes away: the
   // *_host entry points return only after their own work is done, but the caller may have handed
   // the mapped alias to kernels or copies of its own on any stream of any device.
-  int ndev = 0, cur = -1;
-  if (hipGetDeviceCount(&ndev) == hipSuccess && hipGetDevice(&cur) == hipSuccess) {
-    for (int d = 0; d < ndev; ++d)
-      if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
-    (void)hipSetDevice(cur);
+  // Only the devices this process has used through the library, plus the current one, are waited
+  // for (a caller that handed the alias to a device it drives entirely by itself synchronises that
+  // device itself): touching every visible device would create a context on each.
+  int cur = -1;
+  if (hipGetDevice(&cur) == hipSuccess) {
+    note_device(cur);
+    const uint64_t used = g_devices_used.load(std::memory_order_relaxed);
+    for (int d = 0; d < 64; ++d) {
+      if (!((used >> d) & 1)) continue;
+      if (d == cur || hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
+    }
+    if (hipSetDevice(cur) != hipSuccess) return fail(HEXL_AMD_ERR_HIP, "restoring the current device failed");
   }
   HX_HIP(hipHostUnregister(p));
   return HEXL_AMD_OK;
@@ -1017,6 +1197,10 @@ static bool set_host_tuning(const char* key, uint64_t value) {
     g_ks_fuse = (u32)value;
     return true;
   }
+  if (strcmp(key, "host_copy_threads") == 0 && value >= 1 && value <= 64) {
+    g_host_copy_threads = (u32)value;
+    return true;
+  }
   if (strcmp(key, "host_direct_copy") == 0 && value <= 1) {
     g_host_direct_copy = (u32)value;
     return true;
@@ -1085,6 +1269,59 @@ static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t*
   if (int rc = g_staging.ensure(p->device, bytes)) return rc;
   u64* d = (u64*)g_staging.buf;
   hipStream_t st = g_staging.stream;
+  if (op_range.first == 0 && res_range.first == 0 && batch > 1 && bytes >= 2 * Staging::kBigSlot &&
+      g_host_direct_copy.load() == 0) {
+    // Ordinary host memory on both sides, several polynomials, 8 MiB or more: a pipeline over
+    // chunks of about 4 MiB of whole polynomials (round 6) --
+    //   host copy in (k) + out (k - 2)  |  H2D, kernels of chunk k on one stream  |  D2H on another
+    // so that the link carries both directions at once and the host copies hide behind it.
+    // Slots 0, 1 carry the chunks in, slots 2, 3 the chunks out.
+    Staging& s = g_staging;
+    if (int rc = s.ensure_slots(bytes)) return rc;
+    if (!s.stream_out) HX_HIP(hipStreamCreateWithFlags(&s.stream_out, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b)
+      if (!s.chunk_ev[b]) HX_HIP(hipEventCreateWithFlags(&s.chunk_ev[b], hipEventDisableTiming));
+    for (int b = 0; b < Staging::kSlots; ++b)
+      if (int rc = s.slot_ready(b)) return rc;
+    const u64 chunk_polys = s.slot_bytes / poly_bytes ? s.slot_bytes / poly_bytes : 0;
+    if (chunk_polys >= 1) {
+      const u64 nchunks = (batch + chunk_polys - 1) / chunk_polys;
+      auto first = [&](u64 k) { return k * chunk_polys; };
+      auto count = [&](u64 k) { return first(k) + chunk_polys <= batch ? chunk_polys : batch - first(k); };
+      for (u64 k = 0; k < nchunks + 2; ++k) {
+        // host side of this step, as ONE job of the copy pool: chunk k into its slot, chunk k - 2
+        // out of the slot that chunk k's D2H is about to take (its own D2H was enqueued two steps
+        // ago: waiting for it does not stall the step)
+        const bool in = k < nchunks, out = k >= 2;
+        const int b = (int)(k & 1), ob = 2 + b;
+        const size_t off = in ? (size_t)first(k) * p->n : 0, nb = in ? (size_t)count(k) * poly_bytes : 0;
+        const u64 j = out ? k - 2 : 0;
+        const size_t joff = out ? (size_t)first(j) * p->n : 0, jnb = out ? (size_t)count(j) * poly_bytes : 0;
+        if (in)
+          if (int rc = s.slot_free(b)) return rc;  // (the H2D of chunk k - 2 is done)
+        if (out)
+          if (int rc = s.slot_free(ob)) return rc;  // (the D2H of chunk k - 2 is done)
+        if (in && out)
+          CopyPool::get().copy(s.slot[b], operand + off, nb, result + joff, s.slot[ob], jnb);
+        else if (in)
+          host_copy(s.slot[b], operand + off, nb);
+        else
+          host_copy(result + joff, s.slot[ob], jnb);
+        if (in) {
+          HX_HIP(hipMemcpyAsync(d + off, s.slot[b], nb, hipMemcpyHostToDevice, st));
+          if (int rc = s.slot_used(b, st, false)) return rc;
+          hipError_t e = run(d + off, count(k), st);
+          if (e != hipSuccess) return hip_fail(e, "NTT launch");
+          HX_HIP(hipEventRecord(s.chunk_ev[b], st));
+          HX_HIP(hipStreamWaitEvent(s.stream_out, s.chunk_ev[b], 0));
+          HX_HIP(hipMemcpyAsync(s.slot[ob], d + off, nb, hipMemcpyDeviceToHost, s.stream_out));
+          if (int rc = s.slot_used(ob, s.stream_out, false)) return rc;
+        }
+      }
+      HX_HIP(hipStreamSynchronize(st));
+      return HEXL_AMD_OK;
+    }
+  }
   // (a mixed argument set -- device operand, host result -- lands here too: each side by its kind)
   if (int rc = copy_to_device(d, operand, bytes, op_range.first, st)) return rc;
   hipError_t e = run(d, batch, st);
@@ -1500,7 +1737,7 @@ static int key_switch_device(u64* result, const u64* t_target_iter, u64 T, u64 n
   u64* tbuf = prod + R * T * C * n;
   const KsDims dims{n, (u32)D, (u32)T, (u32)C, (u32)K};
   // the launch sequence (no allocation, no synchronisation: capturable)
-  auto enqueue = [&]() -> int {
+  auto enqueue = [&](hipStream_t s) -> int {
     hipError_t e;
 
     // key-switch-internal.cpp:38-56: coefficient form of the targets per decomposition modulus
@@ -1509,7 +1746,7 @@ static int key_switch_device(u64* result, const u64* t_target_iter, u64 T, u64 n
       map.inner = 1;
       map.period = (u32)D;
       for (u64 j = 0; j < D; ++j) map.plan_tab[j] = (uint8_t)j;
-      if (int rc = ntt_mapped(false, plan, map, T * D, t_target, t_target_iter, n, 1, st)) return rc;
+      if (int rc = ntt_mapped(false, plan, map, T * D, t_target, t_target_iter, n, 1, s)) return rc;
     }
 
     // :61-131 per RNS index i: operands to the key modulus, lazy forward NTT, MAC, reduce
@@ -1549,17 +1786,17 @@ static int key_switch_device(u64* result, const u64* t_target_iter, u64 T, u64 n
       std::vector<const NttTables*> tabs(plan.size());
       for (size_t k = 0; k < plan.size(); ++k) tabs[k] = &plan[k]->t;
       e = ntt_multi_launch(true, tabs.data(), (u32)tabs.size(), map, T * D * D, ntt_buf, t_target,
-                           4, st);
+                           4, s);
       if (e == hipErrorNotSupported) {
-        e = ks_gather_launch(ntt_buf, t_target, dims, g, st);
+        e = ks_gather_launch(ntt_buf, t_target, dims, g, s);
         if (e != hipSuccess) return hip_fail(e, "KeySwitch gather");
         map.src_stride = 0;
-        if (int rc = ntt_mapped(true, plan, map, T * D * D, ntt_buf, ntt_buf, n, 4, st)) return rc;
+        if (int rc = ntt_mapped(true, plan, map, T * D * D, ntt_buf, ntt_buf, n, 4, s)) return rc;
       } else if (e != hipSuccess) {
         return hip_fail(e, "KeySwitch multi-plan NTT");
       }
     }
-    e = ks_mac_launch(prod, t_target_iter, ntt_buf, dims, m, st);
+    e = ks_mac_launch(prod, t_target_iter, ntt_buf, dims, m, s);
     if (e != hipSuccess) return hip_fail(e, "KeySwitch multiply-accumulate");
 
     // :134-197 modulus switching from the special prime, all (target, key component) at once
@@ -1582,7 +1819,7 @@ static int key_switch_device(u64* result, const u64* t_target_iter, u64 T, u64 n
       fin.mod[i] = KsFinishMod{qi, s, (u64)((((unsigned __int128)s) << 64) / qi)};
     }
     u64* t_last = prod + D * T * C * n;  // prod[D][.][.]: T C contiguous polynomials
-    e = ntt_inverse_launch(plan[D]->t, t_last, t_last, T * C, 2, st);
+    e = ntt_inverse_launch(plan[D]->t, t_last, t_last, T * C, 2, s);
     if (e != hipSuccess) return hip_fail(e, "KeySwitch inverse NTT (last)");
     if (g_ks_fuse.load() != 0) {
       // Round 6: rounding and finish ride on the forward transform of the corrections -- its first
@@ -1610,20 +1847,20 @@ static int key_switch_device(u64* result, const u64* t_target_iter, u64 T, u64 n
       }
       std::vector<const NttTables*> tabs(plan.size());
       for (size_t k = 0; k < plan.size(); ++k) tabs[k] = &plan[k]->t;
-      e = ntt_multi_launch(true, tabs.data(), (u32)tabs.size(), map, T * C * D, tbuf, t_last, 4, st, &ep);
+      e = ntt_multi_launch(true, tabs.data(), (u32)tabs.size(), map, T * C * D, tbuf, t_last, 4, s, &ep);
       if (e == hipSuccess) return HEXL_AMD_OK;
       if (e != hipErrorNotSupported) return hip_fail(e, "KeySwitch fused tail");
     }
-    e = ks_round_launch(tbuf, prod, dims, rd, st);
+    e = ks_round_launch(tbuf, prod, dims, rd, s);
     if (e != hipSuccess) return hip_fail(e, "KeySwitch rounding");
     {
       MultiMap map{};
       map.inner = 1;
       map.period = (u32)D;
       for (u64 i = 0; i < D; ++i) map.plan_tab[i] = (uint8_t)i;
-      if (int rc = ntt_mapped(true, plan, map, T * C * D, tbuf, tbuf, n, 4, st)) return rc;
+      if (int rc = ntt_mapped(true, plan, map, T * C * D, tbuf, tbuf, n, 4, s)) return rc;
     }
-    e = ks_finish_launch(result, prod, tbuf, dims, fin, st);
+    e = ks_finish_launch(result, prod, tbuf, dims, fin, s);
     if (e != hipSuccess) return hip_fail(e, "KeySwitch finish");
     return HEXL_AMD_OK;
   };
@@ -1644,7 +1881,7 @@ static int key_switch_device(u64* result, const u64* t_target_iter, u64 T, u64 n
   }
   if (!replayable) {
     g_ks_eager.fetch_add(1, std::memory_order_relaxed);
-    return enqueue();
+    return enqueue(st);
   }
   std::vector<uint64_t> key;
   key.reserve(11 + K + 2 * D);
@@ -1663,16 +1900,26 @@ static int key_switch_device(u64* result, const u64* t_target_iter, u64 T, u64 n
       }
       (void)hipGetLastError();
       poison_sequence_graph(st, key);
-      return enqueue();
+      return enqueue(st);
     case kGraphCapture: {
-      if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      // The sequence is captured on a stream of the library's own, never on the caller's: a capture
+      // applies to the whole stream, and work another thread of the caller enqueued on `st` during
+      // the capture window (a transform, a copy, a kernel of its own) would be recorded into the
+      // graph -- not run now, run again on every replay -- while a synchronisation on `st` would
+      // fail (round-5 advice).  The scratch and every pointer are those of `st`; the graph is
+      // launched on `st`.
+      hipStream_t cap = nullptr;
+      if (hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) != hipSuccess ||
+          hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
+        if (cap) (void)hipStreamDestroy(cap);
         poison_sequence_graph(st, key);
-        return enqueue();
+        return enqueue(st);
       }
-      const int rc = enqueue();
+      const int rc = enqueue(cap);
       hipGraph_t graph = nullptr;
-      hipError_t ec = hipStreamEndCapture(st, &graph);
+      hipError_t ec = hipStreamEndCapture(cap, &graph);
+      (void)hipStreamDestroy(cap);
       if (rc == HEXL_AMD_OK && ec == hipSuccess && graph)
         ec = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
       else if (ec == hipSuccess)
@@ -1683,7 +1930,7 @@ static int key_switch_device(u64* result, const u64* t_target_iter, u64 T, u64 n
         (void)hipGetLastError();
         if (exec) (void)hipGraphExecDestroy(exec);
         poison_sequence_graph(st, key);
-        return enqueue();
+        return enqueue(st);
       }
       store_sequence_graph(st, key, exec);
       g_ks_graph_captures.fetch_add(1, std::memory_order_relaxed);
@@ -1691,7 +1938,7 @@ static int key_switch_device(u64* result, const u64* t_target_iter, u64 T, u64 n
     }
     default:
       g_ks_eager.fetch_add(1, std::memory_order_relaxed);
-      return enqueue();
+      return enqueue(st);
   }
 }
 

@@ -66,8 +66,11 @@ int hexl_amd_pointer_is_device(const void* p);
  *   hexl_amd_host_alloc / _free        such memory from the runtime (hipHostMalloc, mapped)
  *   hexl_amd_host_register / _unregister  an existing allocation made such (hipHostRegister,
  *                                      mapped): one call over a caller's memory pool.  _unregister
- *                                      waits for every device first (nothing may still be using the
- *                                      mapping).  REGISTER MAPPINGS YOU OWN -- a page-aligned pool
+ *                                      first waits for every device this process has used through
+ *                                      the library, and the current one (nothing may still be using
+ *                                      the mapping; devices the caller drives entirely by itself are
+ *                                      the caller's to synchronise -- the call creates no context on
+ *                                      a device the process never touched).  REGISTER MAPPINGS YOU OWN -- a page-aligned pool
  *                                      from mmap / an aligned allocator that you keep, or unmap
  *                                      after unregistering -- NOT sub-allocations of the malloc heap:
  *                                      on the HIP runtime torch 2.10 bundles (ROCm 7.0.2) a process
@@ -493,12 +496,18 @@ int hexl_amd_profile_get(int i, const char** name, float* ms);
  *                      pinned, device-mapped bounce buffer instead of staged copies (default 256;
  *                      0 = never)
  *   "host_direct_copy" 0 (default) = the *_host entry points and hexl_amd_copy move ordinary (pageable)
- *                      caller memory through the calling thread's two pinned 1 MiB slots, a host
- *                      memcpy per slot overlapped with the DMA of the other (the runtime is never
- *                      handed pageable caller memory: from about 1 MiB it pins the caller's pages
- *                      for the copy, the path the GPU memory access faults of rounds 4 and 5 sat
- *                      in, EXPERIMENTS.md section 10); 1 = such buffers go to hipMemcpyAsync whole
- *                      (the link's rate instead of a memcpy's from 1 MiB on)
+ *                      caller memory through the calling thread's pinned slots (four, 1 MiB each
+ *                      until a copy of 4 MiB or more is seen, 4 MiB from then on), host copies
+ *                      overlapped with the DMA of the other slots (the runtime is never handed
+ *                      pageable caller memory: from about 1 MiB it pins the caller's pages for the
+ *                      copy, the path the GPU memory access faults of rounds 4 and 5 sat in,
+ *                      EXPERIMENTS.md section 10); *_host transforms of several polynomials and
+ *                      8 MiB or more run as a chunk pipeline (copy in | kernels | copy out, both
+ *                      directions of the link at once); 1 = such buffers go to hipMemcpyAsync whole
+ *   "host_copy_threads" threads that share a host-side copy of 1 MiB or more between caller memory
+ *                      and a pinned slot, the calling thread included (default 6; 1 = the calling
+ *                      thread alone: one memcpy moves 12-25 GB/s, the link 54 GB/s each way).  The
+ *                      helpers are created at the first such copy and sleep otherwise
  *   "ks_graph"         1 (default) = hexl_amd_key_switch / _host / _batch calls of at most four
  *                      targets whose buffers, keys and moduli were seen before on the same stream
  *                      are replayed from a HIP graph captured at their second sight (one graph

@@ -517,10 +517,51 @@ def test_host_pointer_paths_on_ordinary_memory(hx, ho, n, batch, bits):
     assert np.array_equal(a, ho.eltwise_fma_mod(x.reshape(-1), 7, None, q, 1))
 
 
+@pytest.mark.parametrize("threads", [1, 6])
+def test_host_transform_chunk_pipeline(hx, ho, threads):
+    """Round 6: a *_host transform of several polynomials and 8 MiB or more of ordinary host memory
+    runs as a chunk pipeline (host copy in | H2D + kernels | D2H | host copy out, chunks of whole
+    polynomials through four pinned 4 MiB slots, host copies shared by the copy pool): ragged last
+    chunk, a polynomial larger than half a slot, in place and out of place, one thread and the
+    pool, against the oracle on the first / a middle / the last polynomial and bit for bit against
+    the device path; then a small call again (the slots stay big)."""
+    import ctypes as C
+    import torch
+    lib = hx.lib
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    hx.set_tuning("host_copy_threads", threads)
+    try:
+        for n, batch in ((65536, 21), (16384, 70), (131072 * 4, 5)):  # 10.5 MiB, 8.75 MiB, 20 MiB (one poly = a slot)
+            q = ho.generate_primes(1, 54, True, n)[0]
+            ntt = hx.NTT(n, q)
+            x = np.random.default_rng(n + batch).integers(0, q, (batch, n), dtype=np.uint64)
+            d = hx.from_numpy(x)
+            ntt.ComputeForward(d, d, 1, 1)
+            want = hx.to_numpy(d)
+            rows = sorted({0, batch // 2, batch - 1})
+            assert np.array_equal(want[rows], ho.NTT(n, q).forward(x[rows], 1, 1))
+            src, dst = x.copy(), np.zeros_like(x)
+            assert lib.hexl_amd_ntt_forward_host(ntt._h, p(dst), p(src), batch, 1, 1) == 0
+            assert np.array_equal(dst, want) and np.array_equal(src, x)
+            assert lib.hexl_amd_ntt_inverse_host(ntt._h, p(dst), p(dst), batch, 1, 1) == 0  # in place
+            assert np.array_equal(dst, x)
+            del d
+            torch.cuda.empty_cache()
+        n = 4096
+        q = ho.generate_primes(1, 49, True, n)[0]
+        ntt = hx.NTT(n, q)
+        x = ho.fill_splitmix(n, 5, q)
+        y = x.copy()
+        assert lib.hexl_amd_ntt_forward_host(ntt._h, p(y), p(y), 1, 1, 1) == 0
+        assert np.array_equal(y, ho.NTT(n, q).forward(x, 1, 1))
+    finally:
+        hx.set_tuning("host_copy_threads", 6)
+
+
 @pytest.mark.parametrize("direct", [0, 1])
 def test_host_pointer_paths_above_one_mebibyte(hx, ho, direct):
     """Host-pointer calls whose buffers exceed one pinned slot (1 MiB): by default the library
-    copies ordinary caller memory through its own two pinned slots, chunk by chunk, in both
+    copies ordinary caller memory through its own pinned slots, chunk by chunk, in both
     directions ("host_direct_copy" 0: the HIP runtime never gets to pin the caller's pages, the
     path the suite's GPU memory access faults sat in); with the key at 1 the buffers go to
     hipMemcpyAsync whole.  Ragged sizes (not a multiple of the slot), in place and out of place,

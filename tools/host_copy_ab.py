@@ -13,7 +13,10 @@ import hexl_amd as hx  # noqa: E402
 
 print("| N x batch | bytes | pinned slots (default) us | direct us | GB/s in+out (slots / direct) |")
 print("|---|---|---|---|---|")
-for n, batch in ((65536, 1), (131072, 1), (65536, 8), (65536, 32), (65536, 128)):
+THREADS = int(os.environ.get("HOST_COPY_THREADS", "0"))
+if THREADS:
+    hx.set_tuning("host_copy_threads", THREADS)
+for n, batch in ((65536, 1), (131072, 1), (65536, 8), (65536, 16), (65536, 32), (65536, 128), (16384, 512)):
     q = hx.GeneratePrimes(1, 54, True, n)[0]
     ntt = hx.NTT(n, q)
     x = np.random.default_rng(1).integers(0, q, (batch, n), dtype=np.uint64)

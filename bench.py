@@ -613,6 +613,10 @@ def run_multi_device(devices, scaling, steps, warmup, batch=BATCH, n=N, timeout=
     cmd = [MULTI_DEVICE_BIN, "--devices", ",".join(str(d) for d in devices), "--scaling", scaling,
            "--n", str(n), "--batch", str(batch), "--primes", str(len(PRIMES)), "--bits", "54",
            "--steps", str(steps), "--warmup", str(warmup)]
+    if n == N:  # the per-worker probe: the definition digests of the primes of this job (committed data)
+        for c in json.load(open(os.path.join(ROOT, "tests", "golden", "ntt_definition_fixtures.json")))["cases"]:
+            if c["n"] == N and c["q"] in PRIMES:
+                cmd += ["--probe", f"{c['q']}:{c['forward']['sha256_le_u64']}:{c['inverse']['sha256_le_u64']}"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
     line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
     try:
@@ -639,6 +643,7 @@ def threads_main(args):
         "warmup": args.warmup, "prewarm_steps": PREWARM // 2, "ms_per_step": md["ms_per_step"],
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u64",
         "data": "synthetic", "per_rank_NTT_per_s": md["per_rank_NTT_per_s"],
+        "per_rank_probe_ok": md.get("per_rank_probe_ok"), "per_rank_plan_device": md.get("per_rank_plan_device"),
         "launcher": "threads", "rendezvous": "none", "rendezvous_note": "one process: std::thread per GPU",
         "devices": md["devices"], "visible_devices": md["visible_devices"],
         "verified": {"probe_polynomials_compared": md["probe_polynomials_compared"],
@@ -799,6 +804,36 @@ def main():
 
     segments, plans, data, check, step, my_polys, num_primes = build_job(args.scaling)
 
+    # Before anything is timed every rank proves that ITS plans on ITS device compute the right
+    # thing: for each prime of its shard the forward transform of splitmix64(seed = 1) mod q and the
+    # inverse transform of splitmix64(seed = 1001) mod q, N = 65536, are hashed and compared with the
+    # digests of tests/golden/ntt_definition_fixtures.json (committed data, pinned to the big-integer
+    # definition of the transform: no oracle in this process).  A round trip alone would also pass
+    # with another prime's tables or on another device's memory; this does not.
+    def rank_probe():
+        import hashlib
+        fx = {c["q"]: c for c in json.load(open(os.path.join(
+            ROOT, "tests", "golden", "ntt_definition_fixtures.json")))["cases"] if c["n"] == N}
+        ok, devices = True, set()
+        for (prime, _, _), plan in zip(segments, plans):
+            q = PRIMES[prime % len(PRIMES)]
+            devices.add(plan.GetDevice())
+            for which, seed in (("forward", 1), ("inverse", 1001)):
+                v = torch.empty((1, N), dtype=torch.int64, device="cuda")
+                hx.fill_splitmix(v, N, 1, seed, q)
+                (plan.ComputeForward if which == "forward" else plan.ComputeInverse)(v, v, 1, 1)
+                digest = hashlib.sha256(hx.to_numpy(v).astype("<u8").tobytes()).hexdigest()
+                ok = ok and q in fx and digest == fx[q][which]["sha256_le_u64"]
+        expect = int(os.environ.get("BENCH_PROBE_EXPECT_DEVICE", local_rank))
+        return ok and devices == {expect}, sorted(devices)
+
+    probe_ok, probe_devices = rank_probe()
+    per_rank_probe_ok = [bool(v) for v in rv.gather(1.0 if probe_ok else 0.0)]
+    per_rank_device = [int(v) for v in rv.gather(float(probe_devices[0] if probe_devices else -1))]
+    if not all(per_rank_probe_ok):
+        raise SystemExit(f"per-rank probe FAILED: ok per rank {per_rank_probe_ok}, plan device per rank "
+                         f"{per_rank_device} (rank {rank}: local rank {local_rank}, plans on {probe_devices})")
+
     # The first ~10 passes over a freshly allocated 2 GiB buffer run 8 % slower (clock ramp,
     # first-touch page mapping), whatever W is; PREWARM untimed passes precede the W warm-up
     # steps so that short runs measure the steady state too (reported as "prewarm_steps").
@@ -932,6 +967,9 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "per_rank_NTT_per_s": per_rank,
+            # every rank's pre-timing probe (the transforms of its primes on its device against
+            # the committed definition digests) and the device its plans live on (hexl_amd_ntt_device)
+            "per_rank_probe_ok": per_rank_probe_ok, "per_rank_plan_device": per_rank_device,
             # what the ranks met on for the barrier and the scalar reductions (no data-path
             # collective): "nccl" (= RCCL), "gloo" (RCCL unavailable / failed its probe: why is in
             # rendezvous_note), "none" (one process)

@@ -21,8 +21,16 @@
 // generator's input (round trip).  Timing: W warm-up steps, then K steps between two barriers;
 // the job's time is the slowest thread's.  One JSON line on stdout.
 //
+// Round 6: before the warm-up every worker also proves that ITS plans on ITS device compute the
+// right thing.  "--probe q:fwd_sha256:inv_sha256" (one per modulus; bench.py passes the digests
+// of tests/golden/ntt_definition_fixtures.json, pinned to the big-integer definition of the
+// transform) makes each worker transform splitmix64(seed 1) mod q forward and splitmix64(seed
+// 1001) mod q inverse with each of its plans, on its device, and compare the SHA-256 of the
+// results; hexl_amd_ntt_device(plan) must be the worker's device.  The line carries
+// per_rank_probe_ok and per_rank_plan_device.
+//
 //   multi_device [--devices 0,1,...|all] [--scaling strong|weak] [--n N] [--batch B]
-//                [--primes P] [--bits 54] [--steps K] [--warmup W]
+//                [--primes P] [--bits 54] [--steps K] [--warmup W] [--probe q:hex:hex ...]
 // "--devices 0,0" runs two worker threads on one GPU (the dry run of the N > 1 code on a
 // one-GPU box).
 #include <atomic>
@@ -80,7 +88,64 @@ class Barrier {  // C++17: no std::barrier
   uint64_t gen_ = 0;
 };
 
+// SHA-256 (FIPS 180-4), for the per-worker probe.
+struct Sha256 {
+  uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+  void block(const uint8_t* p) {
+    static const uint32_t k[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+        0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+        0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+        0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+        0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+        0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+        0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+        0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t w[64];
+    for (int i = 0; i < 16; ++i)
+      w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
+    for (int i = 16; i < 64; ++i) {
+      const uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
+      const uint32_t s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+      w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; ++i) {
+      const uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + k[i] + w[i];
+      const uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+  }
+  // digest of `bytes` bytes (a multiple of 64 here: whole polynomials), as lower-case hex
+  static std::string hex(const void* data, size_t bytes) {
+    Sha256 s;
+    const uint8_t* p = (const uint8_t*)data;
+    size_t off = 0;
+    for (; off + 64 <= bytes; off += 64) s.block(p + off);
+    uint8_t tail[128] = {0};
+    const size_t rem = bytes - off;
+    memcpy(tail, p + off, rem);
+    tail[rem] = 0x80;
+    const size_t tl = rem + 9 <= 64 ? 64 : 128;
+    const uint64_t bits = (uint64_t)bytes * 8;
+    for (int i = 0; i < 8; ++i) tail[tl - 1 - i] = (uint8_t)(bits >> (8 * i));
+    s.block(tail);
+    if (tl == 128) s.block(tail + 64);
+    char out[65];
+    for (int i = 0; i < 8; ++i) snprintf(out + 8 * i, 9, "%08x", s.h[i]);
+    return std::string(out, 64);
+  }
+};
+
+struct ProbeDigest {
+  uint64_t q;
+  std::string fwd, inv;
+};
+
 struct Config {
+  std::vector<ProbeDigest> probes;
   std::vector<int> devices;
   bool weak = false;
   uint64_t n = 65536, batch = 4096, primes = 8, bits = 54;
@@ -93,6 +158,8 @@ struct Worker {
   uint64_t polys = 0;
   double seconds = 0;   // its own K steps
   std::string error;    // empty: fine
+  int probe_ok = -1;    // 1 / 0: the digests of its plans' probe transforms matched / did not; -1: no probe asked
+  int plan_device = -1; // hexl_amd_ntt_device of its plans (-2: they disagree)
   // first / last polynomial after the first forward pass and after the round trip
   std::vector<uint64_t> fwd_first, fwd_last, back_first, back_last;
 };
@@ -130,6 +197,34 @@ void run_worker(Worker& w, const Config& cfg, const std::vector<uint64_t>& modul
                                   moduli[s.prime % moduli.size()], stream));
         off += s.count;
       }
+    }
+    // the probe: every plan of this worker, on this worker's device, against the definition digests
+    for (size_t i = 0; i < plans.size(); ++i) {
+      const int pd = hexl_amd_ntt_device(plans[i]);
+      w.plan_device = (i == 0 || w.plan_device == pd) ? pd : -2;
+    }
+    if (!cfg.probes.empty()) {
+      w.probe_ok = w.plan_device == w.device ? 1 : 0;
+      uint64_t* pv = nullptr;
+      CK(hexl_amd_device_alloc((void**)&pv, n * sizeof(uint64_t), w.device));
+      std::vector<uint64_t> host(n);
+      for (size_t i = 0; i < plans.size(); ++i) {
+        const uint64_t q = moduli[w.segments[i].prime % moduli.size()];
+        const ProbeDigest* want = nullptr;
+        for (const ProbeDigest& d : cfg.probes)
+          if (d.q == q) want = &d;
+        if (!want) {
+          w.probe_ok = 0;
+          continue;
+        }
+        for (int inverse = 0; inverse < 2; ++inverse) {
+          CK(hexl_amd_fill_splitmix(pv, n, 1, inverse ? 1001 : 1, q, stream));
+          CK((inverse ? hexl_amd_ntt_inverse : hexl_amd_ntt_forward)(plans[i], pv, pv, 1, 1, 1, stream));
+          CK(hexl_amd_copy(host.data(), pv, n * sizeof(uint64_t), stream, 1));
+          if (Sha256::hex(host.data(), n * sizeof(uint64_t)) != (inverse ? want->inv : want->fwd)) w.probe_ok = 0;
+        }
+      }
+      CK(hexl_amd_device_free(pv));
     }
     bool whole = w.segments.size() > 1;
     for (const Segment& s : w.segments) whole = whole && s.count == w.segments[0].count && s.first == 0;
@@ -220,7 +315,13 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--steps")) cfg.steps = atoi(val());
     else if (!strcmp(argv[i], "--warmup")) cfg.warmup = atoi(val());
     else if (!strcmp(argv[i], "--ref-device")) cfg.ref_device = atoi(val());
-    else if (!strcmp(argv[i], "--print-partition")) print_partition = true;
+    else if (!strcmp(argv[i], "--probe")) {
+      const std::string a = val();
+      const size_t c1 = a.find(':'), c2 = a.find(':', c1 == std::string::npos ? 0 : c1 + 1);
+      if (c1 == std::string::npos || c2 == std::string::npos) return 2;
+      cfg.probes.push_back({strtoull(a.substr(0, c1).c_str(), nullptr, 10), a.substr(c1 + 1, c2 - c1 - 1),
+                            a.substr(c2 + 1)});
+    } else if (!strcmp(argv[i], "--print-partition")) print_partition = true;
     else {
       fprintf(stderr, "unknown argument %s\n", argv[i]);
       return 2;
@@ -312,6 +413,14 @@ int main(int argc, char** argv) {
       error = "worker " + std::to_string(w.index) + " (device " + std::to_string(w.device) + "): " + w.error;
       break;
     }
+  if (ok)
+    for (const Worker& w : workers)
+      if (w.probe_ok == 0) {
+        ok = false;
+        error = "worker " + std::to_string(w.index) + " (device " + std::to_string(w.device) +
+                "): per-rank probe failed (plan device " + std::to_string(w.plan_device) + ")";
+        break;
+      }
   // bit-compare every shard's first and last polynomial with a single-device run
   uint64_t compared = 0, mismatches = 0;
   if (ok) {
@@ -359,6 +468,11 @@ int main(int argc, char** argv) {
            workers[g].seconds > 0 ? 2.0 * (double)workers[g].polys * cfg.steps / workers[g].seconds : 0.0);
   printf("], \"per_rank_polynomials\": [");
   for (uint64_t g = 0; g < G; ++g) printf("%s%llu", g ? ", " : "", (unsigned long long)workers[g].polys);
+  printf("], \"per_rank_probe_ok\": [");
+  for (uint64_t g = 0; g < G; ++g)
+    printf("%s%s", g ? ", " : "", workers[g].probe_ok == 1 ? "true" : workers[g].probe_ok == 0 ? "false" : "null");
+  printf("], \"per_rank_plan_device\": [");
+  for (uint64_t g = 0; g < G; ++g) printf("%s%d", g ? ", " : "", workers[g].plan_device);
   printf("], \"probe_polynomials_compared\": %llu, \"probe_mismatches\": %llu, \"ref_device\": %d}\n",
          (unsigned long long)compared, (unsigned long long)mismatches, cfg.ref_device);
   return ok ? 0 : 1;

@@ -14,7 +14,7 @@ oracle is only consulted at the end, to (a) assert that it agrees on every sampl
 and (b) record the SHA-256 of its full output vector, which the tests then use as the
 whole-vector pin for both the oracle and the HIP path.
 
-    python tests/golden/make_ntt_definition_fixtures.py        (~1 min)
+    python tests/golden/make_ntt_definition_fixtures.py        (~4 min)
 """
 import hashlib
 import json
@@ -31,6 +31,11 @@ CASES = [  # (N, q, what it pins)
     (4096, 562949954093057, "BASELINE configs[1]: N=4096, 50-bit prime"),
     (65536, 18014398510661633, "BASELINE configs[2] (headline): N=65536, 55-bit prime"),
     (131072, 1152921504616808449, "BASELINE configs[4]: N=131072, 61-bit prime"),
+] + [  # the other seven RNS primes of configs[3] (bench.py's per-rank probe: every rank checks the
+       # transform of ITS prime on ITS device against these digests before it is timed)
+    (65536, q, "BASELINE configs[3]: RNS prime %d of 8, N=65536" % (k + 2))
+    for k, q in enumerate([18014398512365569, 18014398514200577, 18014398514987009, 18014398515511297,
+                           18014398516559873, 18014398521016321, 18014398524424193])
 ]
 SAMPLES = 64
 

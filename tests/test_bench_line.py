@@ -50,6 +50,8 @@ class FakeTensor:
     def data_ptr(self):
         return 0
 
+    payload = None  # (the per-rank probe's one polynomial: real words, see fake_hexl_amd)
+
 
 def fake_torch():
     t = types.ModuleType("torch")
@@ -97,6 +99,7 @@ def fake_torch():
 def fake_hexl_amd(real, fail_composites=False):
     """The real package's host-side number theory; every compute entry point a no-op that feeds
     the launch profiler with fixed kernel times."""
+    from oracle import hexl_oracle as ho  # (tests may use the checker: the stand-in's probe transform)
     hx = types.ModuleType("hexl_amd")
     state = {"profiling": False, "records": []}
 
@@ -108,11 +111,18 @@ def fake_hexl_amd(real, fail_composites=False):
         def __init__(self, n, q, root=0, device=None):
             self.n, self.q, self._h = n, q, C.c_void_p(1)
 
+        def GetDevice(self):
+            return 0
+
         def ComputeForward(self, out, x, a, b):
+            if x.payload is not None:  # the per-rank probe: the real transform, by the oracle
+                out.payload = ho.NTT(self.n, self.q).forward(x.payload, 1, 1)
             launched(["ntt_fwd_strided_pass", "ntt_fwd_tile_pass_bottom"] if self.n > 16384
                      else ["ntt_fwd_tile_pass_bottom"])
 
         def ComputeInverse(self, out, x, a, b):
+            if x.payload is not None:
+                out.payload = ho.NTT(self.n, self.q).inverse(x.payload, 1, 1)
             launched(["ntt_inv_tile_pass_bottom", "ntt_inv_strided_pass"] if self.n > 16384
                      else ["ntt_inv_tile_pass_bottom"])
 
@@ -129,7 +139,13 @@ def fake_hexl_amd(real, fail_composites=False):
 
     hx.NTT = NTT
     hx.profile_start, hx.profile_stop = profile_start, profile_stop
-    hx.fill_splitmix = lambda *a, **k: None
+    def fill_splitmix(data, n, batch, seed0, bound):
+        # (one polynomial = the per-rank probe of bench.py: the stand-in carries its real words, so
+        # that the probe's comparison with the committed definition digests is exercised here too)
+        if batch == 1 and data.shape == (1, n):
+            data.payload = ho.fill_splitmix(n, seed0, bound)
+    hx.fill_splitmix = fill_splitmix
+    hx.to_numpy = lambda t: t.payload
     for name in ("EltwiseMultMod", "EltwiseFMAMod", "EltwiseReduceMod", "EltwiseReduceFMAMod",
                  "ComputeForwardRNS", "ComputeInverseRNS"):
         setattr(hx, name, lambda *a, **k: None)
@@ -199,6 +215,7 @@ def test_default_line_has_the_contract_and_the_round_4_blocks(monkeypatch, capfd
     assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 1
     assert line["higher_is_better"] is True and line["vs_baseline"] is None and line["dtype"] == "u64"
     assert "workload" in line["config"] and "model" not in line["config"]
+    assert line["per_rank_probe_ok"] == [True] and line["per_rank_plan_device"] == [0]  # round 6
     roof = line["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "transform_frac", "transform",
                 "achievable_GBps", "per_kernel"):

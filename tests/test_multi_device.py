@@ -83,6 +83,58 @@ def test_bench_threads_launcher_emits_the_bench_line():
         assert key in line
     assert line["launcher"] == "threads" and line["n_gpus"] == 2 and len(line["per_rank_NTT_per_s"]) == 2
     assert line["verified"]["probe_mismatches"] == 0 and line["value"] > 0
+    # round 6: every worker proved its plans on its device against the committed definition digests
+    assert line["per_rank_probe_ok"] == [True, True] and line["per_rank_plan_device"] == [0, 0]
+
+
+def _fixture_probes():
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "ntt_definition_fixtures.json")))["cases"]
+    return [(c["q"], c["forward"]["sha256_le_u64"], c["inverse"]["sha256_le_u64"]) for c in cases if c["n"] == 65536]
+
+
+@pytest.mark.gpu
+def test_worker_probe_against_the_definition_digests():
+    """Round 6: before it is timed every worker transforms splitmix64(1) / splitmix64(1001) mod q
+    with each of ITS plans on ITS device and compares the SHA-256 with the digests of
+    tests/golden/ntt_definition_fixtures.json (committed data, pinned to the big-integer definition
+    of the transform: no oracle in the process).  All 8 RNS primes of configs[3] over 4 workers
+    pass; a digest that belongs to another prime (what a worker that picked up the wrong prime's
+    tables would produce) fails the run loudly."""
+    probes = _fixture_probes()
+    assert len(probes) == 8
+    args = ["--devices", "0,0,0,0", "--scaling", "strong", "--n", 65536, "--batch", 8, "--primes", 8,
+            "--steps", 1, "--warmup", 0]
+    good = sum((["--probe", f"{q}:{f}:{i}"] for q, f, i in probes), [])
+    out = json.loads(run(*args, *good).stdout.strip().splitlines()[-1])
+    assert out["ok"] and out["per_rank_probe_ok"] == [True] * 4 and out["per_rank_plan_device"] == [0] * 4
+    # prime 3's digests filed under prime 2: worker 1 (primes 2, 3) must fail, and with it the run
+    swapped = list(probes)
+    swapped[2] = (probes[2][0], probes[3][1], probes[3][2])
+    bad = sum((["--probe", f"{q}:{f}:{i}"] for q, f, i in swapped), [])
+    r = subprocess.run([BIN] + [str(a) for a in args + bad], capture_output=True, text=True, timeout=600)
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert r.returncode != 0 and not out["ok"] and "probe" in out["error"]
+    assert out["per_rank_probe_ok"] == [True, False, True, True]
+
+
+@pytest.mark.gpu
+def test_bench_process_launcher_probe_and_wrong_device(tmp_path):
+    """The one-process-per-GPU launcher (what SCALE_rNN.json measures), two ranks on one device:
+    the line carries per_rank_probe_ok / per_rank_plan_device; told to expect its plans on ANOTHER
+    device than the one they were created on (BENCH_PROBE_EXPECT_DEVICE: a rank that ended up on the
+    wrong GPU) the run fails before anything is timed."""
+    import sys
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+            "--batch", "64", "--no-cpu-baseline", "--no-secondary"]
+    env = dict(os.environ, BENCH_ONE_DEVICE="1", BENCH_BACKEND="gloo", BENCH_SUSTAINED_S="0")
+    r = subprocess.run(base, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([x for x in r.stdout.strip().splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["per_rank_probe_ok"] == [True, True]
+    assert line["per_rank_plan_device"] == [0, 0]
+    r = subprocess.run(base, capture_output=True, text=True, timeout=900,
+                       env=dict(env, BENCH_PROBE_EXPECT_DEVICE="1"))
+    assert r.returncode != 0 and "per-rank probe FAILED" in (r.stdout + r.stderr)
 
 
 @pytest.mark.gpu

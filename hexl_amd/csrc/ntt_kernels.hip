@@ -571,7 +571,12 @@ __device__ __forceinline__ void strided_body(u64* out, const u64* in,
   if (FWD) __builtin_amdgcn_s_setprio(0);
   if constexpr (R < 5 && DATA_FIRST) load_twiddles<R, CTW>(wv, twa, node);
   if (flags & kFirstPass) {
-    if (flags & (kReduceFirst | kRoundFirst)) entry_words<E>(x, flags, m);
+    // (source maps exist in the multi-plan kernels only -- CTW -- : compiled into the single-plan
+    // kernels too, the rounding path cost the Small inverse tile pass its 64-register budget,
+    // 36 bytes of scratch and 18-34 % of its time)
+    if constexpr (CTW && FWD) {  // (... and on forward transforms only: ntt_multi_launch)
+      if (flags & (kReduceFirst | kRoundFirst)) entry_words<E>(x, flags, m);
+    }
 #pragma unroll
     for (int e = 0; e < E; ++e) x[e] = to_internal<A>(x[e], m);
   }
@@ -940,7 +945,9 @@ __device__ __forceinline__ TileGeom make_geom(u32 tile, u32 log_n) {
 // GUARD: the batch may end inside the tile (only possible for CB == 0 and a batch
 // smaller than / not a multiple of the tile); otherwise every access is in range.
 // CONVERT == false: only the loads (fetch_convert follows once the plan constants are there).
-template <bool ROUND0, int S, int CB, int TL, bool GUARD, class A, int LDK, bool CONVERT = true>
+// ENTRY: the launch may carry a source map (the multi-plan kernels): words reduced / rounded on load.
+template <bool ROUND0, int S, int CB, int TL, bool GUARD, class A, int LDK, bool CONVERT = true,
+          bool ENTRY = false>
 __device__ __forceinline__ void fetch_tile(u64* x, const u64* in, u32 tid, const TileGeom& g,
                                            u64 total, u32 flags, const ModConst& m) {
   constexpr int kRE = re_of(S), kE = el_of(S);
@@ -961,16 +968,20 @@ __device__ __forceinline__ void fetch_tile(u64* x, const u64* in, u32 tid, const
   }
   if constexpr (!CONVERT) return;
   if (flags & kFirstPass) {
-    if (flags & (kReduceFirst | kRoundFirst)) entry_words<kE>(x, flags, m);
+    if constexpr (ENTRY) {
+      if (flags & (kReduceFirst | kRoundFirst)) entry_words<kE>(x, flags, m);
+    }
 #pragma unroll
     for (int i = 0; i < kE; ++i) x[i] = to_internal<A>(x[i], m);
   }
 }
-template <int S, class A>
+template <int S, class A, bool ENTRY = false>
 __device__ __forceinline__ void fetch_convert(u64* x, u32 flags, const ModConst& m) {
   constexpr int kE = el_of(S);
   if (flags & kFirstPass) {
-    if (flags & (kReduceFirst | kRoundFirst)) entry_words<kE>(x, flags, m);
+    if constexpr (ENTRY) {
+      if (flags & (kReduceFirst | kRoundFirst)) entry_words<kE>(x, flags, m);
+    }
 #pragma unroll
     for (int i = 0; i < kE; ++i) x[i] = to_internal<A>(x[i], m);
   }
@@ -1097,10 +1108,10 @@ __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
       if constexpr (DATA_FIRST) {  // see strided_body
         fetch_tile<true, S, CB, TL, GUARD, A, LDK, false>(x, in, tid, g, total, flags, m);
         round_twiddles<S, CB, TL, 0, CTW>(wv, tw, tid, g);
-        fetch_convert<S, A>(x, flags, m);
+        fetch_convert<S, A, (CTW && FWD)>(x, flags, m);
       } else {
         round_twiddles<S, CB, TL, 0, CTW>(wv, tw, tid, g);
-        fetch_tile<true, S, CB, TL, GUARD, A, LDK>(x, in, tid, g, total, flags, m);  // round-0 set
+        fetch_tile<true, S, CB, TL, GUARD, A, LDK, true, (CTW && FWD)>(x, in, tid, g, total, flags, m);  // round-0 set
       }
       __builtin_amdgcn_s_setprio(0);
       if constexpr (RD::pre_fwd(1)) round_twiddles<S, CB, TL, 1, CTW>(wn, tw, tid, g);
@@ -1135,10 +1146,10 @@ __device__ __forceinline__ void tile_body(u64* lds, u64* out, const u64* in,
     if constexpr (DATA_FIRST) {
       fetch_tile<false, S, CB, TL, GUARD, A, LDK, false>(x, in, tid, g, total, flags, m);
       if constexpr (NR > 1) round_twiddles<S, CB, TL, NR - 1, CTW>(wtop, tw, tid, g);
-      fetch_convert<S, A>(x, flags, m);
+      fetch_convert<S, A, (CTW && FWD)>(x, flags, m);
     } else {
       if constexpr (NR > 1) round_twiddles<S, CB, TL, NR - 1, CTW>(wtop, tw, tid, g);
-      fetch_tile<false, S, CB, TL, GUARD, A, LDK>(x, in, tid, g, total, flags, m);
+      fetch_tile<false, S, CB, TL, GUARD, A, LDK, true, (CTW && FWD)>(x, in, tid, g, total, flags, m);
     }
     __builtin_amdgcn_s_setprio(0);
     HX_PROFILE_WAIT_VMEM();
@@ -1488,11 +1499,16 @@ int set_tuning(const char* key, u64 value) {
 // (Small -16 %, Fp64 / Fp64L -9 %, Lazy -10 %, Harvey60 -6 %); the forward only with the Fp64
 // family (-5 ... -7 %), is flat under Lazy and loses 9 % under Small.  "walk14": 0 = never,
 // 1 = this table, 2 = always (A/B).
-template <bool FWD, class A>
+// MULTI (several moduli in one launch): the inverse walk of the Lazy family carries the plan's
+// constants through the loop beside everything else, spills 52-64 bytes and measured 3 % slower than
+// one workgroup per polynomial (8 moduli x 512 polynomials, tools/rns_ab.py; Harvey60 -7 %, Fp64L
+// -10 % with it): not used there.
+template <bool FWD, class A, bool MULTI = false>
 static bool walk14_wanted() {
   const u32 w = tuning().walk14.load();
   if (w == 0) return false;
   if (w == 2) return true;
+  if (MULTI && !FWD && A::kLazy) return false;
   return !FWD || A::kFp;
 }
 
@@ -1594,8 +1610,7 @@ static hipError_t launch_bottom(int S, u64* out, const u64* in, const ulonglong2
         }
       } else {  // N = 16384 as one kernel (128 KiB tile)
         if constexpr (TL == 14) {
-          if (log_n == 14 && walk14_wanted<FWD, A>() && grid > cu_count() &&
-              (FWD || mc->map.src_stride == 0)) {  // persistent: see tile_walk
+          if (log_n == 14 && walk14_wanted<FWD, A, true>() && grid > cu_count()) {  // persistent: see tile_walk
             const unsigned pg = cu_count();
             if (last)
               hipLaunchKernelGGL((tile_walk_pass_multi<FWD, 14, A, !FWD>), dim3(pg), dim3(1024), 0, st, out,
@@ -1947,7 +1962,8 @@ hipError_t ntt_multi_launch(bool forward, const NttTables* const* tabs, u32 num_
                             u64 out_mf, hipStream_t st, const KsEpilogue* epi) {
   if (num_plans == 0 || polys == 0) return hipSuccess;
   if (num_plans > (u32)kMaxMultiPlans || polys >= (1ull << 31) || map.inner == 0 ||
-      map.period == 0 || map.period > (u32)kMaxMultiPeriod || (map.src_stride && map.inner != 1))
+      map.period == 0 || map.period > (u32)kMaxMultiPeriod || (map.src_stride && map.inner != 1) ||
+      (map.src_stride && !forward))  // (source maps: forward transforms only)
     return hipErrorNotSupported;
   const NttTables& t0 = *tabs[0];
   if (t0.log_n < 12 || t0.log_n > 17) return hipErrorNotSupported;  // one strided + one bottom pass

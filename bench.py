@@ -56,8 +56,12 @@ HBM_ACHIEVABLE_GBPS = 6290.0  # same guide: 6.29 TB/s measured with a float4 cop
 # per wave, shader clock): collected with rocprofv3 --pmc by tools/collect_profiles.sh, written
 # by tools/summarize_profiles.py together with a hash of the kernel sources they were measured
 # on.  They are NOT collected in this run; a profile of other sources is not reported.
-COUNTER_PROFILE = "r5_counters.json"
+COUNTER_PROFILE = "r6_counters.json"
+# ... and of every kernel outside the headline configuration (tools/collect_pmc_cells.sh,
+# tools/summarize_pmc_cells.py): the one-kernel plans, BASELINE configs[1] / configs[4], the composites
+CELL_PROFILE = "r6_pmc_cells.json"
 KERNEL_SOURCES = ("ntt_kernels.hip", "modarith.h", "lazy_inverse.h", "tile_geometry.h", "internal.h")
+CELL_SOURCES = KERNEL_SOURCES + ("eltwise_kernels.hip", "keyswitch_kernels.hip")
 # what keeps each kernel family below the HBM roofline (profiles/r5_pmc_summary.md)
 KERNEL_LIMITER = {"ntt_fwd_strided_pass": "hbm", "ntt_inv_strided_pass": "hbm",
                   "ntt_fwd_tile_pass_bottom": "valu-issue + latency",
@@ -172,13 +176,42 @@ def cpu_per_call_baseline(hx):
     return out
 
 
-def kernel_source_hash():
+def kernel_source_hash(sources=None):
     """sha256 over the sources the NTT kernels are compiled from (ties a counter profile to a build)"""
     import hashlib
     h = hashlib.sha256()
-    for name in KERNEL_SOURCES:
+    for name in sources or KERNEL_SOURCES:
         h.update(open(os.path.join(ROOT, "hexl_amd", "csrc", name), "rb").read())
     return h.hexdigest()[:16]
+
+
+def cell_source_hash():
+    return kernel_source_hash(CELL_SOURCES)
+
+
+def cell_counters():
+    """(lookup, note): lookup(cell substring, kernel substring) -> the counter row of that kernel in
+    profiles/CELL_PROFILE -- traced duration, fraction of the 8 TB/s peak on algorithmic bytes, HBM
+    traffic / algorithmic bytes, VALU busy, waves per SIMD, LDS bank-conflict share -- if the profile
+    was collected on the kernel sources of this checkout; otherwise every lookup is None."""
+    path = os.path.join(ROOT, "profiles", CELL_PROFILE)
+    try:
+        prof = json.load(open(path))
+    except (OSError, ValueError):
+        return (lambda *a: None), "no cell profile committed (profiles/" + CELL_PROFILE + ")"
+    if prof.get("kernel_source_sha16") != cell_source_hash():
+        return (lambda *a: None), ("profiles/" + CELL_PROFILE + " was collected on other kernel sources ("
+                                   + str(prof.get("kernel_source_sha16")) + "): not reported")
+    keep = ("kernel", "grid", "traced_us", "frac_of_peak", "traffic_ratio", "valu_busy", "waves_per_simd",
+            "wait_any_frac", "lds_conflict_share", "lds_busy", "valu_per_wave", "clock_GHz")
+
+    def lookup(cell, kernel):
+        for r in prof.get("rows", []):
+            if cell in (r.get("cell") or "") and kernel in r["kernel"]:
+                return {k: r.get(k) for k in keep}
+        return None
+    return lookup, ("committed rocprofv3 --pmc profile (tools/collect_pmc_cells.sh) on these kernel sources (sha16 "
+                    + prof["kernel_source_sha16"] + "), not collected in this run: profiles/" + CELL_PROFILE)
 
 
 def counter_profile():
@@ -358,6 +391,29 @@ def secondary_configs(hx, torch):
     out["config4_on_one_gpu"] = {
         "shape": f"N={n}, 8 primes (55-bit) x {b} polynomials, hexl_amd_ntt_forward_rns/_inverse_rns",
         "ms_per_step": sec * 1e3, "NTT_per_s": 2 * len(primes) * b / sec}
+    # the committed counter profile of these kernels (same shapes, same kernel sources)
+    look, note = cell_counters()
+    out["counters_source"] = note
+    c2 = "N=2^12 49-bit (Fp64) x 256"
+    out["config2"]["counters"] = {
+        "fwd": look(c2, "tile_pass<true, 12"), "inv": look(c2, "tile_pass<false, 12"),
+        "multmod": look("EltwiseMultMod configs[1]", "eltwise_vec2<MultOp"),
+        "at_1_GiB_batches": {"fwd": look("N=2^12 49-bit (Fp64) x 32768", "tile_pass<true, 12"),
+                             "inv": look("N=2^12 49-bit (Fp64) x 32768", "tile_pass<false, 12")}}
+    out["config5"]["counters"] = {
+        "fma": look("EltwiseFMAMod configs[4]", "FmaOp"), "reduce": look("EltwiseReduceMod configs[4]", "ReduceOp"),
+        "fused": look("fused ReduceMod+FMAMod", "ReduceFmaOp")}
+    out["one_kernel_plans_counters"] = {
+        f"N=2^{ln} {bits}-bit ({pol})": {"fwd": look(f"N=2^{ln} {bits}-bit ({pol})", "<true, "),
+                                         "inv": look(f"N=2^{ln} {bits}-bit ({pol})", "<false, ")}
+        for ln in (13, 14) for bits, pol in ((28, "Small"), (44, "Fp64L"), (49, "Fp64"), (55, "Lazy"), (60, "Harvey60"))}
+    for label, cell in (("30-bit prime (Small policy)", "N=2^16 28-bit (Small)"),
+                        ("50-bit prime (Fp64 policy)", "N=2^16 49-bit (Fp64)")):
+        if label in other:
+            other[label]["counters"] = {
+                "note": "cell profile collected on the first prime GeneratePrimes(1, b, true, N) returns: same policy",
+                "fwd_strided": look(cell, "strided_pass<true"), "fwd_tile": look(cell, "tile_pass<true, 11"),
+                "inv_tile": look(cell, "tile_pass<false, 11"), "inv_strided": look(cell, "strided_pass<false")}
     return out
 
 
@@ -569,6 +625,17 @@ def composites(hx):
         del d_tt, d_rr
     ks["one_target_frac_of_ntt_floor"] = ntt_floor / t_replay
     ks["one_target_frac_of_ntt_floor_eager"] = ntt_floor / t_eager
+    # the committed counter profile of the 256-target call's kernels (same shape, same sources)
+    look, note = cell_counters()
+    cell = "KeySwitchBatch 256 targets n=16384"
+    ks["counters_256_targets"] = {
+        "source": note,
+        "targets_inverse": look(cell, "tile_pass_multi<false, 14"),
+        "operands_forward": look(cell, "false, false>"),
+        "multiply_accumulate": look(cell, "ks_mac_kernel"),
+        "fused_tail_round_forward_finish": look("fused tail", "false, true>"),
+        "launches_per_call": "5 (one-kernel transforms): inverse of the targets, forward of the operands through a "
+                             "source map, multiply-accumulate, inverse of the last components, fused tail"}
     out["key_switch"] = ks
     torch.cuda.empty_cache()
     return out

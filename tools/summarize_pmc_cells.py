@@ -81,12 +81,27 @@ def cell_of(kernel, grid, cells):
                 if f"({pol})" in c["label"]:
                     return c["label"], 16 * elems
         return None, 16 * elems
-    m = re.match(r"tile_pass_multi<(true|false), (\d+), (\d+), ", kernel)
+    m = re.match(r"tile_walk_pass<(true|false), (\d+), ([\w:<>, ]+?), (true|false)>$", kernel)
+    if m:  # the persistent walk: the grid is the number of CUs, the work is the cell's batch
+        S, pol = int(m.group(2)), m.group(3)
+        pol = {"Small": "Small", "Fp64T<24, 6>": "Fp64L", "Fp64T<7, 3>": "Fp64", "LazyT<128, false>": "Lazy",
+               "Harvey60": "Harvey60"}.get(pol, pol)
+        for c in cells:
+            if c["kind"] == "ntt" and c["logn"] == S and f"({pol})" in c["label"] and c["batch"] * 1024 > grid:
+                return c["label"], 16 * (c["batch"] << c["logn"])
+        return None, None
+    m = re.match(r"tile_pass_multi<(true|false), (\d+), (\d+), .*, (true|false), (true|false)>$", kernel)
     if m:
-        S, TL = int(m.group(2)), int(m.group(3))
+        S, TL, epi = int(m.group(2)), int(m.group(3)), m.group(5) == "true"
         wg = 1 << (TL - (4 if S >= 14 else 3))
         elems = grid // wg << TL
-        lab = next((c["label"] for c in cells if c["kind"] == "keyswitch" and c["n"] == 1 << S), None)
+        c = next((c for c in cells if c["kind"] == "keyswitch" and c["n"] == 1 << S), None)
+        lab = c["label"] if c else None
+        if epi and c:
+            # the fused tail of KeySwitch (rounding on load, finish on store): per (target, component)
+            # the last component once + prod in, result in and out for each of the D moduli
+            polys = elems >> S
+            return lab + " -- fused tail (round | forward NTT | finish)", 8 * (1 << S) * (polys // c["D"] + 3 * polys)
         return lab, 16 * elems
     m = re.match(r"eltwise_vec2<(\w+)", kernel)
     if m:
@@ -183,10 +198,10 @@ def main():
            "conflict | LDS busy | VALU/wave | GHz |")
     sep = "|" + "---|" * 15
     groups = [("One-kernel transform plans and the headline shape under the cheap policies",
-               lambda r: r["kernel"].startswith(("tile_pass<", "strided_pass<"))),
+               lambda r: r["kernel"].startswith(("tile_pass<", "strided_pass<", "tile_walk_pass<"))),
               ("Element-wise kernels", lambda r: r["kernel"].startswith(("eltwise", "dyadic"))),
               ("KeySwitch (256 targets per call)", lambda r: r["kernel"].startswith(("ks_", "tile_pass_multi")) or
-               (r["cell"] is None and r["kernel"].startswith("tile_pass<")))]
+               (r["cell"] is None and r["kernel"].startswith(("tile_pass<", "tile_walk_pass"))))]
     seen = set()
     for title, pred in groups:
         out += [f"## {title}", "", hdr, sep]
@@ -207,8 +222,8 @@ def main():
     open(os.path.join(DST, f"r{ROUND}_pmc_{SUFFIX}.md"), "w").write("\n".join(out) + "\n")
     sys.path.insert(0, ROOT)
     import bench
-    json.dump({"source": f"profiles/r{ROUND}_pmc_{SUFFIX}.md", "kernel_source_sha16": bench.kernel_source_hash(),
-               "kernel_sources": list(bench.KERNEL_SOURCES), "rows": rows},
+    json.dump({"source": f"profiles/r{ROUND}_pmc_{SUFFIX}.md", "kernel_source_sha16": bench.cell_source_hash(),
+               "kernel_sources": list(bench.CELL_SOURCES), "rows": rows},
               open(os.path.join(DST, f"r{ROUND}_pmc_{SUFFIX}.json"), "w"), indent=1)
     print("\n".join(out))
 

@@ -1505,6 +1505,43 @@ def test_key_switch_batch_vs_oracle(hx, ho, n, D, K, C, T, bits):
     assert np.array_equal(host(hx, d_res), want)
 
 
+@pytest.mark.parametrize("n,D,K,C,T,bits", [(32768, 3, 4, 2, 3, 54), (8192, 2, 3, 3, 40, 54), (16384, 3, 4, 2, 60, 59),
+                                            (4096, 2, 3, 2, 7, 44)])
+def test_key_switch_fused_tail(hx, ho, n, D, K, C, T, bits):
+    """Round 6: the rounding stage rides on the load and the finish stage on the store of the forward
+    transform between them (`ks_fuse`, key-switch-internal.cpp:146-196) -- two-pass plans (n = 32768: the
+    strided pass rounds on load, the tile pass folds into the result), one-kernel plans with enough
+    polynomials (n = 8192 / 16384: 240 / 360 of them), three key components, moduli of mixed size
+    (reduce and copy branches of the rounding, mixed arithmetic policies in one launch sequence):
+    fused == stage by stage bit for bit, both == the oracle on the first, a middle and the last target."""
+    rng = np.random.default_rng(n + D + T)
+    moduli = [int(q) for q in ho.generate_primes(K, bits, True, n)]
+    moduli[0] = int(ho.generate_primes(1, bits - 9, True, n)[0])
+    if D >= 2:
+        moduli[1] = int(ho.generate_primes(1, min(bits + 5, 60), False, n)[0])
+    R = D + 1
+    keys = [np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                            for _ in range(C) for i in range(K)]) for j in range(D)]
+    msf = [int(rng.integers(1, moduli[i], dtype=np.uint64)) for i in range(D)]
+    targets = [np.concatenate([rng.integers(0, moduli[j], n, dtype=np.uint64) for j in range(D)])
+               for _ in range(T)]
+    results = [np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                               for _ in range(C) for i in range(D)]) for _ in range(T)]
+    d_keys = [dev(hx, k) for k in keys]
+    got = {}
+    try:
+        for fuse in (0, 1):
+            hx.set_tuning("ks_fuse", fuse)
+            d_res = dev(hx, np.concatenate(results))
+            hx.KeySwitchBatch(d_res, dev(hx, np.concatenate(targets)), T, n, D, K, R, C, moduli, d_keys, msf)
+            got[fuse] = host(hx, d_res).reshape(T, -1)
+    finally:
+        hx.set_tuning("ks_fuse", 1)
+    assert np.array_equal(got[0], got[1])
+    for t in sorted({0, T // 2, T - 1}):
+        assert np.array_equal(got[1][t], ho.key_switch(results[t], targets[t], n, D, K, R, C, moduli, keys, msf))
+
+
 def _ks_case(ho, rng, n, D, K, C, bits):
     moduli = [int(q) for q in ho.generate_primes(K, bits, True, n)]
     keys = [np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)

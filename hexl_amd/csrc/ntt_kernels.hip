@@ -135,7 +135,7 @@ constexpr u32 kStageMaskShift = 8;
 // exactly once, and marking the accesses so is worth 4-6 % on the HBM-bound strided
 // pass and 3 % on the forward tile pass; the single-plan inverse tile pass streams too since round 6
 // (0.7 % of the headline step; the multi-plan inverse keeps plain accesses).
-enum : int { kPlain = 0, kStream = 1 };
+enum : int { kPlain = 0, kStream = 1, kRaw = 2 };  // kRaw: raw_load_b64 / raw_store_b64 below (nontemporal)
 
 template <int KIND>
 __device__ __forceinline__ u64 ld_global(const u64* p) {
@@ -176,6 +176,31 @@ __device__ __forceinline__ void entry_words(u64* x, u32 flags, const ModConst& m
 #pragma unroll
     for (int e = 0; e < E; ++e) x[e] = reduce_any_straight(x[e], m.q, m.barrett);
   }
+}
+
+// Vector memory operations OUTSIDE the compiler's s_waitcnt bookkeeping (the persistent tile walk).
+// hipcc counts the operations in flight per basic block and merges the counts where paths join by
+// assuming the FEWEST newer operations: at the head of the walk's loop (entered from the prologue,
+// with nothing behind the tile's loads, and from the back edge, with the previous tile's sixteen
+// stores behind them) every wait for a load became a wait for those stores' acknowledgements too --
+// vmcnt(13) ... vmcnt(0) where the back edge needs vmcnt(29) ... vmcnt(16) -- and under a branch
+// the same happened to the prefetch.  These loads and stores are invisible to that pass; the walk
+// waits for them itself (raw_wait: exact counts, every use of a loaded value behind the wait).
+__device__ __forceinline__ u64 raw_load_b64(const u64* uniform_base, u32 byte_off) {
+  u64 v;
+  asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=v"(v) : "v"(byte_off), "s"(uniform_base) : "memory");
+  return v;
+}
+__device__ __forceinline__ void raw_store_b64(u64* uniform_base, u32 byte_off, u64 v) {
+  asm volatile("global_store_dwordx2 %0, %1, %2 nt" : : "v"(byte_off), "v"(v), "s"(uniform_base) : "memory");
+}
+// wait until at most NEWER of the raw operations issued after the awaited ones are in flight, then
+// pin the E words behind the wait (volatile statements keep their order)
+template <int NEWER, int E>
+__device__ __forceinline__ void raw_wait(u64* x) {
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NEWER) : "memory");
+#pragma unroll
+  for (int i = 0; i < E; ++i) asm volatile("" : "+v"(x[i]));
 }
 
 // ---------------------------------------------------------------------------
@@ -956,6 +981,10 @@ __device__ __forceinline__ void fetch_tile(u64* x, const u64* in, u32 tid, const
     const u32 p0 = xfer_p0<ROUND0, S, CB, TL>(tid, i);
     const u32 dp = xfer_dp<ROUND0, S, CB>(i);
     const u64* src = in + tile_uniform_offset<CB>(g, dp);
+    if constexpr (LDK == kRaw) {  // (the walk: never ragged)
+      x[i] = raw_load_b64(src, tile_byte_offset<CB>(g, p0));
+      continue;
+    }
 #ifdef HEXL_AMD_EXP_NOLOAD  // developer experiment (timing only, wrong results): no global loads
     x[i] = (u64)(p0 + dp) * 0x9E3779B97F4A7C15ull >> 12;
     HX_OPAQUE(x[i]);
@@ -995,6 +1024,10 @@ __device__ __forceinline__ void store_elem(u64* out, u32 tid, int i, u64 v,
 #ifdef HEXL_AMD_EXP_NOSTORE  // developer experiment (timing only): one store in 2^20 happens
   if ((v & 0xfffff) != 0x12345) return;
 #endif
+  if constexpr (STK == kRaw) {
+    raw_store_b64(out + tile_uniform_offset<CB>(g, dp), tile_byte_offset<CB>(g, p0), v);
+    return;
+  }
   if (!GUARD || g.base + p0 + dp < total)
     store_global<STK>(out + tile_uniform_offset<CB>(g, dp), tile_byte_offset<CB>(g, p0), v);
 }
@@ -1271,6 +1304,9 @@ __device__ __forceinline__ u32 walk_next(const MultiCtx* mc, u32 t, u32 ntiles, 
   return t;
 }
 
+// (straight into the words of the twiddle array, two 8-byte loads per (W, W') pair: a 16-byte
+// load into a raw 128-bit value and a conversion behind the wait cost a second array and 100 bytes
+// of scratch)
 // The run this wave owns in the deepest round, from registers to its LDS slots (inverse).
 template <int S, int TL>
 __device__ __forceinline__ void walk_park(const u64* x, u64* lds, u32 tid) {
@@ -1306,7 +1342,13 @@ __device__ __forceinline__ void tile_walk(u64* lds, u64* out, const u64* in_arg,
   TileGeom g = make_geom<S, CB, TL>(tile, log_n);
   u64 x[kE];
   __builtin_amdgcn_s_setprio(3);
-  fetch_tile<FWD, S, CB, TL, false, A, kKind, false>(x, in, tid, g, total, flags, m);
+  if constexpr (FWD) {
+    // (raw: nothing the compiler tracks is in flight at the head of the loop on either path)
+    fetch_tile<true, S, CB, TL, false, A, kRaw, false>(x, in, tid, g, total, flags, m);
+    raw_wait<0, kE>(x);
+  } else {
+    fetch_tile<false, S, CB, TL, false, A, kKind, false>(x, in, tid, g, total, flags, m);
+  }
   __builtin_amdgcn_s_setprio(0);
   if constexpr (!FWD) walk_park<S, TL>(x, lds, tid);
   TileGeom gp = g;  // inverse: the tile whose results wait in x for their stores
@@ -1359,25 +1401,35 @@ __device__ __forceinline__ void tile_walk(u64* lds, u64* out, const u64* in_arg,
       u64 y[kE];
 #pragma unroll
       for (int i = 0; i < kE; ++i) y[i] = 0;
+      // (UNCONDITIONAL loads -- the last tile of a workgroup requests itself once more and drops
+      // it: issued under `if (more)`, the join of the two paths made every later wait for the
+      // round's own twiddle loads a wait for the prefetch as well -- vmcnt(5) ... vmcnt(0) where the
+      // prefetching path needs vmcnt(21) ... vmcnt(16) -- and the walk gained nothing)
       auto prefetch = [&]() {
         asm volatile("" : "+v"(tid));
         look_ahead();
-        if (more) {
-          __builtin_amdgcn_s_setprio(3);
-          fetch_tile<true, S, CB, TL, false, A, kKind, false>(y, nin, tid, ng, total, nflags, m);
-          __builtin_amdgcn_s_setprio(0);
-        }
+        const u64* pin = more ? nin : in;
+        const TileGeom pg = more ? ng : g;
+        // the round's own (tracked) twiddle loads are waited for here, where they have long
+        // arrived: behind the raw loads a wait for them would be a wait for the prefetch
+        __builtin_amdgcn_sched_barrier(0);  // (... here: the scheduler hoisted the wait to the loads' issue)
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) expcnt(7) lgkmcnt(15)
+        __builtin_amdgcn_s_setprio(3);
+        fetch_tile<true, S, CB, TL, false, A, kRaw, false>(y, pin, tid, pg, total, nflags, m);
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
       };
       fwd_mid_rounds<S, CB, TL, 1, A, CTW>(x, lds, tw, tid, g, m, il, wn, flags >> kStageMaskShift,
                                            prefetch);
       asm volatile("" : "+v"(tid));
+      // (raw stores, exactly kE of them behind the prefetch: the wait below counts on it)
       if (finish == 2)
-        fwd_copy_out<2, S, CB, TL, false, A, kKind>(lds, out, tid, g, total, m);
+        fwd_copy_out<2, S, CB, TL, false, A, kRaw>(lds, out, tid, g, total, m);
       else if (finish)
-        fwd_copy_out<1, S, CB, TL, false, A, kKind>(lds, out, tid, g, total, m);
+        fwd_copy_out<1, S, CB, TL, false, A, kRaw>(lds, out, tid, g, total, m);
       else
-        fwd_copy_out<0, S, CB, TL, false, A, kKind>(lds, out, tid, g, total, m);
+        fwd_copy_out<0, S, CB, TL, false, A, kRaw>(lds, out, tid, g, total, m);
+      raw_wait<kE, kE>(y);  // the prefetch has landed; this tile's stores are still draining
 #pragma unroll
       for (int i = 0; i < kE; ++i) x[i] = y[i];
     } else {
@@ -1386,6 +1438,11 @@ __device__ __forceinline__ void tile_walk(u64* lds, u64* out, const u64* in_arg,
       // The PREVIOUS tile's results are still in x: they are stored here, behind the request for
       // this tile's per-lane twiddles -- vector memory operations complete in order, and a load
       // issued behind the stores would wait for their acknowledgements.
+      // (Tracked loads and stores.  The compiler moves the conditional stores in front of the
+      // twiddle loads and merges the two paths conservatively, so the first twiddle wait still
+      // includes the stores' acknowledgements; the raw form of raw_load_b64 -- twiddles, stores and the
+      // wait by hand -- was built for this spot too and cost the mid rounds their registers: 100 bytes
+      // of scratch, the prefetch parked in scratch again.  Not adopted.)
       TwT<A> wtop[kE], w0[kE];
       if constexpr (NR > 1) round_twiddles<S, CB, TL, NR - 1, CTW>(wtop, tw, tid, g);
       if (!first_iteration) {
@@ -1496,9 +1553,9 @@ int set_tuning(const char* key, u64 value) {
 
 // Where the persistent 14-stage tile walk (tile_walk) replaces one workgroup per tile.  Measured
 // at N = 16384 x 8192 (profiles/r6_walk14_ab.txt): the inverse gains with every arithmetic policy
-// (Small -16 %, Fp64 / Fp64L -9 %, Lazy -10 %, Harvey60 -6 %); the forward only with the Fp64
-// family (-5 ... -7 %), is flat under Lazy and loses 9 % under Small.  "walk14": 0 = never,
-// 1 = this table, 2 = always (A/B).
+// (Small -17 %, Fp64 / Fp64L -8 %, Lazy -11 %, Harvey60 -8 %); the forward only with the Fp64
+// family (-7 %), within +-2 % under the other policies.  "walk14": 0 = never, 1 = this table,
+// 2 = always (A/B).
 // MULTI (several moduli in one launch): the inverse walk of the Lazy family carries the plan's
 // constants through the loop beside everything else, spills 52-64 bytes and measured 3 % slower than
 // one workgroup per polynomial (8 moduli x 512 polynomials, tools/rns_ab.py; Harvey60 -7 %, Fp64L

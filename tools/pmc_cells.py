@@ -11,9 +11,9 @@ headline configuration (whose own profile is tools/collect_profiles.sh):
     MultMod at configs[1]'s
   * the composites: DyadicMultiply, KeySwitch with 256 targets per call at n = 16384
 
-Every cell uses kernels whose demangled name (template arguments included) no other cell uses, or a
-launch grid no other cell uses, so the summariser (tools/summarize_pmc_cells.py) attributes
-counters by (kernel name, grid size).  Prints a JSON manifest (the cells, their algorithmic bytes
+A marker launch (a tiny AddMod whose grid encodes the cell's index) precedes every cell, so the
+summariser (tools/summarize_pmc_cells.py) attributes each dispatch to its cell by dispatch order and
+groups counters by (cell, kernel name, grid size).  Prints a JSON manifest (the cells, their algorithmic bytes
 per launch) on stdout; `--list` prints it without touching the GPU.  No oracle, no checks: the
 parity tests are tests/test_gpu_parity.py.
 
@@ -91,7 +91,13 @@ def run(cells, reps):
     import hexl_amd as hx
     rng = np.random.default_rng(1)
 
-    for c in cells:
+    marker = torch.zeros(512 * (len(cells) + 1), dtype=torch.int64, device="cuda")
+    for index, c in enumerate(cells):
+        # a marker launch in front of every cell: eltwise_vec2<AddOp> over 512 * (index + 1) words, a
+        # grid no measured kernel has -- the summariser attributes every later dispatch to this cell
+        # (kernel names and grids alone cannot: the persistent walk's grid is the number of CUs)
+        c["index"] = index
+        hx.EltwiseAddMod(marker, marker, marker, 512 * (index + 1), 257)
         if c["kind"] == "ntt":
             n, batch = 1 << c["logn"], c["batch"]
             q = hx.GeneratePrimes(1, c["bits"], True, n)[0]

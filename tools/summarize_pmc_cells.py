@@ -36,13 +36,29 @@ def short(name):
     return name
 
 
+MARK = "eltwise_vec2<AddOp"
+
+
+def marker_cell(kernel, grid):
+    """index of the cell a marker launch announces (tools/pmc_cells.py), or None"""
+    if kernel.startswith(MARK) and grid % 256 == 0 and grid // 256 <= 4096 and grid < 4096 * 256:
+        return grid // 256 - 1
+    return None
+
+
 def trace():
     out = defaultdict(list)
     meta = {}
     for f in glob.glob(os.path.join(SRC, "trace", "**", "*kernel_trace.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
+        cell = None
+        for r in sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"])):
             grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
-            k = (short(r["Kernel_Name"]), grid)
+            kernel = short(r["Kernel_Name"])
+            mc = marker_cell(kernel, grid)
+            if mc is not None:
+                cell = mc
+                continue
+            k = (cell, kernel, grid)
             out[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
             meta[k] = {"workgroup": int(r["Workgroup_Size_X"]), "lds_bytes": int(r["LDS_Block_Size"]),
                        "scratch": int(r["Scratch_Size"])}
@@ -53,83 +69,58 @@ def trace():
 def counters(name):
     acc = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(os.path.join(SRC, name, "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
-            acc[(short(r["Kernel_Name"]), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        cell = None
+        last_dispatch = None
+        for r in sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"])):
+            kernel, grid = short(r["Kernel_Name"]), int(r["Grid_Size"])
+            mc = marker_cell(kernel, grid)
+            if mc is not None:
+                cell = mc
+                continue
+            acc[(cell, kernel, grid)][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
 
 
-def cell_of(kernel, grid, cells):
-    """The manifest cell a (kernel, grid) group belongs to, and the algorithmic bytes of ONE launch."""
-    m = re.match(r"tile_pass<(true|false), (\d+), 0, (\d+), \w+, ([\w:<>, ]+?), (true|false)>$", kernel)
-    if m:
-        S, TL, pol = int(m.group(2)), int(m.group(3)), m.group(4)
-        pol = {"Small": "Small", "Fp64T<24, 6>": "Fp64L", "Fp64T<7, 3>": "Fp64", "LazyT<128, false>": "Lazy",
-               "Harvey60": "Harvey60"}.get(pol, pol)
-        wg = 1 << (TL - (4 if S >= 14 else 3))
-        elems = grid // wg << TL
-        for c in cells:
-            if c["kind"] == "ntt" and f"({pol})" in c["label"] and (c["batch"] << c["logn"]) == elems and \
-                    (c["logn"] == S or (c["logn"] == 16 and S == 11)):
-                return c["label"], 16 * elems
-        return None, 16 * elems  # a transform inside a composite
-    m = re.match(r"strided_pass<(true|false), (\d+), ([\w:<>, ]+?), (true|false)>$", kernel)
-    if m:
-        elems = grid << int(m.group(2))
-        for c in cells:
-            if c["kind"] == "ntt" and c["logn"] == 16 and (c["batch"] << 16) == elems:
-                pol = m.group(3).replace("Fp64T<7, 3>", "Fp64")
-                if f"({pol})" in c["label"]:
-                    return c["label"], 16 * elems
-        return None, 16 * elems
-    m = re.match(r"tile_walk_pass<(true|false), (\d+), ([\w:<>, ]+?), (true|false)>$", kernel)
-    if m:  # the persistent walk: the grid is the number of CUs, the work is the cell's batch
-        S, pol = int(m.group(2)), m.group(3)
-        pol = {"Small": "Small", "Fp64T<24, 6>": "Fp64L", "Fp64T<7, 3>": "Fp64", "LazyT<128, false>": "Lazy",
-               "Harvey60": "Harvey60"}.get(pol, pol)
-        for c in cells:
-            if c["kind"] == "ntt" and c["logn"] == S and f"({pol})" in c["label"] and c["batch"] * 1024 > grid:
-                return c["label"], 16 * (c["batch"] << c["logn"])
+def cell_of(kernel, grid, c):
+    """(label, algorithmic bytes of ONE launch) of a kernel dispatched inside manifest cell c."""
+    if c is None:
         return None, None
-    m = re.match(r"tile_pass_multi<(true|false), (\d+), (\d+), .*, (true|false), (true|false)>$", kernel)
-    if m:
-        S, TL, epi = int(m.group(2)), int(m.group(3)), m.group(5) == "true"
-        wg = 1 << (TL - (4 if S >= 14 else 3))
-        elems = grid // wg << TL
-        c = next((c for c in cells if c["kind"] == "keyswitch" and c["n"] == 1 << S), None)
-        lab = c["label"] if c else None
-        if epi and c:
-            # the fused tail of KeySwitch (rounding on load, finish on store): per (target, component)
-            # the last component once + prod in, result in and out for each of the D moduli
-            polys = elems >> S
-            return lab + " -- fused tail (round | forward NTT | finish)", 8 * (1 << S) * (polys // c["D"] + 3 * polys)
-        return lab, 16 * elems
-    m = re.match(r"eltwise_vec2<(\w+)", kernel)
-    if m:
-        op = {"MultOp": "mult", "FmaOp": "fma", "ReduceOp": "reduce", "ReduceFmaOp": "reducefma", "AddOp": "add"}.get(m.group(1))
-        n = grid * 2  # 16 bytes per lane
-        for c in cells:
-            if c["kind"] == "eltwise" and c["op"].startswith(op or "?") and abs(c["n"] - n) <= 2 * 256 * 2:
-                if op == "reduce":
-                    return "EltwiseReduceMod configs[4] (q->1 and 4->1, one kernel)", c["alg_bytes"]
-                if c["op"] == op:
-                    return c["label"], c["alg_bytes"]
-    if kernel.startswith("dyadic_multiply_kernel"):
-        c = next((c for c in cells if c["kind"] == "dyadic"), None)
-        return (c["label"], c["alg_bytes"]) if c else (None, None)
-    if kernel.startswith("ks_"):
-        # element-wise stages of KeySwitch; algorithmic bytes per launch in units of polynomials:
-        for c in cells:
-            if c["kind"] != "keyswitch":
-                continue
-            n, D, T, C = c["n"], c["D"], c["T"], 2
-            K = D + 1
-            per = {"ks_mac_kernel": (T * (D * D + D + (D + 1) * C) + D * C * K, ((n + 255) // 256) * 256 * (D + 1) * ((T + 3) // 4)),
-                   "ks_round_kernel": (T * C * (1 + D), ((n + 255) // 256) * 256 * D * T * C),
-                   "ks_finish_kernel": (T * C * D * 4, ((n + 255) // 256) * 256 * D * T * C)}
-            polys, g = per.get(kernel, (None, None))
-            if g == grid:
-                return c["label"], 8 * n * polys
-    return None, None
+    lab = c["label"]
+    if c["kind"] == "ntt":
+        if kernel.startswith(("tile_pass<", "tile_walk_pass<", "strided_pass<")):
+            return lab, 16 * (c["batch"] << c["logn"])  # one read + one write of the batch per pass
+        return lab, None
+    if c["kind"] == "eltwise":
+        if kernel.startswith("eltwise_vec2<"):
+            if c["op"] in ("reduce", "reduce41"):
+                return lab, c["alg_bytes"]
+            return lab, c["alg_bytes"]
+        return lab, None
+    if c["kind"] == "dyadic":
+        return lab, c["alg_bytes"] if kernel.startswith("dyadic_multiply_kernel") else None
+    if c["kind"] == "keyswitch":
+        n, D, T, C = c["n"], c["D"], c["T"], 2
+        K = D + 1
+        poly = 8 * n
+        if kernel.startswith("ks_mac_kernel"):
+            return lab + " -- multiply-accumulate", poly * (T * (D * D + D + (D + 1) * C) + D * C * K)
+        if kernel.startswith("ks_round_kernel"):
+            return lab + " -- rounding", poly * T * C * (1 + D)
+        if kernel.startswith("ks_finish_kernel"):
+            return lab + " -- finish", poly * T * C * D * 4
+        m = re.match(r"tile_pass_multi<(true|false), (\d+), (\d+), .*, (true|false), (true|false)>$", kernel)
+        if m:
+            S, TL, epi = int(m.group(2)), int(m.group(3)), m.group(5) == "true"
+            polys = (grid // (1 << (TL - (4 if S >= 14 else 3))) << TL) >> S
+            if epi:  # the fused tail: last component once per (target, component) + prod in, result in and out
+                return lab + " -- fused tail (round | forward NTT | finish)", poly * (polys // D + 3 * polys)
+            which = "forward NTT of the operands" if m.group(1) == "true" else "inverse NTT of the targets"
+            return lab + " -- " + which, 2 * poly * polys
+        if kernel.startswith(("tile_pass<false", "tile_walk_pass<false")):
+            return lab + " -- inverse NTT of the last components", 2 * poly * T * C
+        if kernel.startswith(("strided_pass", "tile_pass<", "tile_walk_pass")):
+            return lab + " -- (a transform)", None
+    return lab, None
 
 
 def main():
@@ -138,11 +129,14 @@ def main():
     dur, meta = trace()
     fetch, write, sq, sq2, lds = (counters(n) for n in ("fetch", "write", "sq", "sq2", "lds"))
     rows = []
-    for k in sorted(dur, key=lambda k: (k[0], k[1])):
-        kernel, grid = k
-        if kernel.startswith("__amd") or "fill_splitmix" in kernel:
+    by_index = {c.get("index", i): c for i, c in enumerate(cells)}
+    for k in sorted(dur, key=lambda k: (-1 if k[0] is None else k[0], k[1], k[2])):
+        cell_index, kernel, grid = k
+        if kernel.startswith("__amd") or "fill_splitmix" in kernel or cell_index is None:
             continue
-        label, alg = cell_of(kernel, grid, cells)
+        if kernel.startswith(("at::", "void at::")):
+            continue
+        label, alg = cell_of(kernel, grid, by_index.get(cell_index))
         ns = dur[k]
         row = {"kernel": kernel, "grid": grid, "cell": label, "traced_us": ns / 1e3, "alg_bytes": alg,
                **meta[k]}
@@ -200,15 +194,14 @@ def main():
     groups = [("One-kernel transform plans and the headline shape under the cheap policies",
                lambda r: r["kernel"].startswith(("tile_pass<", "strided_pass<", "tile_walk_pass<"))),
               ("Element-wise kernels", lambda r: r["kernel"].startswith(("eltwise", "dyadic"))),
-              ("KeySwitch (256 targets per call)", lambda r: r["kernel"].startswith(("ks_", "tile_pass_multi")) or
-               (r["cell"] is None and r["kernel"].startswith(("tile_pass<", "tile_walk_pass"))))]
+              ("KeySwitch (256 targets per call)", lambda r: "KeySwitch" in (r["cell"] or ""))]
     seen = set()
     for title, pred in groups:
         out += [f"## {title}", "", hdr, sep]
         for r in rows:
             if id(r) in seen or not pred(r):
                 continue
-            if title.startswith("One-kernel") and r["cell"] is None:
+            if title.startswith("One-kernel") and (r["cell"] is None or "KeySwitch" in r["cell"]):
                 continue
             seen.add(id(r))
             out.append("| `{}` | {} | {} | {:.1f} | {} | {} | {} | {} | {} | {} | {} | {} | {} | {} | {} |".format(

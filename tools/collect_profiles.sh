@@ -14,9 +14,9 @@ OUT=$REPO/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export BENCH_SUSTAINED_S=0  # (the 3 s steady-state loop is not part of what the counters describe)
-BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary"
+BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-probe"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- \
-  python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_under_trace.json 2> $OUT/trace.log
+  python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --no-probe > $OUT/bench_under_trace.json 2> $OUT/trace.log
 run_pmc() {  # name, counters..., then -- command
   local name=$1; shift
   local ctr=()

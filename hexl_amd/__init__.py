@@ -527,7 +527,7 @@ def KeySwitch(result, t_target_iter, n, decomp_modulus_size, key_modulus_size, r
 
 def KeySwitchBatch(result, t_target_iter, num_targets, n, decomp_modulus_size, key_modulus_size,
                    rns_modulus_size, key_component_count, moduli, k_switch_keys, modswitch_factors):
-    """num_targets ciphertexts with the same keys and moduli in one call (at most eleven launches
+    """num_targets ciphertexts with the same keys and moduli in one call (at most nine launches
     whatever the sizes): targets and results back to back in the layouts of KeySwitch."""
     mod = (C.c_uint64 * len(moduli))(*[int(m) for m in moduli])
     msf = (C.c_uint64 * len(modswitch_factors))(*[int(m) for m in modswitch_factors])

@@ -393,7 +393,7 @@ int hexl_amd_key_switch(uint64_t* result, const uint64_t* t_target_iter_ptr,
                         const uint64_t* modswitch_factors, void* stream);
 /* Many ciphertexts with the same keys and moduli in one call -- the loop SEAL runs around
  * KeySwitch (one call per ciphertext, key-switch-internal.cpp:25-201 each time) as ONE
- * sequence of at most eleven launches: t_target_iter_ptr holds num_targets targets back to back
+ * sequence of at most nine launches: t_target_iter_ptr holds num_targets targets back to back
  * (each decomp_modulus_size x n), result num_targets results back to back (each
  * key_component_count x decomp_modulus_size x n, accumulated into).  Every per-modulus
  * transform of every target runs in one multi-plan NTT launch.  num_targets *
@@ -511,7 +511,8 @@ int hexl_amd_profile_get(int i, const char** name, float* ms);
  *   "ks_graph"         1 (default) = hexl_amd_key_switch / _host / _batch calls of at most four
  *                      targets whose buffers, keys and moduli were seen before on the same stream
  *                      are replayed from a HIP graph captured at their second sight (one graph
- *                      launch instead of up to eleven kernel launches); 0 = always launch by launch
+ *                      launch instead of up to nine kernel launches; captured on a stream of the
+ *                      library's own, never on the caller's); 0 = always launch by launch
  *   "ks_fuse"          1 (default) = the rounding and finish stages of KeySwitch ride on the load /
  *                      store of the forward transform between them (two launches and two
  *                      intermediate buffers less; degrees from 4096), 0 = stage by stage

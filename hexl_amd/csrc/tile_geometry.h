@@ -50,6 +50,8 @@ struct Rounds {
   // executed just before it.  (Doing the same for per-lane twiddles needs 28 more
   // VGPRs during a round and spills under the 64-VGPR cap of 8 waves per SIMD.)
   // Forward executes rounds 0..NR-1, inverse NR-1..0.
+  // (round 6: the same for the per-lane twiddles of round 2 of the 16-element geometry -- requested during
+  // round 1, whose twiddles are scalar: fits the 128 VGPRs, measured flat at N = 16384, not kept)
   static constexpr bool pre_fwd(int j) { return j >= 1 && j < NR && !vec(j); }
   static constexpr bool pre_inv(int j) { return j >= 0 && j <= NR - 2 && !vec(j); }
   // Fp64 family, forward: a pass starts from fully reduced values; all elements are reduced

@@ -558,6 +558,39 @@ def test_host_transform_chunk_pipeline(hx, ho, threads):
         hx.set_tuning("host_copy_threads", 6)
 
 
+def test_host_transforms_from_several_threads(hx, ho):
+    """Four host threads calling the *_host transform at once on their own 12 MiB buffers of ordinary memory: each has
+    its own pinned slots, streams and chunk pipeline; the copy pool serves one of them at a time (the others copy by
+    themselves).  Every result equals the device path's."""
+    import ctypes as C
+    import threading
+    n, batch = 32768, 48
+    q = ho.generate_primes(1, 54, True, n)[0]
+    ntt = hx.NTT(n, q)
+    xs = [np.random.default_rng(100 + t).integers(0, q, (batch, n), dtype=np.uint64) for t in range(4)]
+    want = []
+    for x in xs:
+        d = hx.from_numpy(x)
+        ntt.ComputeForward(d, d, 1, 1)
+        want.append(hx.to_numpy(d))
+    assert np.array_equal(want[0][[0, batch - 1]], ho.NTT(n, q).forward(xs[0][[0, batch - 1]], 1, 1))
+    outs = [np.zeros_like(x) for x in xs]
+    errors = []
+
+    def work(t):
+        for _ in range(3):
+            rc = hx.lib.hexl_amd_ntt_forward_host(ntt._h, outs[t].ctypes.data_as(C.c_void_p),
+                                                  xs[t].ctypes.data_as(C.c_void_p), batch, 1, 1)
+            if rc != 0 or not np.array_equal(outs[t], want[t]):
+                errors.append((t, rc))
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+
+
 @pytest.mark.parametrize("direct", [0, 1])
 def test_host_pointer_paths_above_one_mebibyte(hx, ho, direct):
     """Host-pointer calls whose buffers exceed one pinned slot (1 MiB): by default the library

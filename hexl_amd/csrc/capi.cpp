@@ -1269,8 +1269,13 @@ static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t*
   if (int rc = g_staging.ensure(p->device, bytes)) return rc;
   u64* d = (u64*)g_staging.buf;
   hipStream_t st = g_staging.stream;
+  // (in place or disjoint only: a result that overlaps the operand at an offset -- not a call the
+  // reference defines either -- keeps the plain sequence, which reads all of the operand first)
+  const bool same_or_disjoint = (const void*)result == (const void*)operand ||
+                                (const char*)result + bytes <= (const char*)operand ||
+                                (const char*)operand + bytes <= (const char*)result;
   if (op_range.first == 0 && res_range.first == 0 && batch > 1 && bytes >= 2 * Staging::kBigSlot &&
-      g_host_direct_copy.load() == 0) {
+      same_or_disjoint && g_host_direct_copy.load() == 0) {
     // Ordinary host memory on both sides, several polynomials, 8 MiB or more: a pipeline over
     // chunks of about 4 MiB of whole polynomials (round 6) --
     //   host copy in (k) + out (k - 2)  |  H2D, kernels of chunk k on one stream  |  D2H on another

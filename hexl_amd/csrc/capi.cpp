@@ -1178,6 +1178,9 @@ static std::atomic<u32> g_ks_graph{1};
 // "ks_fuse": 1 (default) = the rounding and finish stages of KeySwitch ride on the load / store of
 // the forward transform between them (round 6), 0 = stage by stage (A/B).
 static std::atomic<u32> g_ks_fuse{1};
+// "ks_mac_onestep": 1 (default) = the multiply-accumulate of KeySwitch reduces a 128-bit sum below
+// 2^(bits(q) + 61) in one generalised Barrett step, 0 = always as BarrettReduce128's two-word form (A/B).
+static std::atomic<u32> g_ks_mac_onestep{1};
 // Bumped by every hexl_amd_set_tuning call: part of the key of a captured KeySwitch sequence, so a
 // graph captured under other tuning values (another kernel selection) is never replayed.
 static std::atomic<u64> g_tuning_epoch{0};
@@ -1195,6 +1198,10 @@ static bool set_host_tuning(const char* key, uint64_t value) {
   }
   if (strcmp(key, "ks_fuse") == 0 && value <= 1) {
     g_ks_fuse = (u32)value;
+    return true;
+  }
+  if (strcmp(key, "ks_mac_onestep") == 0 && value <= 1) {
+    g_ks_mac_onestep = (u32)value;
     return true;
   }
   if (strcmp(key, "host_copy_threads") == 0 && value >= 1 && value <= 64) {
@@ -1770,6 +1777,8 @@ static int key_switch_device(u64* result, const u64* t_target_iter, u64 T, u64 n
       const u32 ceil_log = 64 - __builtin_clzll(q);
       m.shift[i] = ceil_log - 2;
       m.mu[i] = (u64)((((unsigned __int128)(1ull << (ceil_log + 62 - 64))) << 64) / q);
+      // sums below 2^(bits(q) + 61) take one generalised Barrett step (ks_mac_kernel)
+      m.hi_limit[i] = ceil_log >= 4 && g_ks_mac_onestep.load() != 0 ? 1ull << (ceil_log - 3) : 0;
     }
     {
       // The D^2 product operands of a target, ordered by RNS index i: target polynomial j

@@ -207,6 +207,8 @@ struct KsMacAll {
   u64 q[kKsMaxDecomp + 1], barrett[kKsMaxDecomp + 1], two64_mod_q[kKsMaxDecomp + 1],
       mu[kKsMaxDecomp + 1];  // mu, shift: generalised Barrett of MultOp
   u32 shift[kKsMaxDecomp + 1], key_index[kKsMaxDecomp + 1];
+  // a 128-bit sum whose high word is below this takes ONE generalised Barrett step (ks_mac_kernel); 0: never
+  u64 hi_limit[kKsMaxDecomp + 1];
 };
 struct KsRoundMod {
   u64 q, barrett, fix;

@@ -74,6 +74,7 @@ ks_mac_kernel(u64* prod, const u64* t_target_iter, const u64* ntt_buf, KsDims d,
   const u64 buf_off = i < D ? (u64)i * (D - 1) : (u64)D * (D - 1);  // first operand of index i
   const u64 q = m.q[i], barrett = m.barrett[i], two64 = m.two64_mod_q[i], mu = m.mu[i];
   const u32 shift = m.shift[i];
+  const u64 hi_limit = m.hi_limit[i];
   const u64 stride = (u64)gridDim.x * 256;
   for (u64 l = (u64)blockIdx.x * 256 + threadIdx.x; l < n; l += stride) {
     u64 lo[2][kMacTargets], hi[2][kMacTargets];
@@ -107,6 +108,22 @@ ks_mac_kernel(u64* prod, const u64* t_target_iter, const u64* ntt_buf, KsDims d,
 #pragma unroll
         for (int t = 0; t < kMacTargets; ++t) {
           if ((u32)t < nt) {
+            if (hi[c][t] < hi_limit) {
+              // Generalised Barrett with alpha = 62, beta = -2 (MultOp, eltwise_kernels.hip;
+              // eltwise-mult-mod-internal.hpp:50-93) on the whole sum S = hi 2^64 + lo: with n = bits(q),
+              // mu = floor(2^(n + 62) / q), c1 = S >> (n - 2) < 2^63, the estimate floor(c1 mu / 2^64) is
+              // the quotient or one less for every S < 2^(n + 61) (S/q - estimate < 2^(gamma - alpha) +
+              // 2^(beta + 1) + 1 <= 2 with gamma = 61) -- hi < 2^(n - 3), checked per element, so operands
+              // outside the ranges the reference assumes still get the exact path below.  In range (a < 4q
+              // lazy transform outputs, b < q) S < D 2^(2n + 2): every sum of D <= 16 products up to 55-bit
+              // moduli.  One estimate, one multiply, one conditional subtraction instead of two single-word
+              // reductions, a 128-bit product and a second estimate; the same canonical residue as
+              // BarrettReduce128 (util/gcc.hpp:20-28).
+              const u64 c1 = (lo[c][t] >> shift) | (hi[c][t] << (64 - shift));  // (hi_limit > 0: 2 <= shift <= 62)
+              const u64 r = lo[c][t] - __umul64hi(c1, mu) * q;                   // in [0, 2q)
+              prod[(((u64)i * d.targets + t0 + t) * d.components + k0 + c) * n + l] = csub(r, q);
+              continue;
+            }
             // (hi * 2^64 + lo) mod q exactly (BarrettReduce128, util/gcc.hpp:20-28)
             const u64 r1 = full_reduce(hi[c][t], q, barrett);
             const u64 r2 = full_reduce(lo[c][t], q, barrett);

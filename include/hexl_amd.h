@@ -516,6 +516,9 @@ int hexl_amd_profile_get(int i, const char** name, float* ms);
  *   "ks_fuse"          1 (default) = the rounding and finish stages of KeySwitch ride on the load /
  *                      store of the forward transform between them (two launches and two
  *                      intermediate buffers less; degrees from 4096), 0 = stage by stage
+ *   "ks_mac_onestep"   1 (default) = the multiply-accumulate of KeySwitch reduces every 128-bit sum
+ *                      below 2^(bits(q) + 61) in one generalised Barrett step (decided per coefficient;
+ *                      the same canonical residue), 0 = always the two-word form of BarrettReduce128
  *   (the round-2 keys "host_pipeline_min_mb" / "host_chunk_mb" went with the chunked two-stream
  *   host pipeline they switched on: measured equal to the plain sequence, removed in round 5) */
 int hexl_amd_set_tuning(const char* key, uint64_t value);

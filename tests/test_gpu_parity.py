@@ -1511,6 +1511,43 @@ def test_key_switch_random_vs_oracle(hx, ho, n, D, K, C, bits):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n,D,K,C,bits,key_bits", [(4096, 3, 4, 2, 40, 64), (2048, 4, 5, 2, 36, 64),
+                                                   (4096, 2, 3, 3, 45, 62), (1024, 16, 17, 2, 55, 0),
+                                                   (1024, 17, 18, 2, 55, 0), (1024, 3, 4, 2, 58, 0)])
+def test_key_switch_accumulator_on_both_sides_of_the_one_step_limit(hx, ho, n, D, K, C, bits, key_bits):
+    """The multiply-accumulate reduces a 128-bit sum below 2^(bits(q) + 61) in one generalised Barrett step
+    and every other sum like BarrettReduce128 (util/gcc.hpp:20-28; key-switch-internal.cpp:122-130), decided
+    per coefficient.  Key words of up to 64 bits (the reference never reduces or checks them: the sum is still
+    exact as long as it fits 128 bits) put coefficients on both sides of the limit in one call; key_bits = 0:
+    in-range keys with the largest decomposition counts and moduli around the limit."""
+    rng = np.random.default_rng(n + D + bits)
+    moduli = [int(q) for q in ho.generate_primes(K, bits, True, n)]
+    R = D + 1
+    target = np.concatenate([rng.integers(0, moduli[j], n, dtype=np.uint64) for j in range(D)])
+    keys = []
+    for j in range(D):
+        if key_bits:  # a mixture of magnitudes: log-uniform widths up to key_bits
+            width = rng.integers(bits - 4, key_bits + 1, C * K * n)
+            k = rng.integers(0, 2**63, C * K * n, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+            keys.append(k >> (np.uint64(64) - width.astype(np.uint64)))
+        else:
+            keys.append(np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                                        for _ in range(C) for i in range(K)]))
+            keys[-1][::3] = np.tile(np.concatenate([np.full(n, moduli[i] - 1, dtype=np.uint64)
+                                                    for i in range(K)]), C)[::3]
+    msf = [int(rng.integers(1, moduli[i], dtype=np.uint64)) for i in range(D)]
+    result = np.concatenate([rng.integers(0, moduli[i], n, dtype=np.uint64)
+                             for _ in range(C) for i in range(D)])
+    want = ho.key_switch(result, target, n, D, K, R, C, moduli, keys, msf)
+    try:
+        for onestep in (1, 0):
+            hx.set_tuning("ks_mac_onestep", onestep)
+            got = _run_key_switch(hx, result, target, n, D, K, R, C, moduli, keys, msf)
+            assert np.array_equal(got, want), onestep
+    finally:
+        hx.set_tuning("ks_mac_onestep", 1)
+
+
 @pytest.mark.parametrize("n,D,K,C,T,bits", [(4096, 3, 4, 2, 5, 50), (8192, 4, 5, 2, 3, 54),
                                             (64, 2, 3, 2, 4, 40), (16384, 7, 8, 2, 2, 45)])
 def test_key_switch_batch_vs_oracle(hx, ho, n, D, K, C, T, bits):

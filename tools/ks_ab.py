@@ -27,8 +27,8 @@ def call():
 
 if os.environ.get("KS_FUSE") is not None:
     hx.set_tuning("ks_fuse", int(os.environ["KS_FUSE"]))
-if os.environ.get("KS_N"):
-    pass
+if os.environ.get("KS_ONESTEP") is not None:
+    hx.set_tuning("ks_mac_onestep", int(os.environ["KS_ONESTEP"]))
 for _ in range(3):
     call()
 torch.cuda.synchronize()
@@ -38,6 +38,6 @@ for _ in range(10):
     call()
 e1.record()
 torch.cuda.synchronize()
-print(os.path.basename(os.environ.get("HEXL_AMD_LIB", "product")), "ks_fuse=" + os.environ.get("KS_FUSE", "default"),
+print(os.path.basename(os.environ.get("HEXL_AMD_LIB", "product")), "ks_fuse=" + os.environ.get("KS_FUSE", "default"), "onestep=" + os.environ.get("KS_ONESTEP", "default"),
       f"{e0.elapsed_time(e1) / 10 * 1e3 / T:.2f} us per target ({e0.elapsed_time(e1) / 10:.3f} ms per call)",
       "checksum", int(d_rr.view(-1)[::4099].sum().item()) & 0xffffffff, flush=True)

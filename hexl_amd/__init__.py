@@ -584,7 +584,8 @@ def profile_stop():
 
 
 def get_counter(key):
-    """Process-wide event counters: "ks_graph_captures", "ks_graph_replays", "ks_eager"."""
+    """Process-wide event counters: "ks_graph_captures", "ks_graph_replays", "ks_eager", "host_polls",
+    "host_poll_timeouts"."""
     v = C.c_uint64(0)
     _check(lib.hexl_amd_get_counter(key.encode(), C.byref(v)))
     return int(v.value)
@@ -592,7 +593,7 @@ def get_counter(key):
 
 def set_tuning(key, value):
     """Tuning knobs (include/hexl_amd.h documents them): "fp64", "fp64_long", "lazy_family", "h60" (read when a
-    plan is created), "tile13", "bigtile", "walk14", "host_bounce_kb", "host_direct_copy", "host_copy_threads", "ks_graph", "ks_fuse", "ks_mac_onestep".
+    plan is created), "tile13", "bigtile", "walk14", "host_bounce_kb", "host_direct_copy", "host_copy_threads", "host_poll", "ks_graph", "ks_fuse", "ks_mac_onestep".
     The library reads no environment variable; results never depend on the knobs."""
     _check(lib.hexl_amd_set_tuning(key.encode(), int(value)))
 

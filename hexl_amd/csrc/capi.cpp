@@ -3,6 +3,7 @@
 // staging.  All compute is in ntt_kernels.hip / eltwise_kernels.hip; there is
 // no CPU fallback -- if HIP is unusable every compute entry point fails.
 #include <hip/hip_runtime_api.h>
+#include <time.h>
 
 #include <atomic>
 #include <condition_variable>
@@ -102,6 +103,16 @@ struct StreamDeviceScope : DeviceScope {
   if (stream_scope_.err != hipSuccess) return hip_fail(stream_scope_.err, "selecting the stream's device")
 
 // Per-thread staging buffers for the host-pointer entry points.
+// "host_poll": 1 (default) = a host-pointer call learns that its stream's work is done from a sequence
+// number that a one-thread kernel behind the work stores into device-mapped host memory and the calling
+// thread polls (Staging::finish); 0 = hipStreamSynchronize.  The runtime's completion path (signal,
+// its bookkeeping on the host) costs 3-4 us more than the extra dispatch: N = 4096 one polynomial on
+// mapped memory 17.2 -> 13.8 us, N = 16384 24.3 -> 21.1 (tools/completion_probe.hip; an in-kernel flag
+// measured the same as the flag kernel).
+std::atomic<u32> g_host_poll{1};
+// hexl_amd_get_counter: waits that the flag ended / that ran out of polling time and went to the runtime
+std::atomic<u64> g_host_polls{0}, g_host_poll_timeouts{0};
+
 struct Staging {
   int device = -1;
   void* buf = nullptr;
@@ -115,6 +126,10 @@ struct Staging {
   void* bounce = nullptr;      // host address
   void* bounce_dev = nullptr;  // the address kernels use
   size_t bounce_cap = 0;
+  // completion flag of `stream` (pinned, device-mapped) and the last sequence number asked for
+  u32* done = nullptr;
+  u32* done_dev = nullptr;
+  u32 done_seq = 0;
   // Copies between ordinary (pageable) caller memory and the device go through these pinned
   // slots, never through the runtime's own handling of pageable memory: from about 1 MiB the HIP
   // runtime pins the CALLER's pages for the duration of a copy instead of staging them, and
@@ -157,6 +172,7 @@ struct Staging {
     }
     if (buf) (void)hipFree(buf);
     if (bounce) (void)hipHostFree(bounce);
+    if (done) (void)hipHostFree(done);
     for (int b = 0; b < kSlots; ++b) {
       (void)slot_free(b);
       if (slot_ev[b]) (void)hipEventDestroy(slot_ev[b]);
@@ -201,6 +217,45 @@ struct Staging {
     slot_state[b] = kSlotFree;
     if (was == kSlotEvent) HX_HIP(hipEventSynchronize(slot_ev[b]));
     if (was == kSlotStream) HX_HIP(hipStreamSynchronize(slot_stream[b]));
+    return HEXL_AMD_OK;
+  }
+  // Returns when everything enqueued on st so far is done.  The thread's own stream: by polling the
+  // completion flag ("host_poll"), for at most about a millisecond -- work that long is left to
+  // hipStreamSynchronize, which is also what reports an error of the stream.  For calls whose last
+  // operation on the stream is a KERNEL (the bounce buffer, mapped caller memory): behind a copy out
+  // the flag kernel's dependency on the copy costs more than the runtime's wait (N = 65536 staged:
+  // 84 -> 100 us when the copy's wait polled), so the staged paths keep hipStreamSynchronize.
+  int finish(hipStream_t st) {
+    if (st != nullptr && st == stream && g_host_poll.load(std::memory_order_relaxed) != 0) {
+      if (!done) {
+        HX_HIP(hipHostMalloc((void**)&done, 64, hipHostMallocMapped | hipHostMallocPortable));
+        *done = 0;
+        HX_HIP(hipHostGetDevicePointer((void**)&done_dev, done, 0));
+      }
+      const u32 seq = ++done_seq;
+      if (completion_flag_launch(done_dev, seq, st) == hipSuccess) {
+        timespec t0{};
+        for (u32 spins = 1;; ++spins) {
+          if (__atomic_load_n(done, __ATOMIC_ACQUIRE) == seq) {
+            g_host_polls.fetch_add(1, std::memory_order_relaxed);
+            return HEXL_AMD_OK;
+          }
+          __builtin_ia32_pause();
+          if ((spins & 0x3ff) == 0) {
+            timespec t{};
+            clock_gettime(CLOCK_MONOTONIC, &t);
+            if (spins == 0x400) t0 = t;
+            else if ((t.tv_sec - t0.tv_sec) * 1000000000ll + (t.tv_nsec - t0.tv_nsec) > 1000000) {
+              g_host_poll_timeouts.fetch_add(1, std::memory_order_relaxed);
+              break;
+            }
+          }
+        }
+      } else {
+        (void)hipGetLastError();
+      }
+    }
+    HX_HIP(hipStreamSynchronize(st));
     return HEXL_AMD_OK;
   }
   // marks slot b in use by the DMA just enqueued on st; `last`: no more chunks follow in this call
@@ -1166,10 +1221,14 @@ int hexl_amd_ntt_inverse_rns(const hexl_amd_ntt* const* plans, uint64_t num_plan
 // in round 5.
 // Knob of the host path (hexl_amd_set_tuning; no environment variable is read):
 // largest call (bytes of operand) that goes through the mapped bounce buffer: beyond it the
-// host-side copies cost as much as the DMA they replace (measured: N = 65536, 512 KiB: 82 us
-// against 88 staged; N = 131072: 185 against 144; reading only the operand through the buffer:
-// 80 / 142).  "host_bounce_kb"; 0 switches the bounce path off.
-static std::atomic<size_t> g_host_bounce_max_bytes{(size_t)256 << 10};
+// host-side copies cost as much as the DMA they replace (round 4 measured N = 65536, 512 KiB: 82 us
+// against 88 staged; N = 131072: 185 against 144 -- with the completion flag polled, round 6: N = 65536
+// 74 against 83 staged, EltwiseMultMod of 65536 words 66-70 against 91, of 131072 words 145 either
+// way: the limit went from 256 to 512 KiB).  What the buffer costs beyond the two memcpys is the
+// device reading lines the CPU has just written, out of its caches: +1 us at 32 KiB, +4 at 128 KiB,
+// +17 at 512 KiB against memory only the device writes (tests/cpp/host_call_budget.cpp: `unaccounted`).
+// "host_bounce_kb"; 0 switches the bounce path off.
+static std::atomic<size_t> g_host_bounce_max_bytes{(size_t)512 << 10};
 static size_t host_bounce_max_bytes() { return g_host_bounce_max_bytes.load(); }
 // "ks_graph": 1 (default) = a KeySwitch of at most kKsGraphMaxTargets targets whose buffers, keys
 // and moduli were seen before on the same stream is replayed from a captured HIP graph; 0 = the
@@ -1212,6 +1271,10 @@ static bool set_host_tuning(const char* key, uint64_t value) {
     g_host_direct_copy = (u32)value;
     return true;
   }
+  if (strcmp(key, "host_poll") == 0 && value <= 1) {
+    g_host_poll = (u32)value;
+    return true;
+  }
   return false;
 }
 
@@ -1236,6 +1299,11 @@ static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t*
   const RangeKind op_range = classify_range(operand, bytes);
   const RangeKind res_range =
       (const void*)result == (const void*)operand ? op_range : classify_range(result, bytes);
+  // (in place or disjoint only: a result that overlaps the operand at an offset -- not a call the
+  // reference defines either -- keeps the plain sequence, which reads all of the operand first)
+  const bool same_or_disjoint = (const void*)result == (const void*)operand ||
+                                (const char*)result + bytes <= (const char*)operand ||
+                                (const char*)operand + bytes <= (const char*)result;
   void *op_dev = op_range.alias, *res_dev = res_range.alias;
   const int op_kind = op_range.kind, res_kind = res_range.kind;
   if (op_kind == 2) {
@@ -1245,10 +1313,13 @@ static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t*
       return forward ? ntt_forward_launch(p->t, dst, (const u64*)op_dev, batch, out_mf, st)
                      : ntt_inverse_launch(p->t, dst, (const u64*)op_dev, batch, out_mf, st);
     };
-    if (res_kind == 2 && ntt_is_single_kernel(p->t, batch)) {
+    // (a two-pass transform of a small call likewise runs both passes on the caller's mapped memory, as
+    // it does on the bounce buffer below: N = 16384 one polynomial 32 -> 23 us against pass 1 into a
+    // device buffer and a copy back)
+    if (res_kind == 2 && (ntt_is_single_kernel(p->t, batch) || (bytes <= host_bounce_max_bytes() && same_or_disjoint))) {
       hipError_t e = launch((u64*)res_dev);
       if (e != hipSuccess) return hip_fail(e, "NTT launch");
-      HX_HIP(hipStreamSynchronize(st));
+      if (int rc = g_staging.finish(st)) return rc;
       return HEXL_AMD_OK;
     }
     if (int rc = g_staging.ensure(p->device, bytes)) return rc;
@@ -1269,18 +1340,13 @@ static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t*
     memcpy(g_staging.bounce, operand, bytes);
     hipError_t e = run((u64*)g_staging.bounce_dev, batch, st);
     if (e != hipSuccess) return hip_fail(e, "NTT launch");
-    HX_HIP(hipStreamSynchronize(st));
+    if (int rc = g_staging.finish(st)) return rc;
     memcpy(result, g_staging.bounce, bytes);
     return HEXL_AMD_OK;
   }
   if (int rc = g_staging.ensure(p->device, bytes)) return rc;
   u64* d = (u64*)g_staging.buf;
   hipStream_t st = g_staging.stream;
-  // (in place or disjoint only: a result that overlaps the operand at an offset -- not a call the
-  // reference defines either -- keeps the plain sequence, which reads all of the operand first)
-  const bool same_or_disjoint = (const void*)result == (const void*)operand ||
-                                (const char*)result + bytes <= (const char*)operand ||
-                                (const char*)operand + bytes <= (const char*)result;
   if (op_range.first == 0 && res_range.first == 0 && batch > 1 && bytes >= 2 * Staging::kBigSlot &&
       same_or_disjoint && g_host_direct_copy.load() == 0) {
     // Ordinary host memory on both sides, several polynomials, 8 MiB or more: a pipeline over
@@ -1514,7 +1580,7 @@ static int eltwise_host_run(EltOp op, EltArgs g, uint64_t* result, const uint64_
     g.b = (const u64*)b;
     hipError_t e = eltwise_launch(op, g, g_staging.stream);
     if (e != hipSuccess) return hip_fail(e, "eltwise launch");
-    HX_HIP(hipStreamSynchronize(g_staging.stream));
+    if (int rc = g_staging.finish(g_staging.stream)) return rc;
     return HEXL_AMD_OK;
   }
   // small call, every buffer ordinary host memory: the mapped bounce buffer (ntt_run_host).
@@ -1533,7 +1599,7 @@ static int eltwise_host_run(EltOp op, EltArgs g, uint64_t* result, const uint64_
     g.b = has_b ? da_ + n : nullptr;
     hipError_t e = eltwise_launch(op, g, g_staging.stream);
     if (e != hipSuccess) return hip_fail(e, "eltwise launch");
-    HX_HIP(hipStreamSynchronize(g_staging.stream));
+    if (int rc = g_staging.finish(g_staging.stream)) return rc;
     memcpy(result, ha, bytes);
     return HEXL_AMD_OK;
   }
@@ -2142,6 +2208,10 @@ int hexl_amd_get_counter(const char* key, uint64_t* value) {
     *value = g_ks_graph_replays.load();
   else if (strcmp(key, "ks_eager") == 0)
     *value = g_ks_eager.load();
+  else if (strcmp(key, "host_polls") == 0)
+    *value = g_host_polls.load();
+  else if (strcmp(key, "host_poll_timeouts") == 0)
+    *value = g_host_poll_timeouts.load();
   else
     return fail(HEXL_AMD_ERR_INVALID_ARG, "unknown counter: %s", key);
   return HEXL_AMD_OK;

@@ -417,6 +417,17 @@ hipError_t count_out_of_bounds_launch(const u64* data, u64 n, u64 bound,
   return hipGetLastError();
 }
 
+// Behind everything enqueued on its stream so far: publishes `seq` in device-mapped host memory, where the
+// calling host thread polls for it (capi.cpp: Staging::finish).
+__global__ void completion_flag_kernel(u32* flag, u32 seq) {
+  __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t completion_flag_launch(u32* flag, u32 seq, hipStream_t st) {
+  hipLaunchKernelGGL(completion_flag_kernel, dim3(1), dim3(1), 0, st, flag, seq);
+  return hipGetLastError();
+}
+
 hipError_t fill_splitmix_launch(u64* data, u64 n, u64 batch, u64 seed0, u64 bound,
                                 hipStream_t st) {
   const u64 total = n * batch;

@@ -249,6 +249,8 @@ hipError_t ks_finish_launch(u64* result, const u64* prod, const u64* tbuf, const
 hipError_t count_out_of_bounds_launch(const u64* data, u64 n, u64 bound,
                                       unsigned long long* violations, hipStream_t st);
 
+hipError_t completion_flag_launch(u32* flag, u32 seq, hipStream_t st);
+
 hipError_t fill_splitmix_launch(u64* data, u64 n, u64 batch, u64 seed0, u64 bound,
                                 hipStream_t st);
 

@@ -493,7 +493,7 @@ int hexl_amd_profile_get(int i, const char** name, float* ms);
  *                      on the inverse, -5 ... -7 % on the Fp64 forward); 0 = one workgroup per
  *                      polynomial everywhere; 2 = the walk everywhere (A/B)
  *   "host_bounce_kb"   largest host-pointer call (KiB of operand) that runs on the per-thread
- *                      pinned, device-mapped bounce buffer instead of staged copies (default 256;
+ *                      pinned, device-mapped bounce buffer instead of staged copies (default 512;
  *                      0 = never)
  *   "host_direct_copy" 0 (default) = the *_host entry points and hexl_amd_copy move ordinary (pageable)
  *                      caller memory through the calling thread's pinned slots (four, 1 MiB each
@@ -508,6 +508,11 @@ int hexl_amd_profile_get(int i, const char** name, float* ms);
  *                      and a pinned slot, the calling thread included (default 6; 1 = the calling
  *                      thread alone: one memcpy moves 12-25 GB/s, the link 54 GB/s each way).  The
  *                      helpers are created at the first such copy and sleep otherwise
+ *   "host_poll"        1 (default) = a host-pointer call learns that its work is done from a sequence
+ *                      number which a one-thread kernel behind the work stores into device-mapped host
+ *                      memory and the calling thread polls (for at most a millisecond, then it waits
+ *                      in the runtime); 0 = hipStreamSynchronize, whose completion path costs 3-4 us
+ *                      more per call (N = 4096: 17.2 -> 13.8 us on mapped memory)
  *   "ks_graph"         1 (default) = hexl_amd_key_switch / _host / _batch calls of at most four
  *                      targets whose buffers, keys and moduli were seen before on the same stream
  *                      are replayed from a HIP graph captured at their second sight (one graph
@@ -525,7 +530,9 @@ int hexl_amd_set_tuning(const char* key, uint64_t value);
 /* Process-wide event counters (monotonic; for tests and the bench line, which must be able to
  * tell a replayed KeySwitch from a launch-by-launch one): "ks_graph_captures" (sequences
  * captured and instantiated), "ks_graph_replays" (calls served by a graph launch), "ks_eager"
- * (calls enqueued launch by launch).  Unknown keys return HEXL_AMD_ERR_INVALID_ARG. */
+ * (calls enqueued launch by launch); "host_polls" (host-pointer calls whose end the polled completion
+ * flag reported), "host_poll_timeouts" (those that polled for a millisecond and then waited in the
+ * runtime).  Unknown keys return HEXL_AMD_ERR_INVALID_ARG. */
 int hexl_amd_get_counter(const char* key, uint64_t* value);
 
 /* Device scratch of the composite entry points (KeySwitch, the experimental one-launch

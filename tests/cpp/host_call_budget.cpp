@@ -17,7 +17,7 @@
 //
 //   g++ -std=c++17 -O2 -Iinclude tests/cpp/host_call_budget.cpp -Lhexl_amd/lib -lhexl -lhexl_amd
 //       -Wl,-rpath,$PWD/hexl_amd/lib -pthread -o tests/cpp/host_call_budget
-//   tests/cpp/host_call_budget [iterations]      -> one JSON line per degree
+//   tests/cpp/host_call_budget [iterations [host_bounce_kb]]      -> one JSON line per degree
 #include <time.h>
 
 #include <algorithm>
@@ -74,6 +74,10 @@ void budget(uint64_t n, int bits, int iters) {
 
   // the whole call, as an unmodified caller makes it (in place; and out of place)
   const double call = median_us(iters, [&] { ntt.ComputeForward(v.data(), v.data(), 1, 1); });
+  // the same call waiting in hipStreamSynchronize instead of polling the completion flag (round 6 A/B)
+  OK(hexl_amd_set_tuning("host_poll", 0));
+  const double call_sync = median_us(iters, [&] { ntt.ComputeForward(v.data(), v.data(), 1, 1); });
+  OK(hexl_amd_set_tuning("host_poll", 1));
   std::vector<uint64_t> out(n);
   const double call_oop =
       median_us(iters, [&] { ntt.ComputeForward(out.data(), input.data(), 1, 1); });
@@ -127,11 +131,11 @@ void budget(uint64_t n, int bits, int iters) {
 
   const double parts = classify + copy_in + launch_wait + copy_out;
   std::printf(
-      "{\"n\": %llu, \"bits\": %d, \"iterations\": %d, \"call_us\": %.2f, \"call_out_of_place_us\": %.2f, "
+      "{\"n\": %llu, \"bits\": %d, \"iterations\": %d, \"call_us\": %.2f, \"call_out_of_place_us\": %.2f, \"call_stream_synchronize_us\": %.2f, "
       "\"classify_us\": %.2f, \"memcpy_in_us\": %.2f, \"launch_and_wait_mapped_us\": %.2f, "
       "\"memcpy_out_us\": %.2f, \"sum_of_parts_us\": %.2f, \"unaccounted_us\": %.2f, "
       "\"launch_only_us\": %.2f, \"idle_synchronize_us\": %.2f, \"device_call_and_wait_us\": %.2f}\n",
-      (unsigned long long)n, bits, iters, call, call_oop, classify, copy_in, launch_wait, copy_out,
+      (unsigned long long)n, bits, iters, call, call_oop, call_sync, classify, copy_in, launch_wait, copy_out,
       parts, call - parts, launch, idle_wait, dev_call);
   std::fflush(stdout);
   OK(hexl_amd_stream_destroy(stream));
@@ -144,6 +148,7 @@ void budget(uint64_t n, int bits, int iters) {
 
 int main(int argc, char** argv) {
   const int iters = argc >= 2 ? std::atoi(argv[1]) : 2000;
+  if (argc >= 3) OK(hexl_amd_set_tuning("host_bounce_kb", (uint64_t)std::atoll(argv[2])));  // (A/B of the limit)
   budget(4096, 49, iters);
   budget(8192, 54, iters);
   budget(16384, 54, iters);

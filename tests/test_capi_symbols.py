@@ -201,9 +201,9 @@ def test_every_tuning_key_and_counter_is_documented_in_the_header():
     for name in ("capi.cpp", "ntt_kernels.hip"):
         accepted |= set(re.findall(r'strcmp\(key, "([a-z0-9_]+)"\)', open(os.path.join(csrc, name)).read()))
     assert {"fp64", "fp64_long", "lazy_family", "h60", "tile13", "bigtile", "walk14", "host_bounce_kb",
-            "host_direct_copy", "host_copy_threads", "ks_graph", "ks_fuse", "ks_mac_onestep", "ks_graph_replays", "ks_graph_captures", "ks_eager"} <= accepted
+            "host_direct_copy", "host_copy_threads", "host_poll", "ks_graph", "ks_fuse", "ks_mac_onestep", "ks_graph_replays", "ks_graph_captures", "ks_eager", "host_polls", "host_poll_timeouts"} <= accepted
     header = open(os.path.join(ROOT, "include", "hexl_amd.h")).read()
     documented = set(re.findall(r'^ \*   "([a-z0-9_]+)"', header, re.M)) | set(
-        re.findall(r'"(ks_[a-z_]+)"', header))
+        re.findall(r'"(ks_[a-z_]+|host_polls|host_poll_timeouts)"', header))
     assert accepted <= documented, sorted(accepted - documented)
     assert documented <= accepted, sorted(documented - accepted)

@@ -494,7 +494,7 @@ def test_short_lived_registration_then_large_pageable_copies(hx, ho):
 @pytest.mark.parametrize("n,batch,bits", [(4096, 1, 49), (4096, 8, 54), (16384, 2, 54), (16384, 3, 54),
                                           (32768, 1, 54), (65536, 1, 54), (1024, 1, 35), (64, 3, 40)])
 def test_host_pointer_paths_on_ordinary_memory(hx, ho, n, batch, bits):
-    """The *_host entry points on ordinary (pageable) host memory, both sides of the 256 KiB
+    """The *_host entry points on ordinary (pageable) host memory, both sides of the 512 KiB
     bounce-buffer threshold -- one-kernel and two-pass plans in place on the pinned mapped bounce
     buffer below it, staged H2D / D2H above -- in place and out of place, against the oracle."""
     import ctypes as C
@@ -515,6 +515,39 @@ def test_host_pointer_paths_on_ordinary_memory(hx, ho, n, batch, bits):
     assert np.array_equal(r, ho.eltwise_mult_mod(a, b, q, 1))
     assert hx.lib.hexl_amd_eltwise_host(5, p(a), p(a), None, 7, a.size, q, 1, 1) == 0
     assert np.array_equal(a, ho.eltwise_fma_mod(x.reshape(-1), 7, None, q, 1))
+
+
+def test_host_calls_end_on_the_polled_completion_flag(hx, ho):
+    """Round 6: a host-pointer call whose last operation is a kernel (the bounce buffer, mapped caller memory)
+    learns that it is done from a sequence number a one-thread kernel stores into device-mapped host memory
+    ("host_poll", capi.cpp Staging::finish) instead of from hipStreamSynchronize.  Same bits either way and on
+    both sides of the bounce limit; the counter tells which wait ended the call."""
+    import ctypes as C
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    try:
+        for n, bits in ((4096, 49), (16384, 54), (65536, 54)):
+            q = ho.generate_primes(1, bits, True, n)[0]
+            ntt, ont = hx.NTT(n, q), ho.NTT(n, q)
+            x = ho.fill_splitmix(n, 31 + n, q)
+            want = ont.forward(x, 1, 1)
+            for poll, kb in ((1, 512), (0, 512), (1, 64), (1, 0)):
+                hx.set_tuning("host_poll", poll)
+                hx.set_tuning("host_bounce_kb", kb)
+                bounced = n * 8 <= kb << 10
+                before = hx.get_counter("host_polls")
+                dst = np.zeros_like(x)
+                for _ in range(3):
+                    assert hx.lib.hexl_amd_ntt_forward_host(ntt._h, p(dst), p(x), 1, 1, 1) == 0
+                    assert np.array_equal(dst, want)
+                a = x.copy()
+                assert hx.lib.hexl_amd_eltwise_host(4, p(a), p(a), p(want), 0, n, q, 1, 1) == 0
+                assert np.array_equal(a, ho.eltwise_mult_mod(x, want, q, 1))
+                polled = hx.get_counter("host_polls") - before
+                assert polled == (4 if poll and bounced else 0), (n, poll, kb, polled)
+        assert hx.get_counter("host_poll_timeouts") == 0
+    finally:
+        hx.set_tuning("host_poll", 1)
+        hx.set_tuning("host_bounce_kb", 512)
 
 
 @pytest.mark.parametrize("threads", [1, 6])

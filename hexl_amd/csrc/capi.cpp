@@ -228,7 +228,9 @@ struct Staging {
   int finish(hipStream_t st) {
     if (st != nullptr && st == stream && g_host_poll.load(std::memory_order_relaxed) != 0) {
       if (!done) {
-        HX_HIP(hipHostMalloc((void**)&done, 64, hipHostMallocMapped | hipHostMallocPortable));
+        // (explicitly fine-grained: the store must reach the host without waiting for a cache write-back)
+        HX_HIP(hipHostMalloc((void**)&done, 64,
+                             hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent));
         *done = 0;
         HX_HIP(hipHostGetDevicePointer((void**)&done_dev, done, 0));
       }

@@ -1288,9 +1288,9 @@ static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t*
   if (scope.err != hipSuccess) return hip_fail(scope.err, "hipSetDevice");
   const size_t poly_bytes = (size_t)p->n * sizeof(u64);
   const size_t bytes = (size_t)batch * poly_bytes;
-  auto run = [&](u64* d, u64 polys, hipStream_t st) {
-    return forward ? ntt_forward_launch(p->t, d, d, polys, out_mf, st)
-                   : ntt_inverse_launch(p->t, d, d, polys, out_mf, st);
+  auto run = [&](u64* d, u64 polys, hipStream_t st, u64* mid = nullptr) {
+    return forward ? ntt_forward_launch(p->t, d, d, polys, out_mf, st, mid)
+                   : ntt_inverse_launch(p->t, d, d, polys, out_mf, st, mid);
   };
   // Caller memory the kernels can address (pinned and mapped: hexl_amd_host_alloc /
   // hexl_amd_host_register, the intel::hexl allocator built on them): a one-kernel transform
@@ -1311,15 +1311,24 @@ static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t*
   if (op_kind == 2) {
     if (int rc = g_staging.ensure(p->device, 8)) return rc;  // (the stream)
     hipStream_t st = g_staging.stream;
-    auto launch = [&](u64* dst) {
-      return forward ? ntt_forward_launch(p->t, dst, (const u64*)op_dev, batch, out_mf, st)
-                     : ntt_inverse_launch(p->t, dst, (const u64*)op_dev, batch, out_mf, st);
+    auto launch = [&](u64* dst, u64* mid = nullptr) {
+      return forward ? ntt_forward_launch(p->t, dst, (const u64*)op_dev, batch, out_mf, st, mid)
+                     : ntt_inverse_launch(p->t, dst, (const u64*)op_dev, batch, out_mf, st, mid);
     };
-    // (a two-pass transform of a small call likewise runs both passes on the caller's mapped memory, as
-    // it does on the bounce buffer below: N = 16384 one polynomial 32 -> 23 us against pass 1 into a
-    // device buffer and a copy back)
-    if (res_kind == 2 && (ntt_is_single_kernel(p->t, batch) || (bytes <= host_bounce_max_bytes() && same_or_disjoint))) {
+    if (res_kind == 2 && ntt_is_single_kernel(p->t, batch, true)) {
       hipError_t e = launch((u64*)res_dev);
+      if (e != hipSuccess) return hip_fail(e, "NTT launch");
+      if (int rc = g_staging.finish(st)) return rc;
+      return HEXL_AMD_OK;
+    }
+    if (res_kind == 2 && ntt_is_two_pass(p->t, batch, true)) {
+      // Two passes, both buffers mapped: the first pass reads the operand over the link and hands over
+      // in a DEVICE buffer, the second reads that and writes the result over the link -- every word
+      // crosses the link once per direction, no copy (round 6; before: pass 1 into the device buffer,
+      // pass 2 there, a D2H copy -- or, for small calls, both passes in place over the link:
+      // N = 16384 one polynomial 21.1 us, N = 65536 48.6)
+      if (int rc = g_staging.ensure(p->device, bytes)) return rc;
+      hipError_t e = launch((u64*)res_dev, (u64*)g_staging.buf);
       if (e != hipSuccess) return hip_fail(e, "NTT launch");
       if (int rc = g_staging.finish(st)) return rc;
       return HEXL_AMD_OK;
@@ -1336,11 +1345,14 @@ static int ntt_run_host(const hexl_amd_ntt* p, uint64_t* result, const uint64_t*
       op_range.first != 1 && res_range.first != 1) {
     // ordinary host memory, small call: the kernels (one or two passes) run in place on the
     // mapped bounce buffer
-    if (int rc = g_staging.ensure(p->device, 8)) return rc;  // (the stream)
+    // (a two-pass transform hands over between its passes in device memory: the words cross the link
+    // once per direction)
+    const bool two_pass = ntt_is_two_pass(p->t, batch, true);
+    if (int rc = g_staging.ensure(p->device, two_pass ? bytes : 8)) return rc;  // (the stream)
     if (int rc = g_staging.ensure_bounce(bytes)) return rc;
     hipStream_t st = g_staging.stream;
     memcpy(g_staging.bounce, operand, bytes);
-    hipError_t e = run((u64*)g_staging.bounce_dev, batch, st);
+    hipError_t e = run((u64*)g_staging.bounce_dev, batch, st, two_pass ? (u64*)g_staging.buf : nullptr);
     if (e != hipSuccess) return hip_fail(e, "NTT launch");
     if (int rc = g_staging.finish(st)) return rc;
     memcpy(result, g_staging.bounce, bytes);

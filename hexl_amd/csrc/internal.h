@@ -139,15 +139,22 @@ hipError_t ntt_multi_launch(bool forward, const struct NttTables* const* tabs, u
                             const MultiMap& map, u64 polys, u64* result, const u64* operand,
                             u64 out_mf, hipStream_t st, const KsEpilogue* epi = nullptr);
 
+// `mid` (optional, batch polynomials of device memory): where the first pass of a two-pass plan hands
+// over to the second instead of `result` -- for result / operand in host memory across the link.
 hipError_t ntt_forward_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
-                              u64 out_mf, hipStream_t st);
+                              u64 out_mf, hipStream_t st, u64* mid = nullptr);
 hipError_t ntt_inverse_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
-                              u64 out_mf, hipStream_t st);
+                              u64 out_mf, hipStream_t st, u64* mid = nullptr);
 
 // Whether a transform of `batch` polynomials under plan `t` is ONE kernel launch (degrees up
 // to 2^12, 2^13, and 2^14 from 96 polynomials): what the zero-copy host path can run straight
 // on caller memory.
-bool ntt_is_single_kernel(const NttTables& t, u64 batch);
+// (`link`: the buffers are host memory across the link and a `mid` buffer will be passed if the plan has
+// two passes -- the plan may differ: see link_allows_tile13)
+bool ntt_is_single_kernel(const NttTables& t, u64 batch, bool link = false);
+// ... or two (one strided pass + the tile pass: N = 2^15 ... 2^19, N = 2^14 below 96 polynomials): the
+// shape for which ntt_forward_launch / ntt_inverse_launch use `mid`.
+bool ntt_is_two_pass(const NttTables& t, u64 batch, bool link = false);
 
 // Tuning / diagnostic knobs of the NTT launch logic (ntt_kernels.hip); 0 on success.
 int set_tuning(const char* key, u64 value);

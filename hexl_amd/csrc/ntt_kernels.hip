@@ -1805,6 +1805,16 @@ static Plan make_plan(int L, bool allow_tile13 = true, u64 batch = ~0ull) {
   }
 }
 
+// Buffers across the link (`mid` given: the *_host paths): one, two or three polynomials of N = 8192 keep
+// the two-pass shape -- the one-kernel plan is ONE workgroup per polynomial, whose 64 KiB come over the
+// link as one CU's outstanding requests; two passes spread a polynomial over 16 + 4 workgroups
+// (one polynomial per synchronous host call: 24.1 -> 20.4 us, two 27.2 -> 25.7, four 36.5 either way, round 6;
+// on device memory the one-kernel plan wins at every batch: 9.2 against 12 us per dependent call)
+constexpr u64 kLinkTile13MinBatch = 4;
+[[maybe_unused]] static bool link_allows_tile13(u32 log_n, u64 batch, bool link) {
+  return !(link && log_n == 13 && batch < kLinkTile13MinBatch);
+}
+
 template <bool FWD, class A>
 static hipError_t launch_bottom_tl(int tl, int S, u64* out, const u64* in, const ulonglong2* tw,
                                    const ModConst& m, u32 log_n, u32 finish, u64 batch,
@@ -1826,7 +1836,12 @@ static hipError_t launch_bottom_tl(int tl, int S, u64* out, const u64* in, const
 template <class A>
 static hipError_t forward_seq(const NttTables& t, const Plan& p, u64* result, const u64* operand,
                               u64 batch, u64 out_mf, hipStream_t st,
-                              const MultiCtx* mc = nullptr, const KsEpilogue* epi = nullptr) {
+                              const MultiCtx* mc = nullptr, const KsEpilogue* epi = nullptr,
+                              u64* mid = nullptr) {
+  // `mid` (two-pass plans only): where the first pass hands over to the second instead of `result`
+  // -- a device buffer when result and operand are host memory across the link (capi.cpp: the
+  // bounce buffer, mapped caller memory), so each polynomial crosses the link once per direction
+  u64* const hand = (mid && p.n_strided == 1) ? mid : result;
   const u64* src = operand;
   InvLast il{};
   hipError_t e;
@@ -1851,11 +1866,11 @@ static hipError_t forward_seq(const NttTables& t, const Plan& p, u64* result, co
     return mask << kStageMaskShift;
   };
   for (int i = 0; i < p.n_strided; ++i) {
-    e = launch_strided<true, A>(p.strided[i], result, src, t.fwd, t.mod, t.log_n, a0,
+    e = launch_strided<true, A>(p.strided[i], hand, src, t.fwd, t.mod, t.log_n, a0,
                                 first | stage_mask(p.strided[i]), batch, il, st, mc);
     if (e != hipSuccess) return e;
     a0 += p.strided[i];
-    src = result;
+    src = hand;
     first = 0;
   }
   const u32 fin = out_mf == 1 ? 2 : 1;
@@ -1866,17 +1881,18 @@ static hipError_t forward_seq(const NttTables& t, const Plan& p, u64* result, co
 template <class A>
 static hipError_t inverse_seq(const NttTables& t, const Plan& p, u64* result, const u64* operand,
                               u64 batch, u64 out_mf, hipStream_t st,
-                              const MultiCtx* mc = nullptr) {
+                              const MultiCtx* mc = nullptr, u64* mid = nullptr) {
   const u32 fin = out_mf == 1 ? 2 : 1;
   const bool only = p.n_strided == 0;
-  hipError_t e = launch_bottom_tl<false, A>(p.tl, p.bottom, result, operand, t.inv, t.mod, t.log_n,
+  u64* const hand = (mid && p.n_strided == 1) ? mid : result;  // (see forward_seq)
+  hipError_t e = launch_bottom_tl<false, A>(p.tl, p.bottom, hand, operand, t.inv, t.mod, t.log_n,
                                             kFirstPass | (only ? fin : 0), batch, t.inv_last, st,
                                             mc);
   if (e != hipSuccess) return e;
   u32 a0 = t.log_n - (u32)p.bottom;
   for (int i = p.n_strided - 1; i >= 0; --i) {
     a0 -= p.strided[i];
-    e = launch_strided<false, A>(p.strided[i], result, result, t.inv, t.mod, t.log_n, a0,
+    e = launch_strided<false, A>(p.strided[i], result, hand, t.inv, t.mod, t.log_n, a0,
                                  i == 0 ? fin : 0, batch, t.inv_last, st, mc);
     if (e != hipSuccess) return e;
   }
@@ -1890,10 +1906,10 @@ static hipError_t inverse_seq(const NttTables& t, const Plan& p, u64* result, co
 // exactly the time it gains: 3.64 ms per step against 3.57 ms back to back.)
 template <bool FWD, class A>
 static hipError_t transform_impl(const NttTables& t, u64* result, const u64* operand, u64 batch,
-                                 u64 out_mf, hipStream_t st) {
-  const Plan p = make_plan((int)t.log_n, true, batch);
-  return FWD ? forward_seq<A>(t, p, result, operand, batch, out_mf, st)
-             : inverse_seq<A>(t, p, result, operand, batch, out_mf, st);
+                                 u64 out_mf, hipStream_t st, u64* mid) {
+  const Plan p = make_plan((int)t.log_n, link_allows_tile13(t.log_n, batch, mid != nullptr), batch);
+  return FWD ? forward_seq<A>(t, p, result, operand, batch, out_mf, st, nullptr, nullptr, mid)
+             : inverse_seq<A>(t, p, result, operand, batch, out_mf, st, nullptr, mid);
 }
 
 template <class A>
@@ -1909,7 +1925,8 @@ static hipError_t multi_impl(bool forward, const NttTables& t0, const MultiCtx& 
 // Entry points of one arithmetic policy (see "Translation units" at the top).
 #define HX_POLICY_ENTRY_DECL(NAME)                                                              \
   hipError_t transform_entry_##NAME(bool forward, const NttTables& t, u64* result,              \
-                                    const u64* operand, u64 batch, u64 out_mf, hipStream_t st); \
+                                    const u64* operand, u64 batch, u64 out_mf, hipStream_t st,  \
+                                    u64* mid);                                                  \
   hipError_t multi_entry_##NAME(bool forward, const NttTables& t0, const MultiCtx& mc, u64 polys, \
                                 u64* result, const u64* operand, u64 out_mf, hipStream_t st,    \
                                 const KsEpilogue* epi);
@@ -1925,9 +1942,10 @@ HX_POLICY_ENTRY_DECL(fp64l)
 
 #define HX_POLICY_ENTRY_DEF(NAME, A)                                                            \
   hipError_t transform_entry_##NAME(bool forward, const NttTables& t, u64* result,              \
-                                    const u64* operand, u64 batch, u64 out_mf, hipStream_t st) { \
-    return forward ? transform_impl<true, A>(t, result, operand, batch, out_mf, st)             \
-                   : transform_impl<false, A>(t, result, operand, batch, out_mf, st);           \
+                                    const u64* operand, u64 batch, u64 out_mf, hipStream_t st,  \
+                                    u64* mid) {                                                 \
+    return forward ? transform_impl<true, A>(t, result, operand, batch, out_mf, st, mid)        \
+                   : transform_impl<false, A>(t, result, operand, batch, out_mf, st, mid);      \
   }                                                                                             \
   hipError_t multi_entry_##NAME(bool forward, const NttTables& t0, const MultiCtx& mc, u64 polys, \
                                 u64* result, const u64* operand, u64 out_mf, hipStream_t st,    \
@@ -1965,34 +1983,40 @@ static_assert(kPolicySmall == 0 && kPolicyFp64 == 1 && kPolicyLazy == 2 && kPoli
 
 #if HX_TU_DISPATCH
 static hipError_t transform_dispatch(bool forward, const NttTables& t, u64* result,
-                                     const u64* operand, u64 batch, u64 out_mf, hipStream_t st) {
+                                     const u64* operand, u64 batch, u64 out_mf, hipStream_t st,
+                                     u64* mid) {
   if (batch == 0) return hipSuccess;
   switch (t.policy) {
-    case kPolicySmall: return transform_entry_small(forward, t, result, operand, batch, out_mf, st);
-    case kPolicyFp64: return transform_entry_fp64(forward, t, result, operand, batch, out_mf, st);
-    case kPolicyLazy: return transform_entry_lazy(forward, t, result, operand, batch, out_mf, st);
+    case kPolicySmall: return transform_entry_small(forward, t, result, operand, batch, out_mf, st, mid);
+    case kPolicyFp64: return transform_entry_fp64(forward, t, result, operand, batch, out_mf, st, mid);
+    case kPolicyLazy: return transform_entry_lazy(forward, t, result, operand, batch, out_mf, st, mid);
     case kPolicyHarvey60:
-      return transform_entry_harvey60(forward, t, result, operand, batch, out_mf, st);
-    case kPolicyLazy32: return transform_entry_lazy32(forward, t, result, operand, batch, out_mf, st);
-    case kPolicyLazy16: return transform_entry_lazy16(forward, t, result, operand, batch, out_mf, st);
-    case kPolicyFp64L: return transform_entry_fp64l(forward, t, result, operand, batch, out_mf, st);
-    default: return transform_entry_strict(forward, t, result, operand, batch, out_mf, st);
+      return transform_entry_harvey60(forward, t, result, operand, batch, out_mf, st, mid);
+    case kPolicyLazy32: return transform_entry_lazy32(forward, t, result, operand, batch, out_mf, st, mid);
+    case kPolicyLazy16: return transform_entry_lazy16(forward, t, result, operand, batch, out_mf, st, mid);
+    case kPolicyFp64L: return transform_entry_fp64l(forward, t, result, operand, batch, out_mf, st, mid);
+    default: return transform_entry_strict(forward, t, result, operand, batch, out_mf, st, mid);
   }
 }
 
 hipError_t ntt_forward_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
-                              u64 out_mf, hipStream_t st) {
-  return transform_dispatch(true, t, result, operand, batch, out_mf, st);
+                              u64 out_mf, hipStream_t st, u64* mid) {
+  return transform_dispatch(true, t, result, operand, batch, out_mf, st, mid);
 }
 
 hipError_t ntt_inverse_launch(const NttTables& t, u64* result, const u64* operand, u64 batch,
-                              u64 out_mf, hipStream_t st) {
-  return transform_dispatch(false, t, result, operand, batch, out_mf, st);
+                              u64 out_mf, hipStream_t st, u64* mid) {
+  return transform_dispatch(false, t, result, operand, batch, out_mf, st, mid);
 }
 
-bool ntt_is_single_kernel(const NttTables& t, u64 batch) {
-  const Plan p = make_plan((int)t.log_n, true, batch);
+bool ntt_is_single_kernel(const NttTables& t, u64 batch, bool link) {
+  const Plan p = make_plan((int)t.log_n, link_allows_tile13(t.log_n, batch, link), batch);
   return p.n_strided == 0;
+}
+
+bool ntt_is_two_pass(const NttTables& t, u64 batch, bool link) {
+  const Plan p = make_plan((int)t.log_n, link_allows_tile13(t.log_n, batch, link), batch);
+  return p.n_strided == 1;
 }
 #endif  // HX_TU_DISPATCH
 

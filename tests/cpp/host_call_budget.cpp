@@ -153,5 +153,6 @@ int main(int argc, char** argv) {
   budget(8192, 54, iters);
   budget(16384, 54, iters);
   budget(65536, 54, iters / 2);
+  if (argc >= 4) budget(131072, 54, iters / 2);  // (any fourth argument: the first degree beyond the bounce limit)
   return 0;
 }

@@ -398,7 +398,7 @@ def test_pointer_kinds_and_zero_copy_host_path(hx, ho):
     plain = np.zeros(8, dtype=np.uint64)
     assert lib.hexl_amd_pointer_kind(plain.ctypes.data_as(C.c_void_p)) == 0
     assert lib.hexl_amd_pointer_kind(C.c_void_p(dev(hx, plain).data_ptr())) == 1
-    for n, bits in ((4096, 49), (8192, 54), (65536, 54)):
+    for n, bits in ((4096, 49), (8192, 54), (16384, 49), (65536, 54), (131072, 60)):
         q = ho.generate_primes(1, bits, True, n)[0]
         ntt, ont = hx.NTT(n, q), ho.NTT(n, q)
         x = ho.fill_splitmix(n, 5 + n, q)
@@ -492,11 +492,14 @@ def test_short_lived_registration_then_large_pageable_copies(hx, ho):
 
 
 @pytest.mark.parametrize("n,batch,bits", [(4096, 1, 49), (4096, 8, 54), (16384, 2, 54), (16384, 3, 54),
-                                          (32768, 1, 54), (65536, 1, 54), (1024, 1, 35), (64, 3, 40)])
+                                          (32768, 1, 54), (65536, 1, 54), (1024, 1, 35), (64, 3, 40),
+                                          (8192, 1, 54), (8192, 3, 60), (8192, 4, 49), (8192, 5, 28),
+                                          (16384, 1, 49), (32768, 2, 60)])
 def test_host_pointer_paths_on_ordinary_memory(hx, ho, n, batch, bits):
     """The *_host entry points on ordinary (pageable) host memory, both sides of the 512 KiB
-    bounce-buffer threshold -- one-kernel and two-pass plans in place on the pinned mapped bounce
-    buffer below it, staged H2D / D2H above -- in place and out of place, against the oracle."""
+    bounce-buffer threshold -- one-kernel plans in place on the pinned mapped bounce buffer, two-pass plans
+    handing over between their passes in device memory (N = 8192 below four polynomials takes the two-pass
+    shape there, round 6), staged H2D / D2H above the threshold -- in place and out of place, against the oracle."""
     import ctypes as C
     q = ho.generate_primes(1, bits, True, n)[0]
     ntt, ont = hx.NTT(n, q), ho.NTT(n, q)

@@ -100,6 +100,81 @@ def test_fuzz_ntt(hx, ho, idx):
         assert np.array_equal(hx.to_numpy(src).reshape(batch, n), x), tag
 
 
+_MAPPED = {}
+
+
+def _mapped_words(hx, words):
+    """A pinned, device-mapped region of at least `words` uint64 (hexl_amd_host_alloc), kept for the
+    module: (numpy view, base address)."""
+    import ctypes as C
+    if _MAPPED.get("words", 0) < words:
+        if "ptr" in _MAPPED:
+            assert hx.lib.hexl_amd_host_free(_MAPPED["ptr"]) == 0
+        pm = C.c_void_p()
+        assert hx.lib.hexl_amd_host_alloc(C.byref(pm), words * 8) == 0
+        _MAPPED.update(ptr=pm, words=words,
+                       view=np.ctypeslib.as_array(C.cast(pm, C.POINTER(C.c_uint64)), shape=(words,)))
+    return _MAPPED["view"], _MAPPED["ptr"].value
+
+
+@pytest.mark.parametrize("idx", range(CASES))
+def test_fuzz_ntt_host_pointers(hx, ho, idx):
+    """The *_host entry points (what intel::hexl::NTT binds for caller memory) on random draws: ordinary or
+    pinned device-mapped buffers, in place / out of place, both directions, every legal factor pair, batches
+    on both sides of the bounce limit and of the plan thresholds across the link (N = 8192 below four
+    polynomials, N = 16384 below 96), the completion flag polled or the stream synchronised -- against the oracle."""
+    import ctypes as C
+    rng = random.Random(SEED * 104729 + idx)
+    logn = rng.choice([2, 6, 10, 11, 12, 12, 13, 13, 13, 14, 14, 14, 15, 16, 16, 17])
+    n = 1 << logn
+    q = draw_prime(ho, rng, logn)
+    batch = min(rng.choice([1, 1, 1, 2, 3, 4, 5, 8, 17, 95, 96, 97]), max(1, (MAX_ELEMS // 2) // n))
+    forward = rng.random() < 0.5
+    in_mf, out_mf = rng.choice([(1, 1), (2, 1), (4, 1), (1, 4), (2, 4), (4, 4)] if forward
+                               else [(1, 1), (2, 1), (1, 2), (2, 2)])
+    inplace = rng.random() < 0.5
+    mapped = rng.random() < 0.5
+    poll = rng.choice([1, 1, 0])
+    bounce_kb = rng.choice([512, 512, 64, 0, 2048])
+    tag = dict(idx=idx, n=n, q=q, batch=batch, fwd=forward, in_mf=in_mf, out_mf=out_mf, inplace=inplace,
+               mapped=mapped, poll=poll, bounce_kb=bounce_kb)
+    x = rand_u64(rng, (batch, n), in_mf * q)
+    oracle = ho.NTT(n, q)
+    exp = (oracle.forward if forward else oracle.inverse)(x, in_mf, out_mf)
+    plan = hx.NTT(n, q)
+    words = batch * n
+    if mapped:
+        view, base = _mapped_words(hx, 2 * words)
+        src = view[:words]
+        src[:] = x.reshape(-1)
+        dst = src if inplace else view[words:2 * words]
+        p_src = C.c_void_p(base)
+        p_dst = p_src if inplace else C.c_void_p(base + words * 8)
+    else:
+        src = x.reshape(-1).copy()
+        dst = src if inplace else np.full(words, 0x5A5A5A5A, dtype=np.uint64)
+        p_src, p_dst = src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p)
+    if not inplace:
+        dst[:] = 0x5A5A5A5A
+    try:
+        hx.set_tuning("host_poll", poll)
+        hx.set_tuning("host_bounce_kb", bounce_kb)
+        fn = hx.lib.hexl_amd_ntt_forward_host if forward else hx.lib.hexl_amd_ntt_inverse_host
+        assert fn(plan._h, p_dst, p_src, batch, in_mf, out_mf) == 0, tag
+    finally:
+        hx.set_tuning("host_poll", 1)
+        hx.set_tuning("host_bounce_kb", 512)
+    got = np.array(dst, copy=True).reshape(batch, n)
+    if out_mf == 1:
+        assert np.array_equal(got, exp), tag
+    else:
+        assert (got < np.uint64(out_mf * q)).all(), tag
+        assert np.array_equal(got % np.uint64(q), exp % np.uint64(q)), tag
+    if not inplace:
+        assert np.array_equal(np.array(src).reshape(batch, n), x), tag
+    assert hx.get_counter("host_poll_timeouts") == 0, tag
+
+
 @pytest.mark.parametrize("idx", range(CASES))
 def test_fuzz_ntt_rns(hx, ho, idx):
     """Several moduli in one call (the multi-plan launches), mixed policies allowed."""

@@ -8,12 +8,15 @@ set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-$REPO/gpurun_out/pmc_cells}
 ONLY=${2:-}
-rm -rf "$OUT"; mkdir -p "$OUT"
+# TRACE_ONLY=1: only the duration pass, into an existing OUT (the counter passes there are kept)
+if [ -n "${TRACE_ONLY:-}" ]; then rm -rf "$OUT/trace"; else rm -rf "$OUT"; fi
+mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 CMD=(python $REPO/tools/pmc_cells.py --reps 3)
 [ -n "$ONLY" ] && CMD+=(--only "$ONLY")
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- \
-  "${CMD[@]}" --reps 6 > $OUT/manifest.json 2> $OUT/trace.log
+  "${CMD[@]}" --reps 6 --warm-ms 80 > $OUT/manifest.json 2> $OUT/trace.log
+[ -n "${TRACE_ONLY:-}" ] && { find $OUT -name '*.db' -delete 2>/dev/null; du -sh $OUT; exit 0; }
 run_pmc() {  # name, counters...
   local name=$1; shift
   timeout 600 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -o p -- "${CMD[@]}" > /dev/null 2> $OUT/$name.log

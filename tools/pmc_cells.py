@@ -17,7 +17,7 @@ groups counters by (cell, kernel name, grid size).  Prints a JSON manifest (the 
 per launch) on stdout; `--list` prints it without touching the GPU.  No oracle, no checks: the
 parity tests are tests/test_gpu_parity.py.
 
-    python tools/pmc_cells.py [--reps 3] [--only REGEX] > manifest.json
+    python tools/pmc_cells.py [--reps 3] [--warm-ms 0] [--only REGEX] > manifest.json
 """
 import argparse
 import json
@@ -84,12 +84,27 @@ def all_cells():
     return ntt_cells() + eltwise_cells() + composite_cells()
 
 
-def run(cells, reps):
+def run(cells, reps, warm_ms=0.0):
+    import time
+
     import numpy as np
     import torch
 
     import hexl_amd as hx
     rng = np.random.default_rng(1)
+
+    def burst(fn):
+        """`reps` launches of fn, behind warm_ms of the same call (the duration pass: a burst that starts from
+        an idle GPU runs its first milliseconds above the sustained clock and the next ones below it while the
+        power controller settles; the summariser's median then sits in the steady state)"""
+        t0, calls = time.perf_counter(), 0
+        while (time.perf_counter() - t0) * 1e3 < warm_ms and calls < 400:  # (the trace stays small)
+            for _ in range(4):
+                fn()
+            calls += 4
+            torch.cuda.synchronize()
+        for _ in range(reps):
+            fn()
 
     marker = torch.zeros(512 * (len(cells) + 1), dtype=torch.int64, device="cuda")
     for index, c in enumerate(cells):
@@ -104,10 +119,8 @@ def run(cells, reps):
             x = torch.empty((batch, n), dtype=torch.int64, device="cuda")
             ntt = hx.NTT(n, q)
             hx.fill_splitmix(x, n, batch, 1, q)
-            for _ in range(reps):
-                ntt.ComputeForward(x, x, 1, 1)
-            for _ in range(reps):
-                ntt.ComputeInverse(x, x, 1, 1)
+            burst(lambda: ntt.ComputeForward(x, x, 1, 1))
+            burst(lambda: ntt.ComputeInverse(x, x, 1, 1))
             torch.cuda.synchronize()
             c["q"] = int(q)
             del x
@@ -121,19 +134,12 @@ def run(cells, reps):
             hx.fill_splitmix(a, n, 1, 11, bound)
             hx.fill_splitmix(b, n, 1, 911, bound)
             s = 3 * q + 12345
-            for _ in range(reps):
-                if c["op"] == "mult":
-                    hx.EltwiseMultMod(r, a, b, n, q, 1)
-                elif c["op"] == "fma":
-                    hx.EltwiseFMAMod(r, a, s, b, n, q, 4)
-                elif c["op"] == "reduce":
-                    hx.EltwiseReduceMod(r, a, n, q, q, 1)
-                elif c["op"] == "reduce41":
-                    hx.EltwiseReduceMod(r, a, n, q, 4, 1)
-                elif c["op"] == "reducefma":
-                    hx.EltwiseReduceFMAMod(r, a, s % q, b, n, q, q)
-                elif c["op"] == "add":
-                    hx.EltwiseAddMod(r, a, b, n, q)
+            burst({"mult": lambda: hx.EltwiseMultMod(r, a, b, n, q, 1),
+                   "fma": lambda: hx.EltwiseFMAMod(r, a, s, b, n, q, 4),
+                   "reduce": lambda: hx.EltwiseReduceMod(r, a, n, q, q, 1),
+                   "reduce41": lambda: hx.EltwiseReduceMod(r, a, n, q, 4, 1),
+                   "reducefma": lambda: hx.EltwiseReduceFMAMod(r, a, s % q, b, n, q, q),
+                   "add": lambda: hx.EltwiseAddMod(r, a, b, n, q)}[c["op"]])
             torch.cuda.synchronize()
             c["q"] = int(q)
             del a, b, r
@@ -144,8 +150,7 @@ def run(cells, reps):
             y = np.concatenate([rng.integers(0, q, n, dtype=np.uint64) for q in moduli] * 2)
             dx, dy = hx.from_numpy(x), hx.from_numpy(y)
             out = hx.from_numpy(np.zeros(3 * n * k, dtype=np.uint64))
-            for _ in range(reps):
-                hx.DyadicMultiply(out, dx, dy, n, moduli)
+            burst(lambda: hx.DyadicMultiply(out, dx, dy, n, moduli))
             torch.cuda.synchronize()
         elif c["kind"] == "keyswitch":
             n, D, T = c["n"], c["D"], c["T"]
@@ -160,8 +165,7 @@ def run(cells, reps):
             d_keys = [hx.from_numpy(kk) for kk in keys]
             d_tt = hx.from_numpy(np.tile(target, T))
             d_rr = hx.from_numpy(np.tile(result, T))
-            for _ in range(reps):
-                hx.KeySwitchBatch(d_rr, d_tt, T, n, D, K, D + 1, C, moduli, d_keys, msf)
+            burst(lambda: hx.KeySwitchBatch(d_rr, d_tt, T, n, D, K, D + 1, C, moduli, d_keys, msf))
             torch.cuda.synchronize()
             # algorithmic bytes of the whole call: targets in (D polys) + result in and out
             # (C * D polys each) per target; keys D * C * K polys once (shared by the targets)
@@ -173,6 +177,7 @@ def run(cells, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--warm-ms", type=float, default=0.0)
     ap.add_argument("--only", default=None)
     ap.add_argument("--list", action="store_true")
     a = ap.parse_args()
@@ -180,8 +185,8 @@ def main():
     if a.only:
         cells = [c for c in cells if re.search(a.only, c["label"])]
     if not a.list:
-        run(cells, a.reps)
-    json.dump({"reps": a.reps, "cells": cells}, sys.stdout, indent=1)
+        run(cells, a.reps, a.warm_ms)
+    json.dump({"reps": a.reps, "warm_ms": a.warm_ms, "cells": cells}, sys.stdout, indent=1)
     print()
 
 

@@ -62,7 +62,7 @@ def trace():
             out[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
             meta[k] = {"workgroup": int(r["Workgroup_Size_X"]), "lds_bytes": int(r["LDS_Block_Size"]),
                        "scratch": int(r["Scratch_Size"])}
-    # median of the launches (the first of a burst starts from an idle clock)
+    # median of the launches (a warm-up burst of the same call precedes the measured ones: pmc_cells.py --warm-ms)
     return {k: sorted(v)[len(v) // 2] for k, v in out.items()}, meta
 
 
@@ -181,8 +181,8 @@ def main():
            "`tools/collect_pmc_cells.sh` (one `rocprofv3 --kernel-trace --stats` pass for the durations, then",
            "FETCH_SIZE, WRITE_SIZE, two SQ sets and the LDS set each in its own `--pmc` pass over",
            "`python tools/pmc_cells.py`), summarised by `tools/summarize_pmc_cells.py`. Durations are medians of the",
-           "traced run's launches (6 per kernel, no warm-up burst: a few per cent above the sustained figures of",
-           "`tools/size_sweep.py`). `frac` = algorithmic bytes / duration / 8 TB/s; `traffic` = (2·FETCH_SIZE +",
+           "traced run's launches (80 ms of the same call, then 6: the steady state, as `tools/size_sweep.py` measures it;",
+           "the counter passes run 3 launches from a cold start -- their `GHz` column is the clock of THOSE launches). `frac` = algorithmic bytes / duration / 8 TB/s; `traffic` = (2·FETCH_SIZE +",
            "WRITE_SIZE)·1024 / algorithmic bytes; VALU busy = SQ_ACTIVE_INST_VALU·4 / (1024 SIMDs · GRBM_GUI_ACTIVE/8);",
            "`wait` = SQ_WAIT_ANY / SQ_WAVE_CYCLES (waves parked at s_waitcnt or a barrier), `stall` = SQ_WAIT_INST_ANY /",
            "SQ_WAVE_CYCLES (issue stalls), `LDS stall` = SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES; `conflict` =",

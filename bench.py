@@ -593,6 +593,8 @@ def composites(hx):
     ks["one_target_per_call_path"] = (f"graph replay ({replays} of 34 calls)" if replays >= 30
                                       else f"launch by launch ({replays} replays)")
     ks["host_enqueue_us_per_call"] = {"eager": host_eager * 1e6, "replay": host_replay * 1e6}
+    # the same call from C++ (tests/cpp/ks_call_cost.cpp: no interpreter between the calls)
+    ks["from_cpp"] = guarded("ks_call_cost", lambda: run_ks_call_cost(n, D))
     hx.lib.hexl_amd_release_stream_workspaces(side.cuda_stream)
     # Floors for one target: (a) its transforms alone at the batched per-transform rate of this
     # degree -- D inverse (targets to coefficient form) + D^2 forward (operands) + C inverse (last
@@ -642,6 +644,21 @@ def composites(hx):
 
 
 HOST_CALL_BUDGET_BIN = os.path.join(ROOT, "tests", "cpp", "host_call_budget")
+KS_CALL_COST_BIN = os.path.join(ROOT, "tests", "cpp", "ks_call_cost")
+
+
+def run_ks_call_cost(n, D):
+    import subprocess
+    if not os.path.exists(KS_CALL_COST_BIN):
+        raise SystemExit(f"{KS_CALL_COST_BIN} is missing: python -c 'import __graft_entry__ as g; g.build()'")
+    r = subprocess.run([KS_CALL_COST_BIN, str(n), str(D)], capture_output=True, text=True, timeout=120)
+    rows = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")]
+    if r.returncode != 0 or not rows:
+        raise SystemExit(f"ks_call_cost failed (rc {r.returncode}): {r.stderr[-300:]}")
+    return {("replayed" if row["ks_graph"] else "launch_by_launch") + (", walking over 8 ciphertexts"
+            if row["buffers"].startswith("walking") else ", one ciphertext"):
+            {"wall_us_per_call": row["wall_us_per_call"], "host_enqueue_us": row["host_enqueue_us"],
+             "call_and_wait_us": row["call_and_wait_us"]} for row in rows}
 
 
 def free_port():

@@ -307,6 +307,8 @@ def secondary_configs(hx, torch):
         "multmod": rate(24.0 * n * b,
                         event_timed(torch, lambda: hx.EltwiseMultMod(y, x, x, n * b, q, 1), 200)),
     }
+    # the same calls from C++ (tests/cpp/eager_rate.cpp): no interpreter between the launches
+    out["config2"]["from_cpp"] = guarded("eager_rate", lambda: run_eager_rate(n, b))
     # the same calls replayed from a captured HIP graph of 32 back-to-back launches: what a
     # caller that batches its launches sees (the C-ABI launches are stream-ordered and
     # allocation-free, hence capturable); benchmark/bench-ntt.cpp:212-239 is the reference's
@@ -645,6 +647,23 @@ def composites(hx):
 
 HOST_CALL_BUDGET_BIN = os.path.join(ROOT, "tests", "cpp", "host_call_budget")
 KS_CALL_COST_BIN = os.path.join(ROOT, "tests", "cpp", "ks_call_cost")
+
+
+EAGER_RATE_BIN = os.path.join(ROOT, "tests", "cpp", "eager_rate")
+
+
+def run_eager_rate(n, b):
+    import subprocess
+    if not os.path.exists(EAGER_RATE_BIN):
+        raise SystemExit(f"{EAGER_RATE_BIN} is missing: python -c 'import __graft_entry__ as g; g.build()'")
+    r = subprocess.run([EAGER_RATE_BIN], capture_output=True, text=True, timeout=120)
+    rows = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")]
+    if r.returncode != 0 or not rows or rows[0]["n"] != n or rows[0]["batch"] != b:
+        raise SystemExit(f"eager_rate failed (rc {r.returncode}): {r.stderr[-300:]}")
+    row = rows[0]
+    return {"timing": "calls issued back to back on one stream from C++, wall time per call over 2000 calls",
+            "fwd": rate(16.0 * n * b, row["fwd_us"] * 1e-6), "inv": rate(16.0 * n * b, row["inv_us"] * 1e-6),
+            "multmod": rate(24.0 * n * b, row["multmod_us"] * 1e-6)}
 
 
 def run_ks_call_cost(n, D):

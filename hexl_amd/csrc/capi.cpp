@@ -112,6 +112,28 @@ struct StreamDeviceScope : DeviceScope {
 std::atomic<u32> g_host_poll{1};
 // hexl_amd_get_counter: waits that the flag ended / that ran out of polling time and went to the runtime
 std::atomic<u64> g_host_polls{0}, g_host_poll_timeouts{0};
+// Polls *flag until it has reached `seq` (sequence numbers only grow: wrap-safe comparison), for at most
+// about a millisecond; false: not seen in that time (the caller then waits in the runtime).
+static bool poll_completion_flag(const u32* flag, u32 seq) {
+  timespec t0{};
+  for (u32 spins = 1;; ++spins) {
+    if ((int32_t)(__atomic_load_n(flag, __ATOMIC_ACQUIRE) - seq) >= 0) {
+      g_host_polls.fetch_add(1, std::memory_order_relaxed);
+      return true;
+    }
+    __builtin_ia32_pause();
+    if ((spins & 0x3ff) == 0) {
+      timespec t{};
+      clock_gettime(CLOCK_MONOTONIC, &t);
+      if (spins == 0x400) {
+        t0 = t;
+      } else if ((t.tv_sec - t0.tv_sec) * 1000000000ll + (t.tv_nsec - t0.tv_nsec) > 1000000) {
+        g_host_poll_timeouts.fetch_add(1, std::memory_order_relaxed);
+        return false;
+      }
+    }
+  }
+}
 
 struct Staging {
   int device = -1;
@@ -236,23 +258,7 @@ struct Staging {
       }
       const u32 seq = ++done_seq;
       if (completion_flag_launch(done_dev, seq, st) == hipSuccess) {
-        timespec t0{};
-        for (u32 spins = 1;; ++spins) {
-          if (__atomic_load_n(done, __ATOMIC_ACQUIRE) == seq) {
-            g_host_polls.fetch_add(1, std::memory_order_relaxed);
-            return HEXL_AMD_OK;
-          }
-          __builtin_ia32_pause();
-          if ((spins & 0x3ff) == 0) {
-            timespec t{};
-            clock_gettime(CLOCK_MONOTONIC, &t);
-            if (spins == 0x400) t0 = t;
-            else if ((t.tv_sec - t0.tv_sec) * 1000000000ll + (t.tv_nsec - t0.tv_nsec) > 1000000) {
-              g_host_poll_timeouts.fetch_add(1, std::memory_order_relaxed);
-              break;
-            }
-          }
-        }
+        if (poll_completion_flag(done, seq)) return HEXL_AMD_OK;
       } else {
         (void)hipGetLastError();
       }
@@ -693,6 +699,21 @@ int hexl_amd_get_device(int* device) {
   HX_HIP(hipGetDevice(device));
   return HEXL_AMD_OK;
 }
+// Streams of the library's own making (hexl_amd_stream_create): hexl_amd_synchronize learns that such a
+// stream is done the way the host-pointer calls do -- a one-thread kernel behind the work publishes a
+// sequence number in device-mapped host memory, the caller polls ("host_poll"; 3-4 us earlier than
+// hipStreamSynchronize returns).  The flag of a stream is made at its first synchronisation.
+namespace {
+struct StreamFlag {
+  std::mutex mu;  // sequence number and launch of one synchronisation: the flag only ever grows
+  u32* host = nullptr;
+  u32* dev = nullptr;
+  u32 seq = 0;
+};
+std::mutex g_stream_flags_mu;
+std::map<hipStream_t, std::shared_ptr<StreamFlag>> g_stream_flags;
+}  // namespace
+
 int hexl_amd_stream_create(void** stream, int device) {
   if (!stream) return fail(HEXL_AMD_ERR_INVALID_ARG, "stream == nullptr");
   *stream = nullptr;
@@ -701,6 +722,10 @@ int hexl_amd_stream_create(void** stream, int device) {
   if (scope.err != hipSuccess) return hip_fail(scope.err, "hipSetDevice");
   hipStream_t st = nullptr;
   HX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  {
+    std::lock_guard<std::mutex> lock(g_stream_flags_mu);
+    g_stream_flags[st] = std::make_shared<StreamFlag>();
+  }
   *stream = (void*)st;
   return HEXL_AMD_OK;
 }
@@ -709,14 +734,55 @@ int hexl_amd_stream_destroy(void* stream) {
   HX_ON_STREAM_DEVICE(stream);
   HX_HIP(hipStreamSynchronize((hipStream_t)stream));
   release_stream_workspaces((hipStream_t)stream);
+  std::shared_ptr<StreamFlag> flag;
+  {
+    std::lock_guard<std::mutex> lock(g_stream_flags_mu);
+    auto it = g_stream_flags.find((hipStream_t)stream);
+    if (it != g_stream_flags.end()) {
+      flag = it->second;
+      g_stream_flags.erase(it);
+    }
+  }
+  if (flag && flag->host) (void)hipHostFree(flag->host);
   HX_HIP(hipStreamDestroy((hipStream_t)stream));
   return HEXL_AMD_OK;
 }
 int hexl_amd_synchronize(void* stream) {
-  if (stream)
-    HX_HIP(hipStreamSynchronize((hipStream_t)stream));
-  else
+  if (!stream) {
     HX_HIP(hipDeviceSynchronize());
+    return HEXL_AMD_OK;
+  }
+  std::shared_ptr<StreamFlag> flag;
+  if (g_host_poll.load(std::memory_order_relaxed) != 0) {
+    std::lock_guard<std::mutex> lock(g_stream_flags_mu);
+    auto it = g_stream_flags.find((hipStream_t)stream);
+    if (it != g_stream_flags.end()) flag = it->second;
+  }
+  if (flag) {
+    HX_ON_STREAM_DEVICE(stream);
+    u32 seq = 0;
+    bool launched = false;
+    {
+      std::lock_guard<std::mutex> lock(flag->mu);
+      if (!flag->host) {
+        u32* h = nullptr;
+        if (hipHostMalloc((void**)&h, 64, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) ==
+            hipSuccess) {
+          *h = 0;
+          if (hipHostGetDevicePointer((void**)&flag->dev, h, 0) == hipSuccess) flag->host = h;
+          else (void)hipHostFree(h);
+        }
+        if (!flag->host) (void)hipGetLastError();
+      }
+      if (flag->host) {
+        seq = ++flag->seq;
+        launched = completion_flag_launch(flag->dev, seq, (hipStream_t)stream) == hipSuccess;
+        if (!launched) (void)hipGetLastError();
+      }
+    }
+    if (launched && poll_completion_flag(flag->host, seq)) return HEXL_AMD_OK;
+  }
+  HX_HIP(hipStreamSynchronize((hipStream_t)stream));
   return HEXL_AMD_OK;
 }
 

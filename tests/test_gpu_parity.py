@@ -684,6 +684,64 @@ def test_host_pointer_paths_above_one_mebibyte(hx, ho, direct):
         hx.set_tuning("host_direct_copy", 0)
 
 
+def test_synchronize_of_a_library_stream_polls_a_completion_flag(hx, ho):
+    """hexl_amd_synchronize on a stream from hexl_amd_stream_create learns that the stream is done from a sequence
+    number a one-thread kernel publishes in mapped host memory ("host_poll"; round 6) -- the results are there when it
+    returns, from several threads on ONE stream too, and with the key off it waits in the runtime as before."""
+    import ctypes as C
+    import threading
+    lib = hx.lib
+    n, q = 4096, int(ho.generate_primes(1, 49, True, 4096)[0])
+    ntt, ont = hx.NTT(n, q), ho.NTT(n, q)
+    st = C.c_void_p()
+    assert lib.hexl_amd_stream_create(C.byref(st), -1) == 0
+    x = ho.fill_splitmix(n, 3, q)
+    want = ont.forward(x, 1, 1)
+    bufs = []
+    for _ in range(4):
+        d = C.c_void_p()
+        assert lib.hexl_amd_device_alloc(C.byref(d), n * 8, -1) == 0
+        bufs.append(d)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    try:
+        for poll in (1, 0):
+            hx.set_tuning("host_poll", poll)
+            before = hx.get_counter("host_polls")
+            for _ in range(20):
+                assert lib.hexl_amd_copy(bufs[0], p(x), n * 8, st, 0) == 0
+                assert lib.hexl_amd_ntt_forward(ntt._h, bufs[0], bufs[0], 1, 1, 1, st) == 0
+                back = np.zeros_like(x)
+                assert lib.hexl_amd_copy(p(back), bufs[0], n * 8, st, 0) == 0
+                assert lib.hexl_amd_synchronize(st) == 0
+                assert np.array_equal(back, want)
+            assert (hx.get_counter("host_polls") - before >= 20) == bool(poll)
+        hx.set_tuning("host_poll", 1)
+        errors = []
+
+        def worker(t):
+            mine = np.zeros_like(x)
+            for k in range(100):
+                if lib.hexl_amd_copy(bufs[t], p(x), n * 8, st, 0) or \
+                        lib.hexl_amd_ntt_forward(ntt._h, bufs[t], bufs[t], 1, 1, 1, st) or \
+                        lib.hexl_amd_copy(p(mine), bufs[t], n * 8, st, 0) or lib.hexl_amd_synchronize(st):
+                    errors.append((t, k, "rc"))
+                    return
+                if not np.array_equal(mine, want):
+                    errors.append((t, k, "result"))
+                    return
+        ts = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errors, errors[:3]
+    finally:
+        hx.set_tuning("host_poll", 1)
+        assert lib.hexl_amd_stream_destroy(st) == 0
+        for d in bufs:
+            assert lib.hexl_amd_device_free(d) == 0
+
+
 def test_ntt_config1_on_the_hip_path(hx, ho):
     """BASELINE configs[0] at its exact parameters on the GPU: N = 1024, q = 0xffffee001
     (36-bit), ONE polynomial, seed 1, Fwd(1,1) + Inv(1,1) against the oracle; the plan picks

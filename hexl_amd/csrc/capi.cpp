@@ -1749,14 +1749,35 @@ int hexl_amd_dyadic_multiply_host(uint64_t* result, const uint64_t* operand1,
   int device = 0;
   HX_HIP(hipGetDevice(&device));
   const size_t poly = (size_t)n * num_moduli * sizeof(u64);
+  const int k1 = pointer_kind(operand1, nullptr), k2 = pointer_kind(operand2, nullptr),
+            kr = pointer_kind(result, nullptr);
+  if (k1 == 0 && k2 == 0 && kr == 0 && 7 * poly <= host_bounce_max_bytes()) {
+    // Small call, ordinary host memory on every side: the operands are copied into the thread's pinned,
+    // device-mapped bounce buffer, the kernel runs on it over the link, the call's end is polled
+    // (ntt_run_host; n = 4096 x 2 moduli: 76 -> ~30 us against four staged copies).  Layout as below.
+    if (int rc = g_staging.ensure(device, 8)) return rc;  // (the stream)
+    if (int rc = g_staging.ensure_bounce(7 * poly)) return rc;
+    u64* hx_ = (u64*)g_staging.bounce;
+    u64* dxb = (u64*)g_staging.bounce_dev;
+    const size_t w = (size_t)n * num_moduli;
+    memcpy(hx_, operand1, 2 * poly);
+    memcpy(hx_ + 2 * w, operand2, 2 * poly);
+    // (coefficients the reference leaves untouched -- n > 512 not a multiple of 512 -- keep what the
+    // caller's result buffer holds)
+    if (n > 512 && (n & 511) != 0) memcpy(hx_ + 4 * w, result, 3 * poly);
+    hipError_t e = dyadic_multiply_launch(dxb + 4 * w, dxb, dxb + 2 * w, n, moduli, num_moduli, 1,
+                                          g_staging.stream);
+    if (e != hipSuccess) return hip_fail(e, "dyadic multiply launch");
+    if (int rc = g_staging.finish(g_staging.stream)) return rc;
+    memcpy(result, hx_ + 4 * w, 3 * poly);
+    return HEXL_AMD_OK;
+  }
   // layout of the staging buffer: x (2 polys) | y (2 polys) | result (3 polys)
   if (int rc = g_staging.ensure(device, 7 * poly)) return rc;
   u64* dx = (u64*)g_staging.buf;
   u64* dy = dx + 2 * n * num_moduli;
   u64* dr = dy + 2 * n * num_moduli;
   hipStream_t st = g_staging.stream;
-  const int k1 = pointer_kind(operand1, nullptr), k2 = pointer_kind(operand2, nullptr),
-            kr = pointer_kind(result, nullptr);
   if (int rc = copy_to_device(dx, operand1, 2 * poly, k1, st)) return rc;
   if (int rc = copy_to_device(dy, operand2, 2 * poly, k2, st)) return rc;
   // coefficients the reference leaves untouched (n > 512 not a multiple of 512) keep

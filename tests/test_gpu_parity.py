@@ -1531,6 +1531,33 @@ def test_dyadic_multiply_random_vs_oracle(hx, ho, n, num_moduli):
     assert np.array_equal(host(hx, buf), want_inplace)
 
 
+@pytest.mark.parametrize("n,num_moduli", [(4, 1), (512, 3), (600, 2), (1024, 1), (4096, 2), (8192, 1), (8192, 2)])
+def test_dyadic_multiply_host_small_calls(hx, ho, n, num_moduli):
+    """hexl_amd_dyadic_multiply_host on ordinary host memory, both sides of the bounce limit (round 6: calls of
+    up to 512 KiB in + out run on the thread's pinned mapped bounce buffer and end on the polled flag; larger ones are
+    staged), coefficients beyond the last whole 512-tile left as the caller's result buffer had them
+    (dyadic-multiply-internal.cpp:33-34), with the bounce route on and off."""
+    import ctypes as C
+    rng = np.random.default_rng(7 * n + num_moduli)
+    pool = [int(q) for bits in (30, 45, 54, 61) for q in ho.generate_primes(3, bits, True, 8192)]
+    moduli = pool[:num_moduli]
+    x = np.concatenate([rng.integers(0, q, n, dtype=np.uint64) for q in moduli] * 2)
+    y = np.concatenate([rng.integers(0, q, n, dtype=np.uint64) for q in moduli] * 2)
+    want = ho.dyadic_multiply(x, y, n, moduli, result=np.full(3 * x.size // 2, 5, dtype=np.uint64))
+    mod = (C.c_uint64 * num_moduli)(*moduli)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    try:
+        for kb in (512, 0):
+            hx.set_tuning("host_bounce_kb", kb)
+            out = np.full(3 * x.size // 2, 5, dtype=np.uint64)
+            x0, y0 = x.copy(), y.copy()
+            assert hx.lib.hexl_amd_dyadic_multiply_host(p(out), p(x0), p(y0), n, mod, num_moduli) == 0
+            assert np.array_equal(out, want), kb
+            assert np.array_equal(x0, x) and np.array_equal(y0, y)
+    finally:
+        hx.set_tuning("host_bounce_kb", 512)
+
+
 def test_dyadic_multiply_rejects_bad_arguments(hx):
     d = dev(hx, [1, 2, 3, 4, 5, 6, 0, 0, 0])
     with pytest.raises(hx.HexlAmdError):
